@@ -1,0 +1,111 @@
+"""ctypes binding of libdescriptools_hip.so (include/descriptools_hip.h).
+
+The HIP library is the only compute path: if it cannot be loaded (or built) every descriptor call
+raises -- there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libdescriptools_hip.so")
+_lib = None
+
+c_f32p = C.POINTER(C.c_float)
+c_f64p = C.POINTER(C.c_double)
+c_u8p = C.POINTER(C.c_uint8)
+c_i8p = C.POINTER(C.c_int8)
+c_i32p = C.POINTER(C.c_int32)
+c_i64p = C.POINTER(C.c_int64)
+i64, f64, u32, ci = C.c_int64, C.c_double, C.c_uint32, C.c_int
+vp = C.c_void_p
+
+_SIGS = {
+    "dt_last_error": (C.c_char_p, []),
+    "dt_version": (C.c_char_p, []),
+    "dt_device_count": (ci, []),
+    "dt_ctx_create": (ci, [ci, vp, C.POINTER(vp)]),
+    "dt_ctx_destroy": (ci, [vp]),
+    "dt_ctx_set_stream": (ci, [vp, vp]),
+    "dt_ctx_stream": (vp, [vp]),
+    "dt_ctx_sync": (ci, [vp]),
+    "dt_ctx_scratch_bytes": (i64, [vp]),
+    # host tier
+    "dt_slope_f32": (ci, [c_f32p, i64, i64, f64, c_f32p]),
+    "dt_d8_f32": (ci, [c_f32p, i64, i64, f64, c_u8p, c_f32p]),
+    "dt_flowacc_u8": (ci, [c_u8p, c_f32p, i64, i64, c_i64p]),
+    "dt_flowhand": (ci, [c_f32p, c_u8p, c_i8p, i64, i64, f64, c_f32p, c_i64p, c_f32p]),
+    "dt_hand_f32": (ci, [c_f32p, c_i64p, i64, c_f32p]),
+    "dt_twi": (ci, [c_i64p, c_f32p, i64, f64, f64, c_f32p, c_f32p]),
+    "dt_river_accumulation": (ci, [c_i64p, c_i64p, i64, c_i64p]),
+    "dt_gfi_area": (ci, [c_f32p, c_i64p, i64, f64, f64, f64, ci, c_f32p]),
+    "dt_gfi": (ci, [c_f32p, c_i64p, c_i64p, i64, f64, f64, f64, c_f32p]),
+    "dt_lnhlh": (ci, [c_f32p, c_i64p, i64, f64, f64, f64, c_f32p]),
+    "dt_downslope": (ci, [c_f32p, c_u8p, i64, i64, f64, f64, ci, c_f32p]),
+    "dt_confusion_multi": (ci, [c_f64p, c_i8p, i64, f64, c_f64p, ci, ci, c_i64p]),
+    "dt_synth_dem": (ci, [u32, i64, i64, i64, i64, i64, i64, ci, c_f32p]),
+    # device tier
+    "dt_dev_malloc": (ci, [vp, i64, C.POINTER(vp)]),
+    "dt_dev_free": (ci, [vp, vp]),
+    "dt_dev_h2d": (ci, [vp, vp, vp, i64]),
+    "dt_dev_d2h": (ci, [vp, vp, vp, i64]),
+    "dt_dev_synth_dem": (ci, [vp, u32, i64, i64, i64, i64, i64, i64, ci, vp]),
+    "dt_dev_slope_d8": (ci, [vp, vp, i64, i64, f64, vp, vp, vp]),
+    "dt_dev_slope_twi": (ci, [vp, vp, vp, i64, i64, f64, f64, vp, vp, vp, vp]),
+    "dt_dev_flowacc": (ci, [vp, vp, vp, i64, i64, vp]),
+    "dt_dev_river_mask": (ci, [vp, vp, i64, i64, vp]),
+    "dt_dev_flowhand": (ci, [vp, vp, vp, vp, vp, i64, i64, f64, vp, vp, vp, vp]),
+    "dt_dev_twi": (ci, [vp, vp, vp, i64, f64, f64, vp, vp]),
+    "dt_dev_gfi": (ci, [vp, vp, vp, i64, f64, f64, f64, vp]),
+    "dt_dev_lnhlh": (ci, [vp, vp, vp, i64, f64, f64, f64, vp]),
+    "dt_dev_downslope": (ci, [vp, vp, vp, i64, i64, f64, f64, ci, vp]),
+    "dt_dev_confusion_multi": (ci, [vp, vp, vp, i64, f64, c_f64p, ci, ci, vp]),
+    "dt_dev_i32_to_i64": (ci, [vp, vp, i64, vp]),
+    "dt_dev_i64_to_i32": (ci, [vp, vp, i64, vp]),
+}
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def lib():
+    """Load (building in-tree if the .so is missing) the HIP library; raises if impossible."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        from . import build as _build  # hipcc cross-compiles; raises CalledProcessError on failure
+        _build.build()
+    try:
+        L = C.CDLL(_SO)
+    except OSError as e:  # pragma: no cover
+        raise RuntimeError("descriptools_amd: cannot load %s (%s); the HIP library is required, "
+                           "there is no CPU fallback" % (_SO, e))
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(L, name)  # AttributeError here = header / library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().dt_last_error().decode("utf-8", "replace")
+        raise RuntimeError("descriptools_hip error %d: %s" % (rc, msg))
+
+
+def ptr(a, ct):
+    return a.ctypes.data_as(ct) if a is not None else None
+
+
+def as_c(a, dtype):
+    """C-contiguous array of `dtype` (no copy when already so)."""
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def dem_f32(dem):
+    """DEM / HAND at the boundary: float32 (exact for int16 and for float32 input)."""
+    return np.ascontiguousarray(dem, dtype=np.float32)

@@ -1,0 +1,78 @@
+"""Device-resident descriptor chain (net-new, additive): slope -> D8 -> flow accumulation -> river
+mask -> flow distance / river index / HAND -> TI / MTI -> GFI -> ln(hl/H) -> downslope, every raster
+staying in HBM between steps (the reference round-trips each descriptor through the host,
+Example/example.py:59-91).  Parameters default to the example's (n_top 0.1, n_gfi 0.4, b 0.1, dz 5)."""
+import numpy as np
+
+from . import _lib
+from ._lib import check
+from .device import Context
+
+F32, U8, I8, I32 = np.float32, np.uint8, np.int8, np.int32
+
+OUTPUTS = (("slope", F32), ("fdr", U8), ("fac", I32), ("river", I8), ("fdist", F32), ("idx", I32),
+           ("hand", F32), ("a_river", I32), ("slope_rad", F32), ("ti", F32), ("mti", F32), ("gfi", F32),
+           ("lnhlh", F32), ("down", F32))
+
+# Unfused algorithmic bytes per cell of the chain: slope 8, D8 5, flow-acc 5, river
+# mask 5, HAND 18, TI+MTI 16, GFI 12, ln(hl/H) 12, downslope 9.
+ALGO_BYTES_PER_CELL = 90
+
+
+class Chain:
+    """Owns the output rasters of one H x W tile on one device."""
+
+    def __init__(self, H, W, ctx=None, px=10.0, n_top=0.1, n_gfi=0.4, b=0.1, dz=5.0,
+                 river_threshold=None, alloc=None):
+        self.H, self.W, self.N = int(H), int(W), int(H) * int(W)
+        self.ctx = ctx or Context()
+        self.px, self.n_top, self.n_gfi, self.b, self.dz = px, n_top, n_gfi, b, dz
+        self.river_threshold = self.N // 512 if river_threshold is None else int(river_threshold)
+        self.buf = {}
+        for name, dt in OUTPUTS:
+            self.buf[name] = alloc((H, W), dt) if alloc else self.ctx.empty((H, W), dt)
+
+    def p(self, name):
+        b = self.buf[name]
+        return b.ptr if hasattr(b, "ptr") else b
+
+    def run(self, dem_ptr):
+        """Enqueue the whole chain on the context's stream (asynchronous)."""
+        L, c, H, W, N = _lib.lib(), self.ctx.h, self.H, self.W, self.N
+        p = self.p
+        check(L.dt_dev_slope_d8(c, dem_ptr, H, W, self.px, None, p("fdr"), None))
+        check(L.dt_dev_flowacc(c, p("fdr"), dem_ptr, H, W, p("fac")))
+        check(L.dt_dev_river_mask(c, p("fac"), N, self.river_threshold, p("river")))
+        check(L.dt_dev_flowhand(c, dem_ptr, p("fdr"), p("river"), p("fac"), H, W, self.px, p("fdist"),
+                                p("idx"), p("hand"), p("a_river")))
+        check(L.dt_dev_slope_twi(c, dem_ptr, p("fac"), H, W, self.px, self.n_top, p("slope"),
+                                 p("slope_rad"), p("ti"), p("mti")))
+        check(L.dt_dev_gfi(c, p("hand"), p("a_river"), N, self.n_gfi, self.b, self.px, p("gfi")))
+        check(L.dt_dev_lnhlh(c, p("hand"), p("fac"), N, self.n_gfi, self.b, self.px, p("lnhlh")))
+        check(L.dt_dev_downslope(c, dem_ptr, p("fdr"), H, W, self.px, self.dz, 0, p("down")))
+
+    def free(self):
+        for b in self.buf.values():
+            if hasattr(b, "free"):
+                b.free()
+        self.buf = {}
+
+
+def run_host(dem, px, **kw):
+    """Convenience: host DEM in, dict of host rasters out (fac / idx widened to int64)."""
+    dem32 = _lib.dem_f32(dem)
+    H, W = dem32.shape
+    ctx = Context()
+    ch = Chain(H, W, ctx=ctx, px=px, **kw)
+    d_dem = ctx.to_device(dem32)
+    try:
+        ch.run(d_dem.ptr)
+        ctx.sync()
+        out = {k: ch.buf[k].to_host() for k, _ in OUTPUTS}
+    finally:
+        d_dem.free()
+        ch.free()
+        ctx.close()
+    out["fac"] = out["fac"].astype(np.int64)
+    out["idx"] = out["idx"].astype(np.int64)
+    return out

@@ -1,0 +1,577 @@
+// dt_capi.hip -- extern "C" boundary of libdescriptools_hip.so (see include/descriptools_hip.h).
+#include <stdarg.h>
+
+#include <mutex>
+
+#include "dt_common.h"
+#include "dt_kernels.h"
+
+// ---- errors -----------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void dt_set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char *dt_last_error(void) { return g_err; }
+extern "C" const char *dt_version(void) { return "descriptools_hip 0.1 (gfx950)"; }
+
+extern "C" int dt_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+// ---- context ----------------------------------------------------------------------------------
+extern "C" int dt_ctx_create(int device, void *stream, dt_ctx **out) {
+  DT_REQUIRE(out != nullptr, "out is NULL");
+  int n = dt_device_count();
+  if (n <= 0) {
+    dt_set_error("no HIP device visible");
+    return DT_ENODEV;
+  }
+  DT_REQUIRE(device >= 0 && device < n, "device index out of range");
+  DT_HIP(hipSetDevice(device));
+  dt_ctx *c = new dt_ctx();
+  c->device = device;
+  c->scratch = nullptr;
+  c->scratch_bytes = 0;
+  c->scratch_used = 0;
+  if (stream) {
+    c->stream = (hipStream_t)stream;
+    c->own_stream = false;
+  } else {
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      dt_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+      delete c;
+      return DT_EHIP;
+    }
+    c->own_stream = true;
+  }
+  *out = c;
+  return DT_OK;
+}
+
+extern "C" int dt_ctx_destroy(dt_ctx *c) {
+  if (!c) return DT_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  if (c->scratch) (void)hipFree(c->scratch);
+  if (c->own_stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return DT_OK;
+}
+
+extern "C" int dt_ctx_set_stream(dt_ctx *c, void *stream) {
+  DT_REQUIRE(c != nullptr, "ctx is NULL");
+  DT_HIP(hipStreamSynchronize(c->stream));
+  if (c->own_stream) DT_HIP(hipStreamDestroy(c->stream));
+  if (stream) {
+    c->stream = (hipStream_t)stream;
+    c->own_stream = false;
+  } else {
+    DT_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+  }
+  return DT_OK;
+}
+extern "C" void *dt_ctx_stream(dt_ctx *c) { return c ? (void *)c->stream : nullptr; }
+extern "C" int dt_ctx_sync(dt_ctx *c) {
+  DT_REQUIRE(c != nullptr, "ctx is NULL");
+  DT_HIP(hipStreamSynchronize(c->stream));
+  return DT_OK;
+}
+extern "C" int64_t dt_ctx_scratch_bytes(dt_ctx *c) { return c ? (int64_t)c->scratch_bytes : 0; }
+
+int dt_scratch_reset(dt_ctx *c, size_t total) {
+  total = dt_align256(total) + 256;
+  if (total > c->scratch_bytes) {
+    // earlier work on the stream may still use the old block
+    DT_HIP(hipStreamSynchronize(c->stream));
+    if (c->scratch) DT_HIP(hipFree(c->scratch));
+    c->scratch = nullptr;
+    c->scratch_bytes = 0;
+    DT_HIP(hipMalloc((void **)&c->scratch, total));
+    c->scratch_bytes = total;
+  }
+  c->scratch_used = 0;
+  return DT_OK;
+}
+void *dt_scratch_take(dt_ctx *c, size_t bytes) {
+  size_t off = c->scratch_used;
+  c->scratch_used += dt_align256(bytes);
+  if (c->scratch_used > c->scratch_bytes) return nullptr;
+  return c->scratch + off;
+}
+
+#define DT_CTX(c)                            \
+  DT_REQUIRE((c) != nullptr, "ctx is NULL"); \
+  DT_HIP(hipSetDevice((c)->device))
+
+static int dt_check_hw(int64_t H, int64_t W) {
+  DT_REQUIRE(H >= 0 && W >= 0, "negative raster shape");
+  DT_REQUIRE(H * W < (1ll << 31), "rasters of >= 2^31 cells must be tiled (one tile per GPU)");
+  return DT_OK;
+}
+
+// ---- device tier ------------------------------------------------------------------------------
+extern "C" int dt_dev_malloc(dt_ctx *c, int64_t bytes, void **out) {
+  DT_CTX(c);
+  DT_REQUIRE(out && bytes >= 0, "bad arguments");
+  *out = nullptr;
+  DT_HIP(hipMalloc(out, bytes > 0 ? (size_t)bytes : 16));
+  return DT_OK;
+}
+extern "C" int dt_dev_free(dt_ctx *c, void *p) {
+  DT_CTX(c);
+  if (!p) return DT_OK;
+  DT_HIP(hipStreamSynchronize(c->stream));
+  DT_HIP(hipFree(p));
+  return DT_OK;
+}
+extern "C" int dt_dev_h2d(dt_ctx *c, void *dst, const void *src, int64_t bytes) {
+  DT_CTX(c);
+  if (bytes <= 0) return DT_OK;
+  DT_REQUIRE(dst && src, "NULL pointer");
+  DT_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+  DT_HIP(hipStreamSynchronize(c->stream));
+  return DT_OK;
+}
+extern "C" int dt_dev_d2h(dt_ctx *c, void *dst, const void *src, int64_t bytes) {
+  DT_CTX(c);
+  if (bytes <= 0) return DT_OK;
+  DT_REQUIRE(dst && src, "NULL pointer");
+  DT_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
+  DT_HIP(hipStreamSynchronize(c->stream));
+  return DT_OK;
+}
+
+extern "C" int dt_dev_slope_twi(dt_ctx *c, const float *dem, const int32_t *acc32, int64_t H, int64_t W,
+                                double px, double n_top, float *slope, float *slope_rad, float *ti,
+                                float *mti) {
+  DT_CTX(c);
+  DT_TRY(dt_check_hw(H, W));
+  DT_REQUIRE((dem && acc32 && ti && mti) || H * W == 0, "NULL raster");
+  DT_TRY(dt_launch_stencil(c->stream, dem, H, W, px, slope, nullptr, slope_rad, acc32, n_top, ti, mti));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+
+static int synth_octaves(int64_t Hg, int64_t Wg) {
+  int64_t m = Hg < Wg ? Hg : Wg;
+  int lg = 0;
+  while ((m >> (lg + 1)) > 0) lg++;
+  int O = lg - 2;
+  if (O < 5) O = 5;
+  if (O > 14) O = 14;
+  return O;
+}
+
+extern "C" int dt_dev_synth_dem(dt_ctx *c, uint32_t seed, int64_t Hg, int64_t Wg, int64_t y0,
+                                int64_t x0, int64_t h, int64_t w, int nodata_pct, float *out) {
+  DT_CTX(c);
+  DT_REQUIRE(out || h * w == 0, "out is NULL");
+  DT_REQUIRE(Hg > 0 && Wg > 0 && h >= 0 && w >= 0, "bad shape");
+  DT_TRY(dt_launch_synth_dem(c->stream, seed, synth_octaves(Hg, Wg), Hg, y0, x0, h, w, nodata_pct, out));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+
+extern "C" int dt_dev_slope_d8(dt_ctx *c, const float *dem, int64_t H, int64_t W, double px,
+                               float *slope, uint8_t *fdr, float *slope_rad) {
+  DT_CTX(c);
+  DT_TRY(dt_check_hw(H, W));
+  DT_REQUIRE(dem || H * W == 0, "dem is NULL");
+  DT_REQUIRE(slope || fdr || slope_rad, "no output requested");
+  DT_TRY(dt_launch_stencil(c->stream, dem, H, W, px, slope, fdr, slope_rad, nullptr, 0.0, nullptr, nullptr));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+
+extern "C" int dt_dev_flowacc(dt_ctx *c, const uint8_t *fdr, const float *dem, int64_t H, int64_t W,
+                              int32_t *acc32) {
+  DT_CTX(c);
+  DT_TRY(dt_check_hw(H, W));
+  DT_REQUIRE((fdr && acc32) || H * W == 0, "NULL raster");
+  DT_TRY(dt_scratch_reset(c, (size_t)H * W * 8));
+  unsigned long long *state = (unsigned long long *)dt_scratch_take(c, (size_t)H * W * 8);
+  DT_TRY(dt_launch_flowacc(c->stream, fdr, dem, H, W, state, acc32));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+
+extern "C" int dt_dev_river_mask(dt_ctx *c, const int32_t *acc32, int64_t N, int64_t threshold,
+                                 int8_t *river) {
+  DT_CTX(c);
+  DT_REQUIRE((acc32 && river) || N == 0, "NULL raster");
+  DT_TRY(dt_launch_river_mask(c->stream, acc32, N, threshold, river));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+
+extern "C" int dt_dev_flowhand(dt_ctx *c, const float *dem, const uint8_t *fdr, const int8_t *river,
+                               const int32_t *acc32, int64_t H, int64_t W, double px, float *fdist,
+                               int32_t *idx32, float *hand, int32_t *a_river) {
+  DT_CTX(c);
+  DT_TRY(dt_check_hw(H, W));
+  DT_REQUIRE((fdr && river) || H * W == 0, "NULL raster");
+  DT_REQUIRE(!hand || dem, "hand needs dem");
+  DT_REQUIRE(!a_river || acc32, "a_river needs acc32");
+  DT_TRY(dt_scratch_reset(c, (size_t)H * W * 8));
+  unsigned long long *state = (unsigned long long *)dt_scratch_take(c, (size_t)H * W * 8);
+  DT_TRY(dt_launch_flowhand(c->stream, dem, fdr, river, acc32, H, W, px, state, fdist, idx32, hand, a_river));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+
+extern "C" int dt_dev_twi(dt_ctx *c, const int32_t *acc32, const float *slope_rad, int64_t N, double px,
+                          double n_top, float *ti, float *mti) {
+  DT_CTX(c);
+  DT_REQUIRE((acc32 && slope_rad && ti && mti) || N == 0, "NULL raster");
+  DT_TRY(dt_launch_twi(c->stream, acc32, slope_rad, N, px, n_top, ti, mti));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+
+extern "C" int dt_dev_gfi(dt_ctx *c, const float *hand, const int32_t *a_river, int64_t N, double n_gfi,
+                          double b, double size, float *gfi) {
+  DT_CTX(c);
+  DT_REQUIRE((hand && a_river && gfi) || N == 0, "NULL raster");
+  DT_TRY(dt_launch_gfi(c->stream, hand, a_river, N, n_gfi, b, size, gfi, 0));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+
+extern "C" int dt_dev_lnhlh(dt_ctx *c, const float *hand, const int32_t *acc32, int64_t N, double n_gfi,
+                            double b, double size, float *out) {
+  DT_CTX(c);
+  DT_REQUIRE((hand && acc32 && out) || N == 0, "NULL raster");
+  DT_TRY(dt_launch_gfi(c->stream, hand, acc32, N, n_gfi, b, size, out, 1));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+
+extern "C" int dt_dev_downslope(dt_ctx *c, const float *dem, const uint8_t *fdr, int64_t H, int64_t W,
+                                double px, double dz, int raw, float *out) {
+  DT_CTX(c);
+  DT_TRY(dt_check_hw(H, W));
+  DT_REQUIRE((dem && fdr && out) || H * W == 0, "NULL raster");
+  DT_TRY(dt_launch_downslope(c->stream, dem, fdr, H, W, px, dz, raw, out));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+
+extern "C" int dt_dev_confusion_multi(dt_ctx *c, const double *desc, const int8_t *flood, int64_t N,
+                                      double nodata_value, const double *th_host, int nth, int under,
+                                      int64_t *counts4_dev) {
+  DT_CTX(c);
+  DT_REQUIRE(th_host && counts4_dev, "NULL thresholds / counts");
+  DT_REQUIRE((desc && flood) || N == 0, "NULL raster");
+  DT_TRY(dt_launch_confusion(c->stream, desc, flood, N, nodata_value, th_host, nth, under,
+                             (unsigned long long *)counts4_dev));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+
+extern "C" int dt_dev_i32_to_i64(dt_ctx *c, const int32_t *src, int64_t N, int64_t *dst) {
+  DT_CTX(c);
+  DT_TRY(dt_launch_i32_to_i64(c->stream, src, N, dst));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+extern "C" int dt_dev_i64_to_i32(dt_ctx *c, const int64_t *src, int64_t N, int32_t *dst) {
+  DT_CTX(c);
+  DT_TRY(dt_launch_i64_to_i32(c->stream, src, N, dst));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+
+// ---- host tier: H2D, kernels, D2H on a process-wide default context ----------------------------
+static dt_ctx *g_host_ctx = nullptr;
+static std::mutex g_host_mu;  // whole-call granularity, as SURVEY.md 8b (threading) allows
+
+static int host_ctx(dt_ctx **out) {
+  if (!g_host_ctx) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    DT_TRY(dt_ctx_create(dev, nullptr, &g_host_ctx));
+  }
+  *out = g_host_ctx;
+  return hipSetDevice(g_host_ctx->device) == hipSuccess ? DT_OK : DT_EHIP;
+}
+
+// RAII device buffer
+struct DevBuf {
+  void *p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  int alloc(size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    DT_HIP(hipMalloc(&p, bytes));
+    return DT_OK;
+  }
+  template <typename T>
+  T *as() {
+    return (T *)p;
+  }
+};
+#define H2D(dst, src, bytes, c) DT_HIP(hipMemcpyAsync((dst).p, (src), (bytes), hipMemcpyHostToDevice, (c)->stream))
+#define D2H(dst, src, bytes, c) DT_HIP(hipMemcpyAsync((dst), (src).p, (bytes), hipMemcpyDeviceToHost, (c)->stream))
+
+extern "C" int dt_synth_dem(uint32_t seed, int64_t Hg, int64_t Wg, int64_t y0, int64_t x0, int64_t h,
+                            int64_t w, int nodata_pct, float *out) {
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  dt_ctx *c;
+  DT_TRY(host_ctx(&c));
+  size_t n = (size_t)h * w;
+  DevBuf d;
+  DT_TRY(d.alloc(n * 4));
+  DT_TRY(dt_dev_synth_dem(c, seed, Hg, Wg, y0, x0, h, w, nodata_pct, d.as<float>()));
+  D2H(out, d, n * 4, c);
+  return dt_ctx_sync(c);
+}
+
+static int host_slope_d8(const float *dem, int64_t H, int64_t W, double px, float *slope, uint8_t *fdr) {
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  dt_ctx *c;
+  DT_TRY(host_ctx(&c));
+  DT_TRY(dt_check_hw(H, W));
+  DT_REQUIRE(dem || H * W == 0, "dem is NULL");
+  size_t n = (size_t)H * W;
+  if (n == 0) return DT_OK;
+  DevBuf d_dem, d_sl, d_f;
+  DT_TRY(d_dem.alloc(n * 4));
+  if (slope) DT_TRY(d_sl.alloc(n * 4));
+  if (fdr) DT_TRY(d_f.alloc(n));
+  H2D(d_dem, dem, n * 4, c);
+  DT_TRY(dt_dev_slope_d8(c, d_dem.as<float>(), H, W, px, slope ? d_sl.as<float>() : nullptr,
+                         fdr ? d_f.as<uint8_t>() : nullptr, nullptr));
+  if (slope) D2H(slope, d_sl, n * 4, c);
+  if (fdr) D2H(fdr, d_f, n, c);
+  return dt_ctx_sync(c);
+}
+
+extern "C" int dt_slope_f32(const float *dem, int64_t H, int64_t W, double px, float *slope) {
+  DT_REQUIRE(slope || H * W == 0, "slope is NULL");
+  return host_slope_d8(dem, H, W, px, slope, nullptr);
+}
+extern "C" int dt_d8_f32(const float *dem, int64_t H, int64_t W, double px, uint8_t *fdr, float *slope) {
+  DT_REQUIRE(fdr || H * W == 0, "fdr is NULL");
+  return host_slope_d8(dem, H, W, px, slope, fdr);
+}
+
+extern "C" int dt_flowacc_u8(const uint8_t *fdr, const float *dem, int64_t H, int64_t W, int64_t *acc) {
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  dt_ctx *c;
+  DT_TRY(host_ctx(&c));
+  DT_TRY(dt_check_hw(H, W));
+  size_t n = (size_t)H * W;
+  if (n == 0) return DT_OK;
+  DT_REQUIRE(fdr && acc, "NULL raster");
+  DevBuf d_f, d_dem, d_a32, d_a64;
+  DT_TRY(d_f.alloc(n));
+  DT_TRY(d_a32.alloc(n * 4));
+  DT_TRY(d_a64.alloc(n * 8));
+  H2D(d_f, fdr, n, c);
+  if (dem) {
+    DT_TRY(d_dem.alloc(n * 4));
+    H2D(d_dem, dem, n * 4, c);
+  }
+  DT_TRY(dt_dev_flowacc(c, d_f.as<uint8_t>(), dem ? d_dem.as<float>() : nullptr, H, W, d_a32.as<int32_t>()));
+  DT_TRY(dt_dev_i32_to_i64(c, d_a32.as<int32_t>(), (int64_t)n, d_a64.as<int64_t>()));
+  D2H(acc, d_a64, n * 8, c);
+  return dt_ctx_sync(c);
+}
+
+extern "C" int dt_flowhand(const float *dem, const uint8_t *fdr, const int8_t *river, int64_t H, int64_t W,
+                           double px, float *fdist, int64_t *idx, float *hand) {
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  dt_ctx *c;
+  DT_TRY(host_ctx(&c));
+  DT_TRY(dt_check_hw(H, W));
+  size_t n = (size_t)H * W;
+  if (n == 0) return DT_OK;
+  DT_REQUIRE(fdr && river, "NULL raster");
+  DT_REQUIRE(!hand || dem, "hand needs dem");
+  DevBuf d_dem, d_f, d_r, d_fd, d_i32, d_i64, d_h;
+  DT_TRY(d_f.alloc(n));
+  DT_TRY(d_r.alloc(n));
+  H2D(d_f, fdr, n, c);
+  H2D(d_r, river, n, c);
+  if (hand) {
+    DT_TRY(d_dem.alloc(n * 4));
+    H2D(d_dem, dem, n * 4, c);
+    DT_TRY(d_h.alloc(n * 4));
+  }
+  if (fdist) DT_TRY(d_fd.alloc(n * 4));
+  if (idx) {
+    DT_TRY(d_i32.alloc(n * 4));
+    DT_TRY(d_i64.alloc(n * 8));
+  }
+  DT_TRY(dt_dev_flowhand(c, hand ? d_dem.as<float>() : nullptr, d_f.as<uint8_t>(), d_r.as<int8_t>(), nullptr, H,
+                         W, px, fdist ? d_fd.as<float>() : nullptr, idx ? d_i32.as<int32_t>() : nullptr,
+                         hand ? d_h.as<float>() : nullptr, nullptr));
+  if (idx) {
+    DT_TRY(dt_dev_i32_to_i64(c, d_i32.as<int32_t>(), (int64_t)n, d_i64.as<int64_t>()));
+    D2H(idx, d_i64, n * 8, c);
+  }
+  if (fdist) D2H(fdist, d_fd, n * 4, c);
+  if (hand) D2H(hand, d_h, n * 4, c);
+  return dt_ctx_sync(c);
+}
+
+extern "C" int dt_twi(const int64_t *fac, const float *slope_rad, int64_t N, double px, double n_top,
+                      float *ti, float *mti) {
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  dt_ctx *c;
+  DT_TRY(host_ctx(&c));
+  DT_REQUIRE(N >= 0, "negative size");
+  if (N == 0) return DT_OK;
+  DT_REQUIRE(fac && slope_rad && ti && mti, "NULL raster");
+  size_t n = (size_t)N;
+  DevBuf d_f, d_s, d_t, d_m;
+  DT_TRY(d_f.alloc(n * 8));
+  DT_TRY(d_s.alloc(n * 4));
+  DT_TRY(d_t.alloc(n * 4));
+  DT_TRY(d_m.alloc(n * 4));
+  H2D(d_f, fac, n * 8, c);
+  H2D(d_s, slope_rad, n * 4, c);
+  DT_TRY(dt_launch_twi_i64(c->stream, d_f.as<int64_t>(), d_s.as<float>(), N, px, n_top, d_t.as<float>(),
+                           d_m.as<float>()));
+  DT_HIP(hipGetLastError());
+  D2H(ti, d_t, n * 4, c);
+  D2H(mti, d_m, n * 4, c);
+  return dt_ctx_sync(c);
+}
+
+extern "C" int dt_river_accumulation(const int64_t *fac, const int64_t *idx, int64_t N, int64_t *out) {
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  dt_ctx *c;
+  DT_TRY(host_ctx(&c));
+  DT_REQUIRE(N >= 0, "negative size");
+  if (N == 0) return DT_OK;
+  DT_REQUIRE(fac && idx && out, "NULL raster");
+  size_t n = (size_t)N;
+  DevBuf d_f, d_i, d_a;
+  DT_TRY(d_f.alloc(n * 8));
+  DT_TRY(d_i.alloc(n * 8));
+  DT_TRY(d_a.alloc(n * 8));
+  H2D(d_f, fac, n * 8, c);
+  H2D(d_i, idx, n * 8, c);
+  DT_TRY(dt_launch_river_acc_i64(c->stream, d_f.as<int64_t>(), d_i.as<int64_t>(), N, d_a.as<int64_t>()));
+  DT_HIP(hipGetLastError());
+  D2H(out, d_a, n * 8, c);
+  return dt_ctx_sync(c);
+}
+
+static int host_gfi(const float *hand, const int64_t *fac, const int64_t *idx, int64_t N, double n_gfi,
+                    double b, double size, float *out, int own_cell) {
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  dt_ctx *c;
+  DT_TRY(host_ctx(&c));
+  DT_REQUIRE(N >= 0, "negative size");
+  if (N == 0) return DT_OK;
+  DT_REQUIRE(hand && fac && out, "NULL raster");
+  size_t n = (size_t)N;
+  DevBuf d_h, d_f, d_i, d_a, d_o;
+  DT_TRY(d_h.alloc(n * 4));
+  DT_TRY(d_f.alloc(n * 8));
+  DT_TRY(d_o.alloc(n * 4));
+  H2D(d_h, hand, n * 4, c);
+  H2D(d_f, fac, n * 8, c);
+  const int64_t *area = d_f.as<int64_t>();
+  if (idx) {
+    DT_TRY(d_i.alloc(n * 8));
+    DT_TRY(d_a.alloc(n * 8));
+    H2D(d_i, idx, n * 8, c);
+    DT_TRY(dt_launch_river_acc_i64(c->stream, d_f.as<int64_t>(), d_i.as<int64_t>(), N, d_a.as<int64_t>()));
+    area = d_a.as<int64_t>();
+  }
+  DT_TRY(dt_launch_gfi_i64(c->stream, d_h.as<float>(), area, N, n_gfi, b, size, d_o.as<float>(), own_cell));
+  DT_HIP(hipGetLastError());
+  D2H(out, d_o, n * 4, c);
+  return dt_ctx_sync(c);
+}
+extern "C" int dt_gfi(const float *hand, const int64_t *fac, const int64_t *idx, int64_t N, double n_gfi,
+                      double b, double size, float *gfi) {
+  DT_REQUIRE(idx || N == 0, "idx is NULL");
+  return host_gfi(hand, fac, idx, N, n_gfi, b, size, gfi, 0);
+}
+extern "C" int dt_lnhlh(const float *hand, const int64_t *fac, int64_t N, double n_gfi, double b, double size,
+                        float *out) {
+  return host_gfi(hand, fac, nullptr, N, n_gfi, b, size, out, 1);
+}
+extern "C" int dt_gfi_area(const float *hand, const int64_t *area, int64_t N, double n_gfi, double b,
+                           double size, int zero_guard, float *out) {
+  return host_gfi(hand, area, nullptr, N, n_gfi, b, size, out, zero_guard ? 1 : 0);
+}
+
+extern "C" int dt_hand_f32(const float *dem, const int64_t *idx, int64_t N, float *hand) {
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  dt_ctx *c;
+  DT_TRY(host_ctx(&c));
+  DT_REQUIRE(N >= 0, "negative size");
+  if (N == 0) return DT_OK;
+  DT_REQUIRE(dem && idx && hand, "NULL raster");
+  size_t n = (size_t)N;
+  DevBuf d_d, d_i, d_h;
+  DT_TRY(d_d.alloc(n * 4));
+  DT_TRY(d_i.alloc(n * 8));
+  DT_TRY(d_h.alloc(n * 4));
+  H2D(d_d, dem, n * 4, c);
+  H2D(d_i, idx, n * 8, c);
+  DT_TRY(dt_launch_hand_i64(c->stream, d_d.as<float>(), d_i.as<int64_t>(), N, d_h.as<float>()));
+  DT_HIP(hipGetLastError());
+  D2H(hand, d_h, n * 4, c);
+  return dt_ctx_sync(c);
+}
+
+extern "C" int dt_downslope(const float *dem, const uint8_t *fdr, int64_t H, int64_t W, double px, double dz,
+                            int raw, float *out) {
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  dt_ctx *c;
+  DT_TRY(host_ctx(&c));
+  DT_TRY(dt_check_hw(H, W));
+  size_t n = (size_t)H * W;
+  if (n == 0) return DT_OK;
+  DT_REQUIRE(dem && fdr && out, "NULL raster");
+  DevBuf d_dem, d_f, d_o;
+  DT_TRY(d_dem.alloc(n * 4));
+  DT_TRY(d_f.alloc(n));
+  DT_TRY(d_o.alloc(n * 4));
+  H2D(d_dem, dem, n * 4, c);
+  H2D(d_f, fdr, n, c);
+  DT_TRY(dt_dev_downslope(c, d_dem.as<float>(), d_f.as<uint8_t>(), H, W, px, dz, raw, d_o.as<float>()));
+  D2H(out, d_o, n * 4, c);
+  return dt_ctx_sync(c);
+}
+
+extern "C" int dt_confusion_multi(const double *desc, const int8_t *flood, int64_t N, double nodata_value,
+                                  const double *th, int nth, int under, int64_t *counts4) {
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  dt_ctx *c;
+  DT_TRY(host_ctx(&c));
+  DT_REQUIRE(N >= 0 && th && counts4 && nth >= 1, "bad arguments");
+  size_t n = (size_t)N;
+  DevBuf d_d, d_f, d_c;
+  DT_TRY(d_d.alloc(n * 8));
+  DT_TRY(d_f.alloc(n));
+  DT_TRY(d_c.alloc(sizeof(int64_t) * 4 * 24));
+  if (n) {
+    H2D(d_d, desc, n * 8, c);
+    H2D(d_f, flood, n, c);
+  }
+  // more than 24 thresholds: several passes over the resident rasters
+  for (int t0 = 0; t0 < nth; t0 += 24) {
+    int k = nth - t0 < 24 ? nth - t0 : 24;
+    DT_TRY(dt_dev_confusion_multi(c, d_d.as<double>(), d_f.as<int8_t>(), N, nodata_value, th + t0, k, under,
+                                  d_c.as<int64_t>()));
+    DT_HIP(hipMemcpyAsync(counts4 + (size_t)t0 * 4, d_c.p, sizeof(int64_t) * 4 * k, hipMemcpyDeviceToHost,
+                          c->stream));
+    DT_HIP(hipStreamSynchronize(c->stream));
+  }
+  return DT_OK;
+}

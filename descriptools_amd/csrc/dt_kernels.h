@@ -1,0 +1,34 @@
+// dt_kernels.h -- launchers implemented in dt_kernels.hip (all asynchronous on `s`).
+#pragma once
+#include "dt_common.h"
+
+int dt_launch_synth_dem(hipStream_t s, uint32_t seed, int O, int64_t Hg, int64_t y0, int64_t x0,
+                        int64_t h, int64_t w, int nodata_pct, float *out);
+int dt_launch_stencil(hipStream_t s, const float *dem, int64_t H, int64_t W, double px, float *slope,
+                      uint8_t *fdr, float *slope_rad, const int32_t *acc32, double n_top, float *ti,
+                      float *mti);
+int dt_launch_flowacc(hipStream_t s, const uint8_t *fdr, const float *dem, int64_t H, int64_t W,
+                      unsigned long long *state, int32_t *acc32);
+int dt_launch_river_mask(hipStream_t s, const int32_t *acc32, int64_t n, int64_t thr, int8_t *river);
+int dt_launch_flowhand(hipStream_t s, const float *dem, const uint8_t *fdr, const int8_t *river,
+                       const int32_t *acc32, int64_t H, int64_t W, double px,
+                       unsigned long long *state, float *fdist, int32_t *idx32, float *hand,
+                       int32_t *a_river);
+int dt_launch_twi(hipStream_t s, const int32_t *acc32, const float *srad, int64_t n, double px,
+                  double n_top, float *ti, float *mti);
+int dt_launch_twi_i64(hipStream_t s, const int64_t *fac, const float *srad, int64_t n, double px,
+                      double n_top, float *ti, float *mti);
+int dt_launch_gfi(hipStream_t s, const float *hand, const int32_t *area, int64_t n, double expo,
+                  double b, double size, float *out, int own_cell);
+int dt_launch_gfi_i64(hipStream_t s, const float *hand, const int64_t *area, int64_t n, double expo,
+                      double b, double size, float *out, int own_cell);
+int dt_launch_river_acc_i64(hipStream_t s, const int64_t *fac, const int64_t *idx, int64_t n,
+                            int64_t *out);
+int dt_launch_downslope(hipStream_t s, const float *dem, const uint8_t *fdr, int64_t H, int64_t W,
+                        double px, double dz, int raw, float *out);
+int dt_launch_hand_i64(hipStream_t s, const float *dem, const int64_t *idx, int64_t n, float *hand);
+int dt_launch_confusion(hipStream_t s, const double *desc, const int8_t *flood, int64_t n,
+                        double nodata, const double *th_host, int nth, int under,
+                        unsigned long long *counts4);
+int dt_launch_i32_to_i64(hipStream_t s, const int32_t *a, int64_t n, int64_t *b);
+int dt_launch_i64_to_i32(hipStream_t s, const int64_t *a, int64_t n, int32_t *b);

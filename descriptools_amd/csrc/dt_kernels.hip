@@ -1,0 +1,800 @@
+// dt_kernels.hip -- hand-written HIP kernels for the descriptools hot path (gfx950 / CDNA4).
+//
+// All kernels are HBM-bound integer / float stencil, streaming or graph-propagation work: no MFMA.
+// Reference citations are file:line relative to /root/reference/descriptools/.
+#include "dt_common.h"
+#include "dt_kernels.h"
+
+// ===========================================================================================
+// Synthetic DEM ("tilted integer fBm") -- integer arithmetic identical to
+// oracle/dt_oracle.c so that CPU and GPU rasters are bit-identical.
+// ===========================================================================================
+#define DT_SYNTH_TILT 64
+#define DT_SYNTH_KMIN 5
+#define DT_SYNTH_SX 4
+__constant__ int32_t c_synth_amp[15] = {0,    0,    0,    0,    0,     256,   445,  776,
+                                        1351, 2352, 4096, 7131, 12416, 21618, 37640};
+
+__device__ __forceinline__ uint32_t dt_hash32(uint32_t seed, uint32_t o, uint32_t ix, uint32_t iy) {
+  uint32_t h = seed * 0x9E3779B1u ^ (o + 1u) * 0x85EBCA77u;
+  h ^= ix * 0xC2B2AE3Du;
+  h = ((h << 13) | (h >> 19)) * 0x27D4EB2Fu;
+  h ^= iy * 0x165667B1u;
+  h = ((h << 13) | (h >> 19)) * 0x9E3779B1u;
+  h ^= h >> 15;
+  h *= 0x85EBCA6Bu;
+  h ^= h >> 13;
+  h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h;
+}
+
+__global__ __launch_bounds__(256) void k_synth_dem(uint32_t seed, int O, int64_t Hg, int64_t y0,
+                                                  int64_t x0, int64_t h, int64_t w, int nodata_pct,
+                                                  float *__restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= h * w) return;
+  int64_t r = i / w, c = i - r * w;
+  int64_t y = y0 + r, x = x0 + c;
+  int64_t z = (int64_t)DT_SYNTH_TILT * (Hg - 1 - y);
+  for (int o = 0; o < O; o++) {
+    int sh = O - o;
+    if (sh < DT_SYNTH_KMIN) break;
+    int shx = sh - DT_SYNTH_SX;
+    uint32_t lx = (uint32_t)(x >> shx), ly = (uint32_t)(y >> sh);
+    uint64_t fx = (uint64_t)(x & ((1 << shx) - 1)) << (16 - shx);
+    uint64_t fy = (uint64_t)(y & ((1 << sh) - 1)) << (16 - sh);
+    uint64_t v00 = dt_hash32(seed, (uint32_t)o, lx, ly) >> 16;
+    uint64_t v10 = dt_hash32(seed, (uint32_t)o, lx + 1, ly) >> 16;
+    uint64_t v01 = dt_hash32(seed, (uint32_t)o, lx, ly + 1) >> 16;
+    uint64_t v11 = dt_hash32(seed, (uint32_t)o, lx + 1, ly + 1) >> 16;
+    uint64_t top = v00 * (65536 - fx) + v10 * fx;
+    uint64_t bot = v01 * (65536 - fx) + v11 * fx;
+    uint64_t val = (top * (65536 - fy) + bot * fy) >> 32;
+    z += (int64_t)((val * (uint64_t)c_synth_amp[sh]) >> 16);
+  }
+  float zf = (float)z * (1.0f / 256.0f);
+  if (nodata_pct > 0) {
+    uint32_t hb = dt_hash32(seed ^ 0xA5A5A5A5u, 77u, (uint32_t)(x >> 5), (uint32_t)(y >> 5));
+    if ((hb % 100u) < (uint32_t)nodata_pct) zf = DT_NODATA;
+  }
+  out[i] = zf;
+}
+
+int dt_launch_synth_dem(hipStream_t s, uint32_t seed, int O, int64_t Hg, int64_t y0, int64_t x0,
+                        int64_t h, int64_t w, int nodata_pct, float *out) {
+  int64_t n = h * w;
+  if (n == 0) return DT_OK;
+  hipLaunchKernelGGL(k_synth_dem, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, seed, O, Hg,
+                     y0, x0, h, w, nodata_pct, out);
+  return DT_OK;
+}
+
+// ===========================================================================================
+// 3x3 stencil: slope (S3, slope.py:210-259) + D8 (N1) + radians + optional fused TI/MTI.
+//
+// Tile = 256 columns x 16 rows per 256-thread workgroup, staged (with a 1-cell halo) through
+// LDS by coalesced 16-byte row loads; thread (tx, ty) then owns a 4-wide x 4-tall patch and
+// reads its 6 x 6 neighbourhood as one ds_read_b128 + two ds_read_b32 per row.  Stores are
+// float4 / uchar4 per row (1 KiB / 256 B contiguous per wave).  Workgroup ids are remapped so
+// that each XCD (ids congruent mod 8 share one) sweeps its own horizontal band of the raster
+// top to bottom: the halo rows shared by vertically adjacent tiles are then re-read from that
+// XCD's L2 instead of HBM.
+//
+// Exactness: the reference compares float64 quotients (z_c - z_nb)/d in scan order
+// NW,N,NE,W,E,SW,S,SE with strict '<'.  Division by a positive constant is monotone and
+// injective on float32 differences, so the maximum over the 4 cardinal (4 diagonal)
+// neighbours is taken on the float32 differences and only the two class maxima are divided
+// in float64 -- bit-identical results with 2 instead of 8 float64 divisions per cell.
+// ===========================================================================================
+#define SD_TX 256
+#define SD_TY 16
+#define SD_LDW (SD_TX + 8)  // LDS row stride in floats; interior starts at column 4
+
+struct SlopeCell {
+  float slope;
+  uint8_t code;
+};
+
+// scan positions: NW0 N1 NE2 W3 E4 SW5 S6 SE7
+__device__ __forceinline__ SlopeCell dt_slope_cell(float c, float nw, float n, float ne, float w,
+                                                  float e, float sw, float s, float se,
+                                                  double inv_unused, double dcard, double ddiag) {
+  (void)inv_unused;
+  SlopeCell r;
+  if (c <= DT_NODATA) {  // slope.py:231
+    r.slope = DT_NODATA;
+    r.code = 0;
+    return r;
+  }
+  // cardinals in scan order N, W, E, S; neighbour == -100 skipped (slope.py:247)
+  float cb = 0.0f, db = 0.0f;
+  int cpos = 8, dpos = 8;
+  uint32_t ccode = 0, dcode = 0;
+#define DT_CAND(nb, best, bcode, bpos, code_, pos_) \
+  {                                                 \
+    float d_ = c - (nb);                            \
+    if ((nb) != DT_NODATA && d_ > best) {           \
+      best = d_;                                    \
+      bcode = code_;                                \
+      bpos = pos_;                                  \
+    }                                               \
+  }
+  DT_CAND(n, cb, ccode, cpos, 64u, 1)
+  DT_CAND(w, cb, ccode, cpos, 16u, 3)
+  DT_CAND(e, cb, ccode, cpos, 1u, 4)
+  DT_CAND(s, cb, ccode, cpos, 4u, 6)
+  DT_CAND(nw, db, dcode, dpos, 32u, 0)
+  DT_CAND(ne, db, dcode, dpos, 128u, 2)
+  DT_CAND(sw, db, dcode, dpos, 8u, 5)
+  DT_CAND(se, db, dcode, dpos, 2u, 7)
+#undef DT_CAND
+  double vc = cb > 0.0f ? (double)cb / dcard : 0.0;
+  double vd = db > 0.0f ? (double)db / ddiag : 0.0;
+  double v;
+  uint32_t code;
+  if (vc > vd || (vc == vd && cpos < dpos)) {
+    v = vc;
+    code = ccode;
+  } else {
+    v = vd;
+    code = dcode;
+  }
+  r.slope = (float)(v * 100.0);  // slope.py:259
+  r.code = (uint8_t)code;
+  return r;
+}
+
+// TI / MTI of one cell (topoindexes.py:234-295); float64 inside, float32 out.
+__device__ __forceinline__ void dt_twi_cell(int64_t fac, float srad, double px2, double n, float &ti,
+                                            float &mti) {
+  if (fac <= -100) {
+    ti = DT_NODATA;
+    mti = DT_NODATA;
+    return;
+  }
+  double a = fac == 0 ? px2 : (double)fac * px2;
+  double t = tan((double)srad + 0.01);
+  ti = (float)log(a / t);
+  mti = (float)log(pow(a, n) / t);
+}
+
+// slope % -> radians as Example/example.py:63-64 does on the host: float32 quotient, arctan,
+// float32 result; -100 where dem == -100.
+__device__ __forceinline__ float dt_slope_rad(float slope_pct, float dem) {
+  if (dem == DT_NODATA) return DT_NODATA;
+  float q = slope_pct / 100.0f;
+  return (float)atan((double)q);
+}
+
+template <bool W_SLOPE, bool W_FDR, bool W_RAD, bool W_TWI>
+__global__ __launch_bounds__(256) void k_stencil(const float *__restrict__ dem, int H, int W,
+                                                double px, float *__restrict__ slope,
+                                                uint8_t *__restrict__ fdr,
+                                                float *__restrict__ slope_rad,
+                                                const int32_t *__restrict__ acc32, double n_top,
+                                                float *__restrict__ ti, float *__restrict__ mti,
+                                                int tiles_x, int tiles_y, int vec_ok) {
+  __shared__ __attribute__((aligned(16))) float t[(SD_TY + 2) * SD_LDW];
+
+  // XCD-aware tile mapping: workgroup id b runs on XCD group (b % 8); give each group a band
+  // of tile rows and walk it row-major.
+  int b = blockIdx.x;
+  int ntiles = tiles_x * tiles_y;
+  int tile;
+  {
+    int xcd = b & 7, j = b >> 3;
+    int q = ntiles >> 3, rem = ntiles & 7;
+    int base = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+    tile = base + j;
+  }
+  int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+  int x0 = txi * SD_TX, y0 = tyi * SD_TY;
+
+  // ---- stage (SD_TY + 2) x (SD_TX + 2) cells; outside the raster = -100 ring (slope.py:175) ----
+  for (int i = threadIdx.x; i < (SD_TY + 2) * (SD_TX / 4); i += 256) {
+    int r = i / (SD_TX / 4), c4 = i - r * (SD_TX / 4);
+    int gy = y0 - 1 + r, gx = x0 + c4 * 4;
+    float4 v = make_float4(DT_NODATA, DT_NODATA, DT_NODATA, DT_NODATA);
+    if (gy >= 0 && gy < H) {
+      const float *p = dem + (size_t)gy * W + gx;
+      if (vec_ok && gx + 3 < W) {
+        v = *reinterpret_cast<const float4 *>(p);
+      } else {
+        if (gx < W) v.x = p[0];
+        if (gx + 1 < W) v.y = p[1];
+        if (gx + 2 < W) v.z = p[2];
+        if (gx + 3 < W) v.w = p[3];
+      }
+    }
+    *reinterpret_cast<float4 *>(&t[r * SD_LDW + 4 + c4 * 4]) = v;
+  }
+  for (int i = threadIdx.x; i < (SD_TY + 2) * 2; i += 256) {
+    int r = i >> 1, side = i & 1;
+    int gy = y0 - 1 + r, gx = side ? x0 + SD_TX : x0 - 1;
+    float v = DT_NODATA;
+    if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = dem[(size_t)gy * W + gx];
+    t[r * SD_LDW + (side ? 4 + SD_TX : 3)] = v;
+  }
+  __syncthreads();
+
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int cx = tx * 4;  // tile column of the patch
+  const int ry = ty * 4;  // tile row of the patch
+  const int gx = x0 + cx;
+  if (gx >= W) return;
+  const double dcard = px, ddiag = px * sqrt(2.0);
+  const double px2 = px * px;
+
+  // rolling 3-row window of 6 values (cols cx-1 .. cx+4)
+  float a[6], bb[6], cc[6];
+  auto load_row = [&](int lr, float *dst) {
+    const float *p = &t[lr * SD_LDW + 4 + cx];
+    float4 m = *reinterpret_cast<const float4 *>(p);
+    dst[0] = p[-1];
+    dst[1] = m.x;
+    dst[2] = m.y;
+    dst[3] = m.z;
+    dst[4] = m.w;
+    dst[5] = p[4];
+  };
+  load_row(ry, a);       // row above the first output row (tile row ry == raster row y0-1+ry)
+  load_row(ry + 1, bb);  // first output row
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    int gy = y0 + ry + j;
+    load_row(ry + 2 + j, cc);
+    if (gy < H) {
+      float so[4], ro[4], tio[4], mtio[4];
+      uint32_t codes = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        SlopeCell sc = dt_slope_cell(bb[k + 1], a[k], a[k + 1], a[k + 2], bb[k], bb[k + 2], cc[k],
+                                     cc[k + 1], cc[k + 2], 0.0, dcard, ddiag);
+        so[k] = sc.slope;
+        uint32_t code = sc.code;
+        if (W_FDR) {
+          // N1 border rule: a border cell with no lower neighbour drains out of the raster
+          int xx = gx + k;
+          if (code == 0u && bb[k + 1] > DT_NODATA) {
+            if (gy == H - 1) code = 4u;
+            else if (gy == 0) code = 64u;
+            else if (xx == 0) code = 16u;
+            else if (xx == W - 1) code = 1u;
+          }
+          codes |= code << (8 * k);
+        }
+        if (W_RAD || W_TWI) ro[k] = dt_slope_rad(sc.slope, bb[k + 1]);
+        if (W_TWI) {
+          int xx = gx + k;
+          int64_t f = xx < W ? (int64_t)acc32[(size_t)gy * W + xx] : -100;
+          dt_twi_cell(f, ro[k], px2, n_top, tio[k], mtio[k]);
+        }
+      }
+      size_t o = (size_t)gy * W + gx;
+      bool full = vec_ok && gx + 3 < W;
+      if (full) {
+        if (W_SLOPE) *reinterpret_cast<float4 *>(slope + o) = make_float4(so[0], so[1], so[2], so[3]);
+        if (W_RAD) *reinterpret_cast<float4 *>(slope_rad + o) = make_float4(ro[0], ro[1], ro[2], ro[3]);
+        if (W_TWI) {
+          *reinterpret_cast<float4 *>(ti + o) = make_float4(tio[0], tio[1], tio[2], tio[3]);
+          *reinterpret_cast<float4 *>(mti + o) = make_float4(mtio[0], mtio[1], mtio[2], mtio[3]);
+        }
+        if (W_FDR) *reinterpret_cast<uint32_t *>(fdr + o) = codes;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          if (gx + k < W) {
+            if (W_SLOPE) slope[o + k] = so[k];
+            if (W_RAD) slope_rad[o + k] = ro[k];
+            if (W_TWI) {
+              ti[o + k] = tio[k];
+              mti[o + k] = mtio[k];
+            }
+            if (W_FDR) fdr[o + k] = (uint8_t)(codes >> (8 * k));
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+      a[q] = bb[q];
+      bb[q] = cc[q];
+    }
+  }
+}
+
+int dt_launch_stencil(hipStream_t s, const float *dem, int64_t H, int64_t W, double px, float *slope,
+                      uint8_t *fdr, float *slope_rad, const int32_t *acc32, double n_top, float *ti,
+                      float *mti) {
+  if (H == 0 || W == 0) return DT_OK;
+  int tiles_x = (int)((W + SD_TX - 1) / SD_TX), tiles_y = (int)((H + SD_TY - 1) / SD_TY);
+  int64_t ntiles = (int64_t)tiles_x * tiles_y;
+  DT_REQUIRE(ntiles < (1ll << 31), "raster too large for one launch");
+  // 16-byte vector path needs W % 4 == 0 and 16-byte aligned bases
+  int vec_ok = (W % 4 == 0) && (((uintptr_t)dem & 15) == 0) && (!slope || ((uintptr_t)slope & 15) == 0) &&
+               (!slope_rad || ((uintptr_t)slope_rad & 15) == 0) && (!ti || ((uintptr_t)ti & 15) == 0) &&
+               (!mti || ((uintptr_t)mti & 15) == 0) && (!fdr || ((uintptr_t)fdr & 3) == 0);
+  dim3 g((unsigned)ntiles), b(256);
+  bool ws = slope != nullptr, wf = fdr != nullptr, wr = slope_rad != nullptr, wt = ti != nullptr;
+#define DT_GO(S, F, R, T)                                                                          \
+  hipLaunchKernelGGL((k_stencil<S, F, R, T>), g, b, 0, s, dem, (int)H, (int)W, px, slope, fdr,     \
+                     slope_rad, acc32, n_top, ti, mti, tiles_x, tiles_y, vec_ok)
+  if (wt) {
+    DT_REQUIRE(acc32 && mti, "fused TWI needs acc32, ti and mti");
+    if (ws && wr) DT_GO(true, false, true, true);
+    else if (ws) DT_GO(true, false, false, true);
+    else if (wr) DT_GO(false, false, true, true);
+    else DT_GO(false, false, false, true);
+  } else if (ws && wf && wr) DT_GO(true, true, true, false);
+  else if (ws && wf) DT_GO(true, true, false, false);
+  else if (ws && wr) DT_GO(true, false, true, false);
+  else if (wf && wr) DT_GO(false, true, true, false);
+  else if (ws) DT_GO(true, false, false, false);
+  else if (wf) DT_GO(false, true, false, false);
+  else if (wr) DT_GO(false, false, true, false);
+#undef DT_GO
+  return DT_OK;
+}
+
+// ===========================================================================================
+// Flow accumulation (N2), v1: in-degree countdown with ONE packed 64-bit word per cell,
+//   state = remaining_in_degree << 56 | accumulated_upstream_cells
+// A contribution is a single atomicAdd of (carry + 1) - (1 << 56): it adds the upstream count
+// and retires one pending donor in the same RMW, so the thread that observes "I was the last
+// donor" also observes the complete sum -- no fence / ordering protocol between two words.
+// Integer adds: the result is independent of arrival order (bit-exact, deterministic).
+// ===========================================================================================
+#define FA_CNT_SHIFT 56
+#define FA_ACC_MASK ((1ull << FA_CNT_SHIFT) - 1ull)
+#define FA_CNT(s) (((s) >> FA_CNT_SHIFT) & 0xFull)
+#define FA_SRC_BIT (1ull << 62) /* set at init on cells with in-degree 0; never modified */
+
+__device__ __forceinline__ int64_t dt_step(int64_t pos, uint32_t code, int H, int W, bool &diag) {
+  // returns target cell, -1 for a non-D8 code (incl. 0), -2 when leaving the raster
+  if (!dt_d8_valid(code)) return -1;
+  int dy, dx;
+  dt_d8_delta(code, dy, dx);
+  int y = (int)(pos / W), x = (int)(pos - (int64_t)y * W);
+  y += dy;
+  x += dx;
+  diag = (dy != 0) && (dx != 0);
+  if (y < 0 || y >= H || x < 0 || x >= W) return -2;
+  return (int64_t)y * W + x;
+}
+
+__global__ __launch_bounds__(256) void k_fa_indeg(const uint8_t *__restrict__ fdr, int H, int W,
+                                                 unsigned long long *__restrict__ state) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)H * W) return;
+  int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
+  // neighbour (y+dy, x+dx) drains into me iff its code points back: (-dy, -dx)
+  // code for delta (dy,dx): E(0,1)=1 SE(1,1)=2 S(1,0)=4 SW(1,-1)=8 W(0,-1)=16 NW(-1,-1)=32 N(-1,0)=64 NE(-1,1)=128
+  unsigned cnt = 0;
+#define DT_IN(dy, dx, code)                                                            \
+  {                                                                                    \
+    int yy = y + (dy), xx = x + (dx);                                                  \
+    if (yy >= 0 && yy < H && xx >= 0 && xx < W && fdr[(size_t)yy * W + xx] == (code)) cnt++; \
+  }
+  DT_IN(0, -1, 1)     // W neighbour flowing E
+  DT_IN(-1, -1, 2)    // NW neighbour flowing SE
+  DT_IN(-1, 0, 4)     // N neighbour flowing S
+  DT_IN(-1, 1, 8)     // NE neighbour flowing SW
+  DT_IN(0, 1, 16)     // E neighbour flowing W
+  DT_IN(1, 1, 32)     // SE neighbour flowing NW
+  DT_IN(1, 0, 64)     // S neighbour flowing N
+  DT_IN(1, -1, 128)   // SW neighbour flowing NE
+#undef DT_IN
+  state[i] = ((unsigned long long)cnt << FA_CNT_SHIFT) | (cnt == 0u ? FA_SRC_BIT : 0ull);
+}
+
+__global__ __launch_bounds__(256) void k_fa_walk(const uint8_t *__restrict__ fdr, int H, int W,
+                                                unsigned long long *__restrict__ state) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)H * W) return;
+  // original sources only (a non-source whose count later reaches 0 is continued by its last
+  // donor, never restarted).  A source's word is never written, so a plain read is safe.
+  if (!(state[i] & FA_SRC_BIT)) return;
+  unsigned long long carry = 0ull;  // accumulation of the cell I am leaving
+  int64_t cur = i;
+  const int64_t limit = (int64_t)H * W;  // a walk visits each cell at most once: hard bound
+  for (int64_t it = 0; it < limit; it++) {
+    bool diag;
+    int64_t t = dt_step(cur, fdr[cur], H, W, diag);
+    if (t < 0) break;
+    unsigned long long add = (carry + 1ull) - (1ull << FA_CNT_SHIFT);
+    unsigned long long old = atomicAdd(&state[t], add);
+    if (FA_CNT(old) != 1ull) break;  // other donors still pending: the last one carries on
+    carry = (old & FA_ACC_MASK) + carry + 1ull;
+    cur = t;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_fa_final(const unsigned long long *__restrict__ state,
+                                                 const float *__restrict__ dem, int64_t n,
+                                                 int32_t *__restrict__ acc32) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long s = state[i];
+  int32_t v = (int32_t)(s & FA_ACC_MASK);
+  if (FA_CNT(s) != 0ull) v = -100;  // on a D8 cycle: undefined
+  if (dem && dem[i] <= DT_NODATA) v = -100;
+  acc32[i] = v;
+}
+
+int dt_launch_flowacc(hipStream_t s, const uint8_t *fdr, const float *dem, int64_t H, int64_t W,
+                      unsigned long long *state, int32_t *acc32) {
+  int64_t n = H * W;
+  if (n == 0) return DT_OK;
+  dim3 g((unsigned)((n + 255) / 256)), b(256);
+  hipLaunchKernelGGL(k_fa_indeg, g, b, 0, s, fdr, (int)H, (int)W, state);
+  hipLaunchKernelGGL(k_fa_walk, g, b, 0, s, fdr, (int)H, (int)W, state);
+  hipLaunchKernelGGL(k_fa_final, g, b, 0, s, state, dem, n, acc32);
+  return DT_OK;
+}
+
+__global__ __launch_bounds__(256) void k_river_mask(const int32_t *__restrict__ acc32, int64_t n,
+                                                   int32_t thr, int8_t *__restrict__ river) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) river[i] = acc32[i] > thr ? 1 : 0;  // example.py:52
+}
+int dt_launch_river_mask(hipStream_t s, const int32_t *acc32, int64_t n, int64_t thr, int8_t *river) {
+  if (n == 0) return DT_OK;
+  int32_t t32 = thr > 2147483647ll ? 2147483647 : (thr < -2147483648ll ? (int32_t)-2147483648ll : (int32_t)thr);
+  hipLaunchKernelGGL(k_river_mask, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, acc32, n, t32, river);
+  return DT_OK;
+}
+
+// ===========================================================================================
+// Flow distance / river index / HAND (F3, F4), v1: pointer doubling on ONE packed 64-bit word
+// per cell,
+//   state = ptr:32 | n_diag:16 | done:1 | n_card:15
+// "The path from this cell to cell `ptr` takes n_card cardinal and n_diag diagonal moves."
+// Any historical value of a cell's word is a true statement, so rounds update in place with
+// relaxed 64-bit loads/stores and no inter-workgroup protocol; 15 rounds resolve every path of
+// <= 20000 moves (2^15 > 20000), longer paths / cycles exceed the cap and die, exactly the
+// reference's `loop > 20000 -> -100` (flowhand.py:834-837).  The distance is materialised once,
+// float32(px*n_card + px*sqrt(2)*n_diag) in float64: association-free, <= 1 float32 ulp from the
+// reference's sequential float64 sum.
+// ===========================================================================================
+#define FH_DEAD 0xFFFFFFFFu
+#define FH_DONE 0x8000u
+#define FH_CAP 20000u
+
+__device__ __forceinline__ unsigned long long fh_pack(uint32_t ptr, uint32_t nd, uint32_t nc_flags) {
+  return ((unsigned long long)ptr << 32) | ((unsigned long long)nd << 16) | (unsigned long long)nc_flags;
+}
+
+__global__ __launch_bounds__(256) void k_fh_init(const uint8_t *__restrict__ fdr,
+                                                const int8_t *__restrict__ river, int H, int W,
+                                                unsigned long long *__restrict__ state) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)H * W) return;
+  uint32_t code = fdr[i];
+  unsigned long long s;
+  if (code == 0u) {
+    s = fh_pack(FH_DEAD, 0, FH_DONE);  // flowhand.py:601
+  } else if (river[i] == 1) {
+    s = fh_pack((uint32_t)i, 0, FH_DONE);  // flowhand.py:609-612
+  } else {
+    bool diag = false;
+    int64_t t = dt_step(i, code, H, W, diag);
+    // leaving the raster (:623-628 ...), a non-D8 code (caught by the revisit test :830) and
+    // arrival on fdr == 0 (:826-828) all end in -100
+    if (t < 0 || fdr[t] == 0u) s = fh_pack(FH_DEAD, 0, FH_DONE);
+    else s = fh_pack((uint32_t)t, diag ? 1u : 0u, diag ? 0u : 1u);
+  }
+  state[i] = s;
+}
+
+__global__ __launch_bounds__(256) void k_fh_jump(unsigned long long *__restrict__ state, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long s = __hip_atomic_load(&state[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  uint32_t ncf = (uint32_t)(s & 0xFFFFu);
+  if (ncf & FH_DONE) return;
+  uint32_t ptr = (uint32_t)(s >> 32), nd = (uint32_t)((s >> 16) & 0xFFFFu), nc = ncf;
+  unsigned long long t = __hip_atomic_load(&state[ptr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  uint32_t tptr = (uint32_t)(t >> 32), tnd = (uint32_t)((t >> 16) & 0xFFFFu);
+  uint32_t tncf = (uint32_t)(t & 0xFFFFu);
+  uint32_t tnc = tncf & 0x7FFFu;
+  bool tdone = (tncf & FH_DONE) != 0u;
+  unsigned long long o;
+  uint32_t nnc = nc + tnc, nnd = nd + tnd;
+  if (tptr == FH_DEAD || nnc + nnd > FH_CAP) o = fh_pack(FH_DEAD, 0, FH_DONE);
+  else o = fh_pack(tptr, nnd, nnc | (tdone ? FH_DONE : 0u));
+  __hip_atomic_store(&state[i], o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(256) void k_fh_final(const unsigned long long *__restrict__ state,
+                                                 const float *__restrict__ dem,
+                                                 const int32_t *__restrict__ acc32, int64_t n,
+                                                 double px, float *__restrict__ fdist,
+                                                 int32_t *__restrict__ idx32, float *__restrict__ hand,
+                                                 int32_t *__restrict__ a_river) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long s = state[i];
+  uint32_t ptr = (uint32_t)(s >> 32), nd = (uint32_t)((s >> 16) & 0xFFFFu);
+  uint32_t ncf = (uint32_t)(s & 0xFFFFu), nc = ncf & 0x7FFFu;
+  bool ok = (ncf & FH_DONE) && ptr != FH_DEAD;  // not DONE after all rounds == longer than the cap
+  if (fdist) fdist[i] = ok ? (float)(px * (double)nc + (px * sqrt(2.0)) * (double)nd) : DT_NODATA;
+  if (idx32) idx32[i] = ok ? (int32_t)ptr : -100;
+  if (hand) {
+    float h = DT_NODATA;
+    float z = dem[i];
+    if (z != DT_NODATA && ok) {  // flowhand.py:436
+      h = z - dem[ptr];
+      if (h < 0.0f && h != DT_NODATA) h = 0.0f;  // flowhand.py:438
+    }
+    hand[i] = h;
+  }
+  if (a_river) a_river[i] = ok ? acc32[ptr] : acc32[0];  // gfi.py:141-143
+}
+
+int dt_launch_flowhand(hipStream_t s, const float *dem, const uint8_t *fdr, const int8_t *river,
+                       const int32_t *acc32, int64_t H, int64_t W, double px,
+                       unsigned long long *state, float *fdist, int32_t *idx32, float *hand,
+                       int32_t *a_river) {
+  int64_t n = H * W;
+  if (n == 0) return DT_OK;
+  dim3 g((unsigned)((n + 255) / 256)), b(256);
+  hipLaunchKernelGGL(k_fh_init, g, b, 0, s, fdr, river, (int)H, (int)W, state);
+  for (int r = 0; r < 15; r++) hipLaunchKernelGGL(k_fh_jump, g, b, 0, s, state, n);
+  hipLaunchKernelGGL(k_fh_final, g, b, 0, s, state, dem, acc32, n, px, fdist, idx32, hand, a_river);
+  return DT_OK;
+}
+
+// ===========================================================================================
+// Pointwise descriptors: TI/MTI (T2/T3), GFI (G2), ln(hl/H) (G3).  float64 math, one float32
+// rounding, as Numba types the reference kernels.
+// ===========================================================================================
+template <typename IT>
+__global__ __launch_bounds__(256) void k_twi(const IT *__restrict__ acc32,
+                                            const float *__restrict__ srad, int64_t n, double px2,
+                                            double n_top, float *__restrict__ ti,
+                                            float *__restrict__ mti) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float a, b;
+  dt_twi_cell((int64_t)acc32[i], srad[i], px2, n_top, a, b);
+  ti[i] = a;
+  mti[i] = b;
+}
+int dt_launch_twi(hipStream_t s, const int32_t *acc32, const float *srad, int64_t n, double px,
+                  double n_top, float *ti, float *mti) {
+  if (n == 0) return DT_OK;
+  hipLaunchKernelGGL(k_twi<int32_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, acc32, srad, n,
+                     px * px, n_top, ti, mti);
+  return DT_OK;
+}
+int dt_launch_twi_i64(hipStream_t s, const int64_t *fac, const float *srad, int64_t n, double px,
+                      double n_top, float *ti, float *mti) {
+  if (n == 0) return DT_OK;
+  hipLaunchKernelGGL(k_twi<int64_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, fac, srad, n,
+                     px * px, n_top, ti, mti);
+  return DT_OK;
+}
+
+// gfi.py:268-294 (own_cell = false: A = a_river, no zero guard) and gfi.py:404-440 (own_cell =
+// true: A = fac, fac == 0 -> 1)
+template <bool OWN_CELL, typename IT>
+__global__ __launch_bounds__(256) void k_gfi(const float *__restrict__ hand,
+                                            const IT *__restrict__ area, int64_t n, double expo,
+                                            double b, double size2, float *__restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float h = hand[i];
+  if (h <= DT_NODATA) {
+    out[i] = DT_NODATA;
+    return;
+  }
+  IT ar = area[i];
+  double a = (OWN_CELL && ar == 0) ? size2 : (double)ar * size2;
+  out[i] = (float)log((b * pow(a, expo)) / ((double)h + 0.01));
+}
+int dt_launch_gfi(hipStream_t s, const float *hand, const int32_t *area, int64_t n, double expo,
+                  double b, double size, float *out, int own_cell) {
+  if (n == 0) return DT_OK;
+  dim3 g((unsigned)((n + 255) / 256)), bl(256);
+  if (own_cell) hipLaunchKernelGGL((k_gfi<true, int32_t>), g, bl, 0, s, hand, area, n, expo, b, size * size, out);
+  else hipLaunchKernelGGL((k_gfi<false, int32_t>), g, bl, 0, s, hand, area, n, expo, b, size * size, out);
+  return DT_OK;
+}
+int dt_launch_gfi_i64(hipStream_t s, const float *hand, const int64_t *area, int64_t n, double expo,
+                      double b, double size, float *out, int own_cell) {
+  if (n == 0) return DT_OK;
+  dim3 g((unsigned)((n + 255) / 256)), bl(256);
+  if (own_cell) hipLaunchKernelGGL((k_gfi<true, int64_t>), g, bl, 0, s, hand, area, n, expo, b, size * size, out);
+  else hipLaunchKernelGGL((k_gfi<false, int64_t>), g, bl, 0, s, hand, area, n, expo, b, size * size, out);
+  return DT_OK;
+}
+// gfi.river_accumulation (gfi.py:119-147): A_r = fac.flat[idx] where idx != -100 else fac.flat[0]
+__global__ __launch_bounds__(256) void k_river_acc_i64(const int64_t *__restrict__ fac,
+                                                      const int64_t *__restrict__ idx, int64_t n,
+                                                      int64_t *__restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int64_t k = idx[i];
+  out[i] = (k != -100 && k >= 0 && k < n) ? fac[k] : fac[0];
+}
+int dt_launch_river_acc_i64(hipStream_t s, const int64_t *fac, const int64_t *idx, int64_t n, int64_t *out) {
+  if (n) hipLaunchKernelGGL(k_river_acc_i64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, fac, idx, n, out);
+  return DT_OK;
+}
+
+// ===========================================================================================
+// Downslope index (D1-D3), v1: one direct walk per cell restating kernel + repair
+// (downslope.py:435-532 and :161-314); sequential float64 path-length sum as the reference.
+// ===========================================================================================
+__global__ __launch_bounds__(256) void k_downslope(const float *__restrict__ dem,
+                                                  const uint8_t *__restrict__ fdr, int H, int W,
+                                                  double px, double dz, int raw,
+                                                  float *__restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)H * W) return;
+  float z0 = dem[i];
+  if (z0 <= DT_NODATA) {
+    out[i] = DT_NODATA;
+    return;
+  }
+  const double dcard = px, ddiag = px * sqrt(2.0);
+  int64_t pos = i;
+  double dist = 0.0;
+  float drop = 0.0f;
+  int loop = 0;
+  bool failed = false;  // what downslope_gpu alone marks -50 (downslope.py:526-529)
+  while ((double)drop < dz) {
+    bool diag = false;
+    int64_t t = dt_step(pos, fdr[pos], H, W, diag);
+    if (t == -2) { failed = true; break; }  // raster-edge exit: stop (downslope.py:209-228)
+    if (t >= 0) {
+      float zt = dem[t];
+      if (zt == DT_NODATA) { failed = true; break; }  // nodata ahead: stop without moving (:231-281)
+      pos = t;
+      dist += diag ? ddiag : dcard;
+      drop = z0 - zt;
+    }
+    if (++loop == 5000) { failed = true; break; }  // :303-304 / :518-521
+  }
+  if (raw && failed) out[i] = -50.0f;
+  else out[i] = dist == 0.0 ? 0.0f : (float)((double)drop / dist);
+}
+int dt_launch_downslope(hipStream_t s, const float *dem, const uint8_t *fdr, int64_t H, int64_t W,
+                        double px, double dz, int raw, float *out) {
+  int64_t n = H * W;
+  if (n == 0) return DT_OK;
+  hipLaunchKernelGGL(k_downslope, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dem, fdr, (int)H,
+                     (int)W, px, dz, raw, out);
+  return DT_OK;
+}
+
+// flowhand.hand_calculator alone (flowhand.py:414-442) on int64 indices
+__global__ __launch_bounds__(256) void k_hand_i64(const float *__restrict__ dem,
+                                                 const int64_t *__restrict__ idx, int64_t n,
+                                                 float *__restrict__ hand) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float z = dem[i], h = DT_NODATA;
+  int64_t k = idx[i];
+  if (z != DT_NODATA && k != -100) {
+    if (k < 0) k += n;  // numpy negative indexing, as the reference's dem[indices]
+    if (k >= 0 && k < n) {
+      h = z - dem[k];
+      if (h < 0.0f && h != DT_NODATA) h = 0.0f;
+    }
+  }
+  hand[i] = h;
+}
+int dt_launch_hand_i64(hipStream_t s, const float *dem, const int64_t *idx, int64_t n, float *hand) {
+  if (n) hipLaunchKernelGGL(k_hand_i64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dem, idx, n, hand);
+  return DT_OK;
+}
+
+// ===========================================================================================
+// Confusion counts for up to 24 thresholds in one pass (E2+E3, evaluation.py:90-171).
+// Per lane: B0[t] / B2[t] = #cells classified 1 whose remapped benchmark value is 0 / 2;
+// benchmark values other than {0, 2} (never produced by the reference's inputs) take a slow
+// exact path.  Wave shuffle reduction, then one 64-bit atomic per counter per wave.
+// ===========================================================================================
+#define CF_MAXT 24
+struct CfThresholds {
+  double v[CF_MAXT];
+};
+
+__global__ __launch_bounds__(256) void k_confusion(const double *__restrict__ desc,
+                                                  const int8_t *__restrict__ flood, int64_t n,
+                                                  double nodata, int nth, int under,
+                                                  CfThresholds th,
+                                                  unsigned long long *__restrict__ counts4) {
+  unsigned int b0[CF_MAXT], b2[CF_MAXT];
+#pragma unroll
+  for (int t = 0; t < CF_MAXT; t++) b0[t] = b2[t] = 0u;
+  unsigned int t0 = 0u, t2 = 0u, t3 = 0u;  // cells with g == 0 / 2 / 3
+  int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    double v = desc[i];
+    int g = flood[i];
+    if (g == 1) g = 2;            // evaluation.py:149
+    else if (g == -100) g = 0;    // evaluation.py:150
+    bool isn = (v == nodata) || (v != v);  // evaluation.py:111-121
+    if (g == 0 || g == 2) {
+      if (g == 0) t0++; else t2++;
+#pragma unroll
+      for (int t = 0; t < CF_MAXT; t++) {
+        bool bin = !isn && (t < nth) && (under ? (v <= th.v[t]) : (v >= th.v[t]));
+        b0[t] += (bin && g == 0) ? 1u : 0u;
+        b2[t] += (bin && g == 2) ? 1u : 0u;
+      }
+    } else {
+      // generic value: binary + g counted when it lands in 0..3
+      for (int t = 0; t < nth; t++) {
+        int bin = (!isn && (under ? (v <= th.v[t]) : (v >= th.v[t]))) ? 1 : 0;
+        int r = bin + g;
+        if (r >= 0 && r <= 3) atomicAdd(&counts4[t * 4 + r], 1ull);
+      }
+    }
+  }
+  (void)t3;
+  // wave reduction
+  for (int off = 32; off > 0; off >>= 1) {
+    t0 += __shfl_down(t0, off);
+    t2 += __shfl_down(t2, off);
+#pragma unroll
+    for (int t = 0; t < CF_MAXT; t++) {
+      b0[t] += __shfl_down(b0[t], off);
+      b2[t] += __shfl_down(b2[t], off);
+    }
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int t = 0; t < CF_MAXT; t++) {
+      if (t < nth) {
+        // class 0: g == 0, bin 0 | class 1: g == 0, bin 1 | class 2: g == 2, bin 0 | class 3: g == 2, bin 1
+        atomicAdd(&counts4[t * 4 + 0], (unsigned long long)(t0 - b0[t]));
+        atomicAdd(&counts4[t * 4 + 1], (unsigned long long)b0[t]);
+        atomicAdd(&counts4[t * 4 + 2], (unsigned long long)(t2 - b2[t]));
+        atomicAdd(&counts4[t * 4 + 3], (unsigned long long)b2[t]);
+      }
+    }
+  }
+}
+
+int dt_launch_confusion(hipStream_t s, const double *desc, const int8_t *flood, int64_t n,
+                        double nodata, const double *th_host, int nth, int under,
+                        unsigned long long *counts4) {
+  DT_REQUIRE(nth >= 1 && nth <= CF_MAXT, "1..24 thresholds per call");
+  DT_HIP(hipMemsetAsync(counts4, 0, sizeof(unsigned long long) * 4 * nth, s));
+  if (n == 0) return DT_OK;
+  CfThresholds th;
+  for (int t = 0; t < CF_MAXT; t++) th.v[t] = t < nth ? th_host[t] : 0.0;
+  // each lane counts in 32 bits: keep <= 2^31 cells per lane (grid-stride over >= 1024 blocks)
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_confusion, dim3((unsigned)blocks), dim3(256), 0, s, desc, flood, n, nodata, nth,
+                     under, th, counts4);
+  return DT_OK;
+}
+
+// ---- dtype helpers ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_i32_to_i64(const int32_t *__restrict__ a, int64_t n,
+                                                   int64_t *__restrict__ b) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) b[i] = a[i];
+}
+__global__ __launch_bounds__(256) void k_i64_to_i32(const int64_t *__restrict__ a, int64_t n,
+                                                   int32_t *__restrict__ b) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    int64_t v = a[i];
+    b[i] = v > 2147483647ll ? 2147483647 : (v < -2147483647ll - 1 ? (int32_t)(-2147483647 - 1) : (int32_t)v);
+  }
+}
+int dt_launch_i32_to_i64(hipStream_t s, const int32_t *a, int64_t n, int64_t *b) {
+  if (n) hipLaunchKernelGGL(k_i32_to_i64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, n, b);
+  return DT_OK;
+}
+int dt_launch_i64_to_i32(hipStream_t s, const int64_t *a, int64_t n, int32_t *b) {
+  if (n) hipLaunchKernelGGL(k_i64_to_i32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, n, b);
+  return DT_OK;
+}

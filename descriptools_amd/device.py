@@ -1,0 +1,67 @@
+"""Device context and buffers over the C ABI's device tier (no torch needed; torch tensors'
+data_ptr() can be passed to the same entry points)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+
+
+class DeviceArray:
+    def __init__(self, ctx, shape, dtype):
+        self.ctx, self.shape, self.dtype = ctx, tuple(np.atleast_1d(shape)), np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        p = C.c_void_p()
+        check(_lib.lib().dt_dev_malloc(ctx.h, self.nbytes, C.byref(p)))
+        self.ptr = p
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape))
+
+    def copy_from(self, a):
+        a = np.ascontiguousarray(a, self.dtype)
+        assert a.size == self.size
+        check(_lib.lib().dt_dev_h2d(self.ctx.h, self.ptr, a.ctypes.data_as(C.c_void_p), self.nbytes))
+        return self
+
+    def to_host(self):
+        out = np.empty(self.shape, self.dtype)
+        check(_lib.lib().dt_dev_d2h(self.ctx.h, out.ctypes.data_as(C.c_void_p), self.ptr, self.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            check(_lib.lib().dt_dev_free(self.ctx.h, self.ptr))
+            self.ptr = None
+
+
+class Context:
+    """dt_ctx wrapper: one device, one stream (own, or an external hipStream_t such as
+    torch.cuda.current_stream().cuda_stream)."""
+
+    def __init__(self, device=0, stream=None):
+        h = C.c_void_p()
+        check(_lib.lib().dt_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h)))
+        self.h = h
+        self.device = device
+
+    def empty(self, shape, dtype):
+        return DeviceArray(self, shape, dtype)
+
+    def to_device(self, a):
+        a = np.ascontiguousarray(a)
+        return DeviceArray(self, a.shape, a.dtype).copy_from(a)
+
+    def sync(self):
+        check(_lib.lib().dt_ctx_sync(self.h))
+
+    @property
+    def stream(self):
+        return _lib.lib().dt_ctx_stream(self.h)
+
+    def close(self):
+        if self.h:
+            check(_lib.lib().dt_ctx_destroy(self.h))
+            self.h = None

@@ -1,0 +1,15 @@
+"""Flow accumulation (net-new): number of upstream cells EXCLUDING self, the
+convention of the bundled 12_fac.tif; int64 like the `fac` the reference's callers pass."""
+import numpy as np
+
+from . import _lib
+from ._lib import c_f32p, c_i64p, c_u8p, check, dem_f32, ptr
+
+
+def accumulate(fdr, dem=None):
+    fdr = np.ascontiguousarray(fdr, np.uint8)
+    H, W = fdr.shape
+    d = dem_f32(dem) if dem is not None else None
+    acc = np.empty((H, W), np.int64)
+    check(_lib.lib().dt_flowacc_u8(ptr(fdr, c_u8p), ptr(d, c_f32p), H, W, ptr(acc, c_i64p)))
+    return acc

@@ -1,0 +1,16 @@
+"""D8 flow direction (net-new): ESRI code of the neighbour that realises
+slope.slope_gpu's maximum, first in its scan order NW,N,NE,W,E,SW,S,SE; 0 = nodata / interior
+pit; a raster-border cell with no lower neighbour drains outward."""
+import numpy as np
+
+from . import _lib
+from ._lib import c_f32p, c_u8p, check, dem_f32, ptr
+
+
+def d8(dem, px, return_slope=False):
+    dem32 = dem_f32(dem)
+    H, W = dem32.shape
+    fdr = np.empty((H, W), np.uint8)
+    sl = np.empty((H, W), np.float32) if return_slope else None
+    check(_lib.lib().dt_d8_f32(ptr(dem32, c_f32p), H, W, float(px), ptr(fdr, c_u8p), ptr(sl, c_f32p)))
+    return (fdr, sl) if return_slope else fdr

@@ -1,0 +1,160 @@
+/*
+ * descriptools_hip.h -- C ABI of libdescriptools_hip.so (MI355X / gfx950 terrain-descriptor engine)
+ *
+ * Drop-in boundary for the descriptools hot path.  Each entry point replaces one host<->device
+ * shim (`*_cpu`) + Numba-CUDA kernel (`*_gpu`) pair of the reference (citations are
+ * file:line relative to /root/reference/descriptools/).  Plain pointers and sizes only.
+ *
+ * Conventions:
+ *   - rasters are row-major C-contiguous, H rows x W columns; nodata sentinel is -100;
+ *   - DEM / HAND are float32 (int16 rasters are converted exactly by the caller);
+ *   - D8 codes are ESRI: 1=E 2=SE 4=S 8=SW 16=W 32=NW 64=N 128=NE, 0 = nodata / undefined;
+ *   - every function returns 0 on success and a negative DT_E* code on failure;
+ *     dt_last_error() gives the message (thread-local).  Nothing falls back to the CPU.
+ *
+ * Two tiers:
+ *   dt_<op>(...)      host pointers in / host pointers out (what the reference's *_cpu do);
+ *   dt_dev_<op>(ctx,) device pointers, asynchronous on the context's stream -- the resident
+ *                     chained / multi-GPU path.  Device buffers are caller-owned (hipMalloc,
+ *                     torch tensors, ...); scratch is owned by the context.
+ */
+#ifndef DESCRIPTOOLS_HIP_H
+#define DESCRIPTOOLS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DT_OK 0
+#define DT_EINVAL (-1) /* bad shape / null pointer / unsupported size */
+#define DT_EHIP (-2)   /* HIP runtime error (message in dt_last_error) */
+#define DT_ENOMEM (-3) /* device allocation failed */
+#define DT_ENODEV (-4) /* no usable GPU */
+
+typedef struct dt_ctx dt_ctx;
+
+/* ---- runtime ------------------------------------------------------------------------- */
+const char *dt_last_error(void);
+int dt_device_count(void);
+const char *dt_version(void);
+
+/* Context = one device + one stream + grow-only scratch.  `stream` may be NULL (the context
+ * creates its own non-blocking stream) or an existing hipStream_t (e.g. torch's). */
+int dt_ctx_create(int device, void *stream, dt_ctx **out);
+int dt_ctx_destroy(dt_ctx *ctx);
+int dt_ctx_set_stream(dt_ctx *ctx, void *stream);
+void *dt_ctx_stream(dt_ctx *ctx);
+int dt_ctx_sync(dt_ctx *ctx);
+int64_t dt_ctx_scratch_bytes(dt_ctx *ctx);
+
+/* ---- host-pointer tier (drop-in for the reference's *_cpu shims) ----------------------- */
+
+/* slope.slope_cpu + slope_gpu (slope.py:152-259): steepest-descent slope in percent.  The
+ * -100 ring the reference pads on (slope.py:175-182) is implicit: neighbours outside the raster
+ * are skipped like nodata neighbours. */
+int dt_slope_f32(const float *dem, int64_t H, int64_t W, double px, float *slope);
+
+/* Net-new N1 (no reference function; encoding pinned by flowhand.py:801-824): D8 code of the
+ * neighbour that sets slope_gpu's maximum, first in its scan order.  `slope` may be NULL. */
+int dt_d8_f32(const float *dem, int64_t H, int64_t W, double px, uint8_t *fdr, float *slope);
+
+/* Net-new N2: flow accumulation = number of upstream cells excluding self; `dem` may be NULL,
+ * otherwise cells with dem <= -100 are set to -100.  Cells on a D8 cycle get -100. */
+int dt_flowacc_u8(const uint8_t *fdr, const float *dem, int64_t H, int64_t W, int64_t *acc);
+
+/* flowhand.flow_distance_index_cpu + flow_distance_index_gpu (flowhand.py:476-846, untiled
+ * call: out = 0, row_start = col_start = 0, matrix_columns = W) and flowhand.hand_calculator
+ * (flowhand.py:414-442).  `dem`/`hand` may both be NULL to skip HAND. */
+int dt_flowhand(const float *dem, const uint8_t *fdr, const int8_t *river, int64_t H, int64_t W,
+                double px, float *fdist, int64_t *idx, float *hand);
+
+/* flowhand.hand_calculator alone (flowhand.py:414-442): dem - dem[idx], negatives -> 0. */
+int dt_hand_f32(const float *dem, const int64_t *idx, int64_t N, float *hand);
+
+/* topoindexes.topographic_index_cpu + both kernels (topoindexes.py:170-295); slope in radians. */
+int dt_twi(const int64_t *fac, const float *slope_rad, int64_t N, double px, double n_top,
+           float *ti, float *mti);
+
+/* gfi.river_accumulation (gfi.py:119-147): out[i] = fac[idx[i]] where idx != -100 else fac[0]. */
+int dt_river_accumulation(const int64_t *fac, const int64_t *idx, int64_t N, int64_t *out);
+
+/* gfi.geomorphic_flood_index_cpu/_gpu (gfi.py:210-294; zero_guard = 0) and gfi.ln_hl_H_cpu/_gpu
+ * (gfi.py:349-440; zero_guard = 1: area == 0 -> 1) on an explicit per-cell area raster. */
+int dt_gfi_area(const float *hand, const int64_t *area, int64_t N, double n_gfi, double scale_factor,
+                double size, int zero_guard, float *out);
+
+/* gfi.river_accumulation + geomorphic_flood_index_cpu/_gpu (gfi.py:119-147, 210-294). */
+int dt_gfi(const float *hand, const int64_t *fac, const int64_t *idx, int64_t N, double n_gfi,
+           double scale_factor, double size, float *gfi);
+
+/* gfi.ln_hl_H_cpu/_gpu (gfi.py:349-440). */
+int dt_lnhlh(const float *hand, const int64_t *fac, int64_t N, double n_gfi, double scale_factor,
+             double size, float *out);
+
+/* downslope.downslope_cpu + downslope_gpu + the -50 repair of downslope_sequential_jit
+ * (downslope.py:379-532, 161-314), untiled.
+ * raw != 0 reproduces downslope_cpu alone: failed walks are left as the marker -50. */
+int dt_downslope(const float *dem, const uint8_t *fdr, int64_t H, int64_t W, double px,
+                 double elevation_difference, int raw, float *out);
+
+/* evaluation.binary_map + avaliacao for `nth` thresholds in one pass (evaluation.py:90-171):
+ * counts4[t*4 + v] = #cells with binary(desc, th[t]) + remapped(flood) == v, v = 0..3.
+ * Cells equal to `nodata_value` (the caller passes desc[0,0], evaluation.py:111) or NaN
+ * classify 0; flood is remapped 1 -> 2, -100 -> 0 on the fly (evaluation.py:149-150). */
+int dt_confusion_multi(const double *desc, const int8_t *flood, int64_t N, double nodata_value,
+                       const double *th, int nth, int under, int64_t *counts4);
+
+/* Synthetic "tilted integer fBm" DEM window, bit-identical to the oracle's. */
+int dt_synth_dem(uint32_t seed, int64_t Hg, int64_t Wg, int64_t y0, int64_t x0, int64_t h,
+                 int64_t w, int nodata_pct, float *out);
+
+/* ---- device-pointer tier (resident chain; all asynchronous on ctx's stream) ------------- */
+/* plain device memory for callers without their own allocator (numpy-only hosts) */
+int dt_dev_malloc(dt_ctx *ctx, int64_t bytes, void **out);
+int dt_dev_free(dt_ctx *ctx, void *p);
+int dt_dev_h2d(dt_ctx *ctx, void *dst_dev, const void *src_host, int64_t bytes); /* synchronous */
+int dt_dev_d2h(dt_ctx *ctx, void *dst_host, const void *src_dev, int64_t bytes); /* synchronous */
+int dt_dev_synth_dem(dt_ctx *ctx, uint32_t seed, int64_t Hg, int64_t Wg, int64_t y0, int64_t x0,
+                     int64_t h, int64_t w, int nodata_pct, float *out);
+/* slope (may be NULL), fdr (may be NULL), slope_rad (may be NULL): fused 3x3 stencil.
+ * slope_rad = float32(atan(slope/100)), -100 where dem == -100 (Example/example.py:63-64). */
+int dt_dev_slope_d8(dt_ctx *ctx, const float *dem, int64_t H, int64_t W, double px, float *slope,
+                    uint8_t *fdr, float *slope_rad);
+/* The north_star's fused "slope+TWI" stencil: one pass over dem (+ acc32) producing slope %
+ * (may be NULL), slope in radians (may be NULL), TI and MTI -- the slope raster never has to be
+ * re-read (topoindexes.py:234-295 on top of slope.py:210-259). */
+int dt_dev_slope_twi(dt_ctx *ctx, const float *dem, const int32_t *acc32, int64_t H, int64_t W,
+                     double px, double n_top, float *slope, float *slope_rad, float *ti, float *mti);
+/* acc32: int32 accumulation (H*W < 2^31); dem may be NULL. */
+int dt_dev_flowacc(dt_ctx *ctx, const uint8_t *fdr, const float *dem, int64_t H, int64_t W,
+                   int32_t *acc32);
+int dt_dev_river_mask(dt_ctx *ctx, const int32_t *acc32, int64_t N, int64_t threshold,
+                      int8_t *river);
+/* idx32: local flat index of the drained-to river cell (int32), -100 = none; a_river (may be
+ * NULL, needs acc32) = acc32[idx] carried as payload (removes gfi.river_accumulation's gather) */
+int dt_dev_flowhand(dt_ctx *ctx, const float *dem, const uint8_t *fdr, const int8_t *river,
+                    const int32_t *acc32, int64_t H, int64_t W, double px, float *fdist,
+                    int32_t *idx32, float *hand, int32_t *a_river);
+int dt_dev_twi(dt_ctx *ctx, const int32_t *acc32, const float *slope_rad, int64_t N, double px,
+               double n_top, float *ti, float *mti);
+/* a_river[i] = fac[idx[i]] (or anything where hand <= -100) */
+int dt_dev_gfi(dt_ctx *ctx, const float *hand, const int32_t *a_river, int64_t N, double n_gfi,
+               double scale_factor, double size, float *gfi);
+int dt_dev_lnhlh(dt_ctx *ctx, const float *hand, const int32_t *acc32, int64_t N, double n_gfi,
+                 double scale_factor, double size, float *out);
+int dt_dev_downslope(dt_ctx *ctx, const float *dem, const uint8_t *fdr, int64_t H, int64_t W,
+                     double px, double elevation_difference, int raw, float *out);
+/* counts4_dev: device int64[nth*4], zeroed by the call */
+int dt_dev_confusion_multi(dt_ctx *ctx, const double *desc, const int8_t *flood, int64_t N,
+                           double nodata_value, const double *th_host, int nth, int under,
+                           int64_t *counts4_dev);
+/* widen / narrow helpers for the int64 API dtypes */
+int dt_dev_i32_to_i64(dt_ctx *ctx, const int32_t *src, int64_t N, int64_t *dst);
+int dt_dev_i64_to_i32(dt_ctx *ctx, const int64_t *src, int64_t N, int32_t *dst);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DESCRIPTOOLS_HIP_H */

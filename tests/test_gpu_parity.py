@@ -1,0 +1,206 @@
+"""GPU parity (-m gpu): the HIP path, called through the C ABI (descriptools_amd -> ctypes ->
+libdescriptools_hip.so), against (1) the golden vectors generated from the reference's source,
+(2) the oracle on seeded synthetic DEMs, (3) the reference's own known-answer Example."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import assert_float_close, golden, load_example
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["syn_a", "syn_b", "syn_c", "ex_river", "ex_head", "ex_edge"]
+
+
+@pytest.fixture(scope="module")
+def dt():
+    import descriptools_amd.slope as slope
+    import descriptools_amd.flowdir as flowdir
+    import descriptools_amd.flowacc as flowacc
+    import descriptools_amd.flowhand as flowhand
+    import descriptools_amd.topoindexes as topoindexes
+    import descriptools_amd.gfi as gfi
+    import descriptools_amd.downslope as downslope
+    import descriptools_amd.evaluation as evaluation
+    from descriptools_amd import _lib
+    assert _lib.lib().dt_device_count() >= 1, "no GPU visible: the HIP path cannot run"
+
+    class NS:
+        pass
+    ns = NS()
+    ns.slope, ns.flowdir, ns.flowacc, ns.flowhand = slope, flowdir, flowacc, flowhand
+    ns.topoindexes, ns.gfi, ns.downslope, ns.evaluation = topoindexes, gfi, downslope, evaluation
+    return ns
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_golden_slope(dt, name):
+    g = golden(name)
+    sl = dt.slope.sloper(g["dem"], float(g["px"]))
+    assert sl.dtype == np.float64
+    assert np.array_equal(sl.astype(np.float32), g["slope"]), "slope: bit-exact"
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_golden_twi(dt, name):
+    g = golden(name)
+    ti, mti = dt.topoindexes.topographic_index(g["fac"], g["slope_rad"], float(g["px"]), float(g["n_top"]))
+    assert_float_close(ti, g["ti"], rtol=1e-5, what="ti")
+    assert_float_close(mti, g["mti"], rtol=1e-5, atol=1e-6, what="mti")
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_golden_flowhand(dt, name):
+    g = golden(name)
+    fd, idx, hand = dt.flowhand.flow_hand_index(g["dem"], g["fdr"], g["river"], float(g["px"]))
+    assert idx.dtype == np.int64 and fd.dtype == np.float32 and hand.dtype == g["dem"].dtype
+    assert np.array_equal(idx, g["idx"]), "river index: bit-exact"
+    assert np.array_equal(hand, g["hand"].astype(hand.dtype)), "HAND: bit-exact"
+    assert_float_close(fd, g["fdist"], rtol=1e-6, what="flow distance")
+    assert np.array_equal(dt.flowhand.hand_calculator(g["dem"], g["idx"]), g["hand"].astype(hand.dtype))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_golden_gfi(dt, name):
+    g = golden(name)
+    out = dt.gfi.gfi_calculator(g["hand"], g["fac"], g["idx"], float(g["n_gfi"]), float(g["b"]), float(g["px"]))
+    assert_float_close(out, g["gfi"], rtol=1e-5, atol=1e-6, what="gfi")
+    out = dt.gfi.ln_hl_H_calculator(g["hand"], g["fac"], float(g["n_gfi"]), float(g["b"]), float(g["px"]))
+    assert_float_close(out, g["lnhlh"], rtol=1e-5, atol=1e-6, what="lnhlh")
+    ra = dt.gfi.river_accumulation(g["fac"], g["idx"])
+    assert np.array_equal(ra, np.where(g["idx"] != -100, g["fac"].reshape(-1)[g["idx"]], g["fac"].reshape(-1)[0]))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_golden_downslope(dt, name):
+    g = golden(name)
+    out = dt.downslope.downsloper(g["dem"], g["fdr"], float(g["px"]), float(g["dz"]))
+    ref = g["down"]
+    pit = np.isnan(ref)  # 0/0 in the reference: undefined; the build returns 0
+    assert np.array_equal(out, np.where(pit, 0, ref)), "downslope: bit-exact"
+    raw = dt.downslope.downslope_cpu(g["dem"], g["fdr"], float(g["px"]), float(g["dz"]))
+    ok = raw != -50
+    assert np.array_equal(raw[ok].astype(np.float32), out[ok])
+    fixed = dt.downslope.downslope_sequential_jit(g["dem"], g["fdr"], float(g["px"]), float(g["dz"]),
+                                                  raw.astype(np.float32))
+    assert np.array_equal(fixed, out)
+
+
+def test_golden_edge_cases(dt):
+    g = golden("edge")
+    fd, idx, hand = dt.flowhand.flow_hand_index(g["fh_dem"], g["fh_fdr"], g["fh_river"], 10.0)
+    assert np.array_equal(idx, g["fh_idx"])
+    assert np.array_equal(hand, g["fh_hand"])
+    assert_float_close(fd, g["fh_fdist"], rtol=1e-6)
+    # 20000-move cap (flowhand.py:834-837)
+    W = int(g["cap_W"])
+    fdr = np.ones((1, W), np.uint8)
+    river = np.zeros((1, W), np.int8)
+    river[0, W - 1] = 1
+    fd, idx, _ = dt.flowhand.flow_hand_index(np.full((1, W), 5, np.int16), fdr, river, 10.0)
+    sel = g["cap_sel"]
+    assert np.array_equal(idx[0, sel], g["cap_idx"])
+    assert_float_close(fd[0, sel], g["cap_fdist"], rtol=1e-6)
+    assert idx[0, W - 1 - 20000] == W - 1 and idx[0, W - 1 - 20001] == -100
+    # long diagonal chain: sqrt(2) accumulation
+    n = int(g["diag_n"])
+    fdr = np.full((n, n), 2, np.uint8)
+    river = np.zeros((n, n), np.int8)
+    river[n - 1, n - 1] = 1
+    fd, idx, _ = dt.flowhand.flow_hand_index(np.full((n, n), 5, np.int16), fdr, river, 12.5)
+    sel = g["diag_sel"]
+    assert np.array_equal(idx.reshape(-1)[sel], g["diag_idx"])
+    assert_float_close(fd.reshape(-1)[sel], g["diag_fdist"], rtol=1e-6)
+    # downslope micro cases + 5000-iteration cap
+    out = dt.downslope.downsloper(g["ds_dem"], g["ds_fdr"], 10.0, 5)
+    assert np.array_equal(out, g["ds_out"])
+    out = dt.downslope.downsloper(g["dcap_dem"], np.ones(g["dcap_dem"].shape, np.uint8), 10.0, 5)
+    assert np.array_equal(out[0, g["dcap_sel"]], g["dcap_out"])
+    # pointwise special values
+    ti, mti = dt.topoindexes.topographic_index(g["pw_fac"], g["pw_slr"], 12.5, 0.1)
+    assert_float_close(ti, g["pw_ti"], rtol=1e-5)
+    assert_float_close(mti, g["pw_mti"], rtol=1e-5)
+    assert_float_close(dt.gfi.gfi_calculator(g["pw_hand"], g["pw_fac"], g["pw_idx"], 0.4, 0.1, 12.5),
+                       g["pw_gfi"], rtol=1e-5)
+    assert_float_close(dt.gfi.ln_hl_H_calculator(g["pw_hand"], g["pw_fac"], 0.4, 0.1, 12.5),
+                       g["pw_lnhlh"], rtol=1e-5)
+
+
+def test_golden_eval(dt):
+    g = golden("eval")
+    for k in range(3):
+        under = str(g["e%d_under" % k])
+        flood = g["e%d_flood" % k].copy()
+        desc = dt.evaluation.minMaxScale(g["e%d_hand" % k], g["e%d_mn" % k], g["e%d_mx" % k], -100)
+        assert np.array_equal(desc, g["e%d_desc" % k], equal_nan=True)
+        th = dt.evaluation.calibration(desc, flood, under)
+        assert th == float(g["e%d_th" % k]), "calibrated threshold: exact"
+        assert np.array_equal(flood, g["e%d_flood_after" % k]), "benchmark map remapped in place"
+        binary = dt.evaluation.binary_map(desc, th, under)
+        assert np.array_equal(binary, g["e%d_binary" % k])
+        c, f, cm = dt.evaluation.avaliacao(binary, flood)
+        assert c == float(g["e%d_c" % k]) and f == float(g["e%d_f" % k])
+        assert np.array_equal(cm, g["e%d_class" % k])
+
+
+@pytest.mark.parametrize("seed,H,W,nod", [(1, 257, 300, 0), (2, 512, 512, 4), (3, 1000, 1536, 0),
+                                           (4, 33, 1027, 3), (5, 1, 50, 0), (6, 70, 1, 0)])
+def test_oracle_synthetic_chain(dt, seed, H, W, nod):
+    """Whole chain vs the oracle on seeded synthetic DEMs (ragged shapes, nodata blobs)."""
+    px = 10.0
+    dem = oracle.synth_dem(seed, 2048, 2048, 100, 50, H, W, nod)
+    # device generator is bit-identical to the oracle's
+    from descriptools_amd import _lib
+    dev_dem = np.empty((H, W), np.float32)
+    _lib.check(_lib.lib().dt_synth_dem(seed, 2048, 2048, 100, 50, H, W, nod, _lib.ptr(dev_dem, _lib.c_f32p)))
+    assert np.array_equal(dev_dem, dem)
+    sl_o, fdr_o = oracle.slope_d8(dem, px)
+    fdr, sl = dt.flowdir.d8(dem, px, return_slope=True)
+    assert np.array_equal(fdr, fdr_o), "D8: bit-exact"
+    assert np.array_equal(sl, sl_o), "slope: bit-exact"
+    acc_o = oracle.flowacc(fdr_o, dem)
+    acc = dt.flowacc.accumulate(fdr, dem)
+    assert np.array_equal(acc, acc_o), "flow accumulation: bit-exact"
+    river = (acc > max(8, H * W // 512)).astype(np.int8)
+    fd_o, idx_o, hand_o = oracle.flowhand(dem, fdr, river, px)
+    fd, idx, hand = dt.flowhand.flow_hand_index(dem, fdr, river, px)
+    assert np.array_equal(idx, idx_o) and np.array_equal(hand, hand_o)
+    assert_float_close(fd, fd_o, rtol=1e-6, what="flow distance")
+    slr = np.where(dem == -100, -100, np.arctan(sl / 100)).astype(np.float32)
+    ti_o, mti_o = oracle.twi(acc, slr, px, 0.1)
+    ti, mti = dt.topoindexes.topographic_index_cpu(acc, slr, px, 0.1)
+    assert_float_close(ti, ti_o, rtol=1e-5, what="ti")
+    assert_float_close(mti, mti_o, rtol=1e-5, atol=1e-6, what="mti")
+    assert_float_close(dt.gfi.gfi_calculator(hand, acc, idx, 0.4, 0.1, px), oracle.gfi(hand, acc, idx, 0.4, 0.1, px),
+                       rtol=1e-5, atol=1e-6, what="gfi")
+    assert_float_close(dt.gfi.ln_hl_H_calculator(hand, acc, 0.4, 0.1, px), oracle.lnhlh(hand, acc, 0.4, 0.1, px),
+                       rtol=1e-5, atol=1e-6, what="lnhlh")
+    assert np.array_equal(dt.downslope.downsloper(dem, fdr, px, 5), oracle.downslope(dem, fdr, px, 5.0))
+
+
+def test_empty_rasters(dt):
+    assert dt.slope.sloper(np.zeros((0, 5), np.float32), 10.0).shape == (0, 5)
+    fd, idx, hand = dt.flowhand.flow_hand_index(np.zeros((0, 0), np.int16), np.zeros((0, 0), np.uint8),
+                                                np.zeros((0, 0), np.int8), 10.0)
+    assert fd.shape == (0, 0)
+
+
+def test_example_known_answer(dt):
+    """The reference's only KAT (Example/example.py:82-147): HAND -> minMaxScale -> calibration ->
+    binary_map -> avaliacao must reproduce Example/output/hand_class.tif exactly."""
+    dem, fdr, fac, river, flood, klass = load_example()
+    flow, idx, hand = dt.flowhand.flow_hand_index(dem, fdr, river, 12.5)
+    g = golden("example_full")
+    assert np.array_equal(idx, g["idx"].astype(np.int64))
+    assert np.array_equal(hand, g["hand"])
+    assert_float_close(flow, g["fdist"], rtol=1e-6, what="flow distance")
+    el = np.unique(hand)
+    mx, mn = el[-1], el[1]
+    assert (mn, mx) == (0, 259)
+    desc = dt.evaluation.minMaxScale(hand, mn, mx, -100)
+    th = dt.evaluation.calibration(desc, flood, 'under')
+    assert th == 0.012
+    binary = dt.evaluation.binary_map(desc, th, 'under')
+    c, f, cm = dt.evaluation.avaliacao(binary, flood)
+    assert c == 0.8581615676712259 and f == 0.7240945135019289
+    assert np.array_equal(cm.astype(np.uint8), klass), "class map == Example/output/hand_class.tif"
