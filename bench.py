@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- full descriptor chain on a device-resident synthetic DEM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size S]
+
+A step = one pass of the whole chain (slope -> D8 -> flow accumulation -> river mask -> flow
+distance / river index / HAND -> fused slope+TI+MTI -> GFI -> ln(hl/H) -> downslope) over one
+S x S "tilted integer fBm" DEM that is already in HBM when the timed region starts.
+N = 1 runs BASELINE.json configs[2], the 16384^2 DEM its metric is quoted on.  For N > 1 (launched
+by torch.distributed.run, one rank per GPU) every rank owns one S x S tile of a larger DEM (weak
+scaling).  Rank 0 prints ONE JSON line.
+
+Timing: K steps bracketed by barrier + synchronize on both sides, max over ranks.  Per-op times
+come from HIP events recorded on the stream the kernels run on, inside the same timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+
+# op -> (algorithmic bytes per cell).  "d8" writes fdr only (slope comes out of the
+# fused slope+TWI stencil: dem 4 + fac 4 read, slope 4 + slope_rad 4 + TI 4 + MTI 4 written; the
+# north_star's 20 B/cell figure counts slope+TI+MTI, slope_rad is an extra 4 B we also write).
+OPS = [("d8", 5), ("flowacc", 5), ("river_mask", 5), ("flowhand", 18 + 4), ("slope_twi", 20 + 4),
+       ("gfi", 12), ("lnhlh", 12), ("downslope", 9)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, default=16384, help="tile edge per GPU")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from descriptools_amd import _lib, chain
+    from descriptools_amd.device import Context
+    L = _lib.lib()
+
+    S = args.size
+    H = W = S
+    # a torch-owned NON-default stream: the library launches on it and torch events see it
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
+    ctx = Context(device=local_rank, stream=stream.cuda_stream)
+
+    # ---- tile layout: ranks tile a (ty*S) x (tx*S) DEM; rank r owns tile (r // tx, r % tx) ----
+    tx = 1
+    while tx * tx < world:
+        tx *= 2
+    ty = (world + tx - 1) // tx
+    Hg, Wg = ty * S, tx * S
+    y0, x0 = (rank // tx) * S, (rank % tx) * S
+
+    def alloc(shape, dt):
+        tdt = {np.float32: torch.float32, np.uint8: torch.uint8, np.int8: torch.int8,
+               np.int32: torch.int32}[dt]
+        return torch.empty(shape, dtype=tdt, device=dev)
+
+    bufs = {}
+
+    def alloc_ptr(shape, dt):
+        t = alloc(shape, dt)
+        bufs[len(bufs)] = t
+        return t.data_ptr()
+
+    dem = alloc((H, W), np.float32)
+    _lib.check(L.dt_dev_synth_dem(ctx.h, args.seed, Hg, Wg, y0, x0, H, W, 0, dem.data_ptr()))
+    ch = chain.Chain(H, W, ctx=ctx, px=10.0, river_threshold=(H * W) // 512, alloc=alloc_ptr)
+    p = ch.p
+    c = ctx.h
+    N = H * W
+
+    def op_calls():
+        return [
+            ("d8", lambda: L.dt_dev_slope_d8(c, dem.data_ptr(), H, W, ch.px, None, p("fdr"), None)),
+            ("flowacc", lambda: L.dt_dev_flowacc(c, p("fdr"), dem.data_ptr(), H, W, p("fac"))),
+            ("river_mask", lambda: L.dt_dev_river_mask(c, p("fac"), N, ch.river_threshold, p("river"))),
+            ("flowhand", lambda: L.dt_dev_flowhand(c, dem.data_ptr(), p("fdr"), p("river"), p("fac"), H, W,
+                                                   ch.px, p("fdist"), p("idx"), p("hand"), p("a_river"))),
+            ("slope_twi", lambda: L.dt_dev_slope_twi(c, dem.data_ptr(), p("fac"), H, W, ch.px, ch.n_top,
+                                                     p("slope"), p("slope_rad"), p("ti"), p("mti"))),
+            ("gfi", lambda: L.dt_dev_gfi(c, p("hand"), p("a_river"), N, ch.n_gfi, ch.b, ch.px, p("gfi"))),
+            ("lnhlh", lambda: L.dt_dev_lnhlh(c, p("hand"), p("fac"), N, ch.n_gfi, ch.b, ch.px, p("lnhlh"))),
+            ("downslope", lambda: L.dt_dev_downslope(c, dem.data_ptr(), p("fdr"), H, W, ch.px, ch.dz, 0,
+                                                     p("down"))),
+        ]
+
+    calls = op_calls()
+
+    def step(events=None):
+        for i, (name, fn) in enumerate(calls):
+            if events is not None:
+                events[i][0].record(stream)
+            _lib.check(fn())
+            if events is not None:
+                events[i][1].record(stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in calls]
+          for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(ev[k])
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- per-op device times (HIP events on the launch stream) ----
+    per_op = {}
+    for i, (name, bpc) in enumerate(OPS):
+        ms = float(np.mean([ev[k][i][0].elapsed_time(ev[k][i][1]) for k in range(args.steps)]))
+        gbs = N * bpc / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        per_op[name] = {"ms": round(ms, 4), "algo_bytes_per_cell": bpc, "achieved_GBs": round(gbs, 1),
+                        "frac": round(gbs / HBM_PEAK_GBS, 4)}
+    dom = max(per_op, key=lambda k: per_op[k]["ms"])
+    roof = {"kernel": dom, "bound": "hbm", "achieved": per_op[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": per_op[dom]["frac"], "traffic": None,
+            "note": "algorithmic bytes/cell x cells / mean op time from HIP events in the timed region"}
+
+    cells = N * world
+    value = cells * args.steps / dt / 1e6
+    out = {
+        "metric": "Mcells/s full descriptor chain", "value": round(value, 1), "unit": "Mcells/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%dx%d synthetic tilted-integer-fBm DEM per GPU, full chain "
+                               "(d8, flowacc, river mask, flowhand/HAND, fused slope+TI+MTI, GFI, ln(hl/H), "
+                               "downslope), device-resident" % (S, S),
+                   "global_dem": "%dx%d" % (Hg, Wg), "px": 10.0, "river_threshold_cells": ch.river_threshold,
+                   "parallelism": "1 tile per GPU" if world > 1 else "single GPU"},
+        "roofline": roof,
+        "per_op": per_op,
+        "chain_algo_bytes_per_cell": chain.ALGO_BYTES_PER_CELL,
+        "chain_frac_of_hbm_peak": round(cells * args.steps * chain.ALGO_BYTES_PER_CELL / dt / 1e9 / world
+                                        / HBM_PEAK_GBS, 4),
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.seed)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(seed, n=2048):
+    """The oracle (the reference's per-cell algorithms restated in C, single thread) timed on a
+    bounded sample: the same chain on an n x n DEM from the same generator.  Baseline only."""
+    import oracle
+    px = 10.0
+    dem = oracle.synth_dem(seed, n, n)
+    t0 = time.perf_counter()
+    sl, fdr = oracle.slope_d8(dem, px)
+    acc = oracle.flowacc(fdr, dem)
+    river = (acc > (n * n) // 512).astype(np.int8)
+    fd, idx, hand = oracle.flowhand(dem, fdr, river, px)
+    slr = np.where(dem == -100, -100, np.arctan(sl / 100)).astype(np.float32)
+    oracle.twi(acc, slr, px, 0.1)
+    oracle.gfi(hand, acc, idx, 0.4, 0.1, px)
+    oracle.lnhlh(hand, acc, 0.4, 0.1, px)
+    oracle.downslope(dem, fdr, px, 5.0)
+    dt = time.perf_counter() - t0
+    return {"value": round(n * n / dt / 1e6, 3), "unit": "Mcells/s", "cores": 1, "kind": "port",
+            "sample": "full chain on a %dx%d DEM of the same generator (%.1f s, oracle/dt_oracle.c, "
+                      "gcc -O2, 1 thread; reference-algorithm restatement, not Numba)" % (n, n, dt)}
+
+
+if __name__ == "__main__":
+    main()
