@@ -25,6 +25,7 @@ _SIGS = {
     "dt_last_error": (C.c_char_p, []),
     "dt_version": (C.c_char_p, []),
     "dt_device_count": (ci, []),
+    "dt_set_flow_impl": (ci, [ci]),
     "dt_ctx_create": (ci, [ci, vp, C.POINTER(vp)]),
     "dt_ctx_destroy": (ci, [vp]),
     "dt_ctx_set_stream": (ci, [vp, vp]),

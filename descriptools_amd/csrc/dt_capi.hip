@@ -1,5 +1,6 @@
 // dt_capi.hip -- extern "C" boundary of libdescriptools_hip.so (see include/descriptools_hip.h).
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include <mutex>
 
@@ -110,6 +111,21 @@ void *dt_scratch_take(dt_ctx *c, size_t bytes) {
   DT_REQUIRE((c) != nullptr, "ctx is NULL"); \
   DT_HIP(hipSetDevice((c)->device))
 
+// DT_FLOW_IMPL=v1 selects the first-generation global kernels for flow accumulation / HAND
+static int g_flow_impl = -1;
+static int dt_flow_impl() {
+  if (g_flow_impl < 0) {
+    const char *e = getenv("DT_FLOW_IMPL");
+    g_flow_impl = (e && strcmp(e, "v1") == 0) ? 1 : 2;
+  }
+  return g_flow_impl;
+}
+extern "C" int dt_set_flow_impl(int impl) {
+  DT_REQUIRE(impl == 1 || impl == 2, "impl must be 1 (global kernels) or 2 (tile-hierarchical)");
+  g_flow_impl = impl;
+  return DT_OK;
+}
+
 static int dt_check_hw(int64_t H, int64_t W) {
   DT_REQUIRE(H >= 0 && W >= 0, "negative raster shape");
   DT_REQUIRE(H * W < (1ll << 31), "rasters of >= 2^31 cells must be tiled (one tile per GPU)");
@@ -195,9 +211,16 @@ extern "C" int dt_dev_flowacc(dt_ctx *c, const uint8_t *fdr, const float *dem, i
   DT_CTX(c);
   DT_TRY(dt_check_hw(H, W));
   DT_REQUIRE((fdr && acc32) || H * W == 0, "NULL raster");
-  DT_TRY(dt_scratch_reset(c, (size_t)H * W * 8));
-  unsigned long long *state = (unsigned long long *)dt_scratch_take(c, (size_t)H * W * 8);
-  DT_TRY(dt_launch_flowacc(c->stream, fdr, dem, H, W, state, acc32));
+  if (dt_flow_impl() == 1) {  // v1: one global countdown (kept for A/B runs: DT_FLOW_IMPL=v1)
+    DT_TRY(dt_scratch_reset(c, (size_t)H * W * 8));
+    unsigned long long *state = (unsigned long long *)dt_scratch_take(c, (size_t)H * W * 8);
+    DT_TRY(dt_launch_flowacc(c->stream, fdr, dem, H, W, state, acc32));
+  } else {
+    size_t need = dt_flowacc_tiled_scratch(H, W);
+    DT_TRY(dt_scratch_reset(c, need));
+    void *scr = dt_scratch_take(c, need);
+    DT_TRY(dt_launch_flowacc_tiled(c->stream, fdr, dem, H, W, scr, need, acc32, 0, nullptr));
+  }
   DT_HIP(hipGetLastError());
   return DT_OK;
 }
@@ -219,9 +242,17 @@ extern "C" int dt_dev_flowhand(dt_ctx *c, const float *dem, const uint8_t *fdr, 
   DT_REQUIRE((fdr && river) || H * W == 0, "NULL raster");
   DT_REQUIRE(!hand || dem, "hand needs dem");
   DT_REQUIRE(!a_river || acc32, "a_river needs acc32");
-  DT_TRY(dt_scratch_reset(c, (size_t)H * W * 8));
-  unsigned long long *state = (unsigned long long *)dt_scratch_take(c, (size_t)H * W * 8);
-  DT_TRY(dt_launch_flowhand(c->stream, dem, fdr, river, acc32, H, W, px, state, fdist, idx32, hand, a_river));
+  if (dt_flow_impl() == 1) {
+    DT_TRY(dt_scratch_reset(c, (size_t)H * W * 8));
+    unsigned long long *state = (unsigned long long *)dt_scratch_take(c, (size_t)H * W * 8);
+    DT_TRY(dt_launch_flowhand(c->stream, dem, fdr, river, acc32, H, W, px, state, fdist, idx32, hand, a_river));
+  } else {
+    size_t need = dt_flowhand_tiled_scratch(H, W);
+    DT_TRY(dt_scratch_reset(c, need));
+    void *scr = dt_scratch_take(c, need);
+    DT_TRY(dt_launch_flowhand_tiled(c->stream, dem, fdr, river, acc32, H, W, px, scr, need, fdist, idx32, hand,
+                                    a_river));
+  }
   DT_HIP(hipGetLastError());
   return DT_OK;
 }

@@ -32,3 +32,14 @@ int dt_launch_confusion(hipStream_t s, const double *desc, const int8_t *flood, 
                         unsigned long long *counts4);
 int dt_launch_i32_to_i64(hipStream_t s, const int32_t *a, int64_t n, int64_t *b);
 int dt_launch_i64_to_i32(hipStream_t s, const int64_t *a, int64_t n, int32_t *b);
+
+// tile-hierarchical versions (dt_tiles.hip)
+size_t dt_flowacc_tiled_scratch(int64_t H, int64_t W);
+int dt_launch_flowacc_tiled(hipStream_t s, const uint8_t *fdr, const float *dem, int64_t H, int64_t W,
+                            void *scratch, size_t scratch_bytes, int32_t *acc32, int64_t river_thr,
+                            int8_t *river);
+size_t dt_flowhand_tiled_scratch(int64_t H, int64_t W);
+int dt_launch_flowhand_tiled(hipStream_t s, const float *dem, const uint8_t *fdr, const int8_t *river,
+                             const int32_t *acc32, int64_t H, int64_t W, double px, void *scratch,
+                             size_t scratch_bytes, float *fdist, int32_t *idx32, float *hand,
+                             int32_t *a_river);

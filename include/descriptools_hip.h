@@ -39,6 +39,9 @@ typedef struct dt_ctx dt_ctx;
 const char *dt_last_error(void);
 int dt_device_count(void);
 const char *dt_version(void);
+/* A/B knob: 1 = first-generation global kernels for flow accumulation / HAND, 2 = tile-hierarchical
+ * (default; also selectable with the environment variable DT_FLOW_IMPL=v1).  Same results. */
+int dt_set_flow_impl(int impl);
 
 /* Context = one device + one stream + grow-only scratch.  `stream` may be NULL (the context
  * creates its own non-blocking stream) or an existing hipStream_t (e.g. torch's). */
