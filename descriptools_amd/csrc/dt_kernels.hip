@@ -2,6 +2,8 @@
 //
 // All kernels are HBM-bound integer / float stencil, streaming or graph-propagation work: no MFMA.
 // Reference citations are file:line relative to /root/reference/descriptools/.
+#include <math.h>
+
 #include "dt_common.h"
 #include "dt_kernels.h"
 
@@ -146,17 +148,23 @@ __device__ __forceinline__ SlopeCell dt_slope_cell(float c, float nw, float n, f
 }
 
 // TI / MTI of one cell (topoindexes.py:234-295); float64 inside, float32 out.
-__device__ __forceinline__ void dt_twi_cell(int64_t fac, float srad, double px2, double n, float &ti,
+//   TI  = ln(A / t)   = ln A - ln t,      A = a * px^2 (a = fac, 0 -> 1), t = tan(slope + 0.01)
+//   MTI = ln(A^n / t) = n ln A - ln t
+// evaluated from two logarithms and one tangent instead of pow + 2 log + 2 divisions (the float64
+// difference to the reference's literal expression is ~1e-16 relative, invisible after the float32
+// rounding except at rounding ties; NaN / inf cases propagate identically: ln of a negative A or t
+// is NaN like pow / log of it).  lnpx2 = ln(px^2) is computed once on the host.
+__device__ __forceinline__ void dt_twi_cell(int64_t fac, float srad, double lnpx2, double n, float &ti,
                                             float &mti) {
   if (fac <= -100) {
     ti = DT_NODATA;
     mti = DT_NODATA;
     return;
   }
-  double a = fac == 0 ? px2 : (double)fac * px2;
-  double t = tan((double)srad + 0.01);
-  ti = (float)log(a / t);
-  mti = (float)log(pow(a, n) / t);
+  double la = (fac == 0 ? 0.0 : log((double)fac)) + lnpx2;
+  double lt = log(tan((double)srad + 0.01));
+  ti = (float)(la - lt);
+  mti = (float)(n * la - lt);
 }
 
 // slope % -> radians as Example/example.py:63-64 does on the host: float32 quotient, arctan,
@@ -173,8 +181,9 @@ __global__ __launch_bounds__(256) void k_stencil(const float *__restrict__ dem, 
                                                 uint8_t *__restrict__ fdr,
                                                 float *__restrict__ slope_rad,
                                                 const int32_t *__restrict__ acc32, double n_top,
-                                                float *__restrict__ ti, float *__restrict__ mti,
-                                                int tiles_x, int tiles_y, int vec_ok) {
+                                                double lnpx2, float *__restrict__ ti,
+                                                float *__restrict__ mti, int tiles_x, int tiles_y,
+                                                int vec_ok) {
   __shared__ __attribute__((aligned(16))) float t[(SD_TY + 2) * SD_LDW];
 
   // XCD-aware tile mapping: workgroup id b runs on XCD group (b % 8); give each group a band
@@ -224,7 +233,6 @@ __global__ __launch_bounds__(256) void k_stencil(const float *__restrict__ dem, 
   const int gx = x0 + cx;
   if (gx >= W) return;
   const double dcard = px, ddiag = px * sqrt(2.0);
-  const double px2 = px * px;
 
   // rolling 3-row window of 6 values (cols cx-1 .. cx+4)
   float a[6], bb[6], cc[6];
@@ -268,7 +276,7 @@ __global__ __launch_bounds__(256) void k_stencil(const float *__restrict__ dem, 
         if (W_TWI) {
           int xx = gx + k;
           int64_t f = xx < W ? (int64_t)acc32[(size_t)gy * W + xx] : -100;
-          dt_twi_cell(f, ro[k], px2, n_top, tio[k], mtio[k]);
+          dt_twi_cell(f, ro[k], lnpx2, n_top, tio[k], mtio[k]);
         }
       }
       size_t o = (size_t)gy * W + gx;
@@ -319,7 +327,7 @@ int dt_launch_stencil(hipStream_t s, const float *dem, int64_t H, int64_t W, dou
   bool ws = slope != nullptr, wf = fdr != nullptr, wr = slope_rad != nullptr, wt = ti != nullptr;
 #define DT_GO(S, F, R, T)                                                                          \
   hipLaunchKernelGGL((k_stencil<S, F, R, T>), g, b, 0, s, dem, (int)H, (int)W, px, slope, fdr,     \
-                     slope_rad, acc32, n_top, ti, mti, tiles_x, tiles_y, vec_ok)
+                     slope_rad, acc32, n_top, log(px * px), ti, mti, tiles_x, tiles_y, vec_ok)
   if (wt) {
     DT_REQUIRE(acc32 && mti, "fused TWI needs acc32, ti and mti");
     if (ws && wr) DT_GO(true, false, true, true);
@@ -565,23 +573,25 @@ int dt_launch_twi(hipStream_t s, const int32_t *acc32, const float *srad, int64_
                   double n_top, float *ti, float *mti) {
   if (n == 0) return DT_OK;
   hipLaunchKernelGGL(k_twi<int32_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, acc32, srad, n,
-                     px * px, n_top, ti, mti);
+                     log(px * px), n_top, ti, mti);
   return DT_OK;
 }
 int dt_launch_twi_i64(hipStream_t s, const int64_t *fac, const float *srad, int64_t n, double px,
                       double n_top, float *ti, float *mti) {
   if (n == 0) return DT_OK;
   hipLaunchKernelGGL(k_twi<int64_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, fac, srad, n,
-                     px * px, n_top, ti, mti);
+                     log(px * px), n_top, ti, mti);
   return DT_OK;
 }
 
 // gfi.py:268-294 (own_cell = false: A = a_river, no zero guard) and gfi.py:404-440 (own_cell =
-// true: A = fac, fac == 0 -> 1)
+// true: A = fac, fac == 0 -> 1):  ln(b * (A size^2)^n / (h + 0.01)) = c0 + n ln A - ln(h + 0.01)
+// with c0 = ln b + n ln(size^2) from the host; two logarithms instead of pow + log + division
+// (same remark on rounding and NaN / inf propagation as dt_twi_cell: A == 0 gives -inf, A < 0 NaN).
 template <bool OWN_CELL, typename IT>
 __global__ __launch_bounds__(256) void k_gfi(const float *__restrict__ hand,
                                             const IT *__restrict__ area, int64_t n, double expo,
-                                            double b, double size2, float *__restrict__ out) {
+                                            double c0, float *__restrict__ out) {
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   float h = hand[i];
@@ -590,23 +600,23 @@ __global__ __launch_bounds__(256) void k_gfi(const float *__restrict__ hand,
     return;
   }
   IT ar = area[i];
-  double a = (OWN_CELL && ar == 0) ? size2 : (double)ar * size2;
-  out[i] = (float)log((b * pow(a, expo)) / ((double)h + 0.01));
+  double la = (OWN_CELL && ar == 0) ? 0.0 : log((double)ar);
+  out[i] = (float)(c0 + expo * la - log((double)h + 0.01));
 }
 int dt_launch_gfi(hipStream_t s, const float *hand, const int32_t *area, int64_t n, double expo,
                   double b, double size, float *out, int own_cell) {
   if (n == 0) return DT_OK;
   dim3 g((unsigned)((n + 255) / 256)), bl(256);
-  if (own_cell) hipLaunchKernelGGL((k_gfi<true, int32_t>), g, bl, 0, s, hand, area, n, expo, b, size * size, out);
-  else hipLaunchKernelGGL((k_gfi<false, int32_t>), g, bl, 0, s, hand, area, n, expo, b, size * size, out);
+  if (own_cell) hipLaunchKernelGGL((k_gfi<true, int32_t>), g, bl, 0, s, hand, area, n, expo, log(b) + expo * log(size * size), out);
+  else hipLaunchKernelGGL((k_gfi<false, int32_t>), g, bl, 0, s, hand, area, n, expo, log(b) + expo * log(size * size), out);
   return DT_OK;
 }
 int dt_launch_gfi_i64(hipStream_t s, const float *hand, const int64_t *area, int64_t n, double expo,
                       double b, double size, float *out, int own_cell) {
   if (n == 0) return DT_OK;
   dim3 g((unsigned)((n + 255) / 256)), bl(256);
-  if (own_cell) hipLaunchKernelGGL((k_gfi<true, int64_t>), g, bl, 0, s, hand, area, n, expo, b, size * size, out);
-  else hipLaunchKernelGGL((k_gfi<false, int64_t>), g, bl, 0, s, hand, area, n, expo, b, size * size, out);
+  if (own_cell) hipLaunchKernelGGL((k_gfi<true, int64_t>), g, bl, 0, s, hand, area, n, expo, log(b) + expo * log(size * size), out);
+  else hipLaunchKernelGGL((k_gfi<false, int64_t>), g, bl, 0, s, hand, area, n, expo, log(b) + expo * log(size * size), out);
   return DT_OK;
 }
 // gfi.river_accumulation (gfi.py:119-147): A_r = fac.flat[idx] where idx != -100 else fac.flat[0]
@@ -660,8 +670,165 @@ __global__ __launch_bounds__(256) void k_downslope(const float *__restrict__ dem
   if (raw && failed) out[i] = -50.0f;
   else out[i] = dist == 0.0 ? 0.0f : (float)((double)drop / dist);
 }
+// Windowed version: a 1024-thread workgroup stages a 112 x 112 window (64 x 64 core + 24-cell
+// margin) in LDS as float32 heights plus one pre-decoded 16-bit "move word" per cell
+//   bits 0-8  window-index offset of the D8 successor, biased by 256
+//   bit  9    the move is diagonal
+//   bits 10.. why the fast walk must stop here: non-D8 code / the move leaves the raster / the
+//             cell is on the window's outer ring (successor may be outside the window)
+// so the inner loop is ~20 VALU instructions per move instead of ~60 (the global walk is
+// VALU-bound on D8 decoding and bounds tests, not latency-bound).  A walk that reaches the ring
+// continues on global memory with the generic step.  Same arithmetic as k_downslope: the path
+// length is the reference's sequential float64 sum (bit-identical results).  75 KiB of LDS: two
+// workgroups per CU; workgroups are banded per XCD so overlapping margins come from L2.
+#define DW_CORE 64
+#define DW_M 24
+#define DW_WIN (DW_CORE + 2 * DW_M) /* 112 */
+#define MW_DIAG 0x200u
+#define MW_BADCODE 0x400u
+#define MW_EDGE 0x800u
+#define MW_RING 0x1000u
+#define MW_STOP (MW_BADCODE | MW_EDGE | MW_RING)
+
+__global__ __launch_bounds__(1024) void k_downslope_win(const float *__restrict__ dem,
+                                                       const uint8_t *__restrict__ fdr, int H, int W,
+                                                       double px, double dz, float dzf, int raw,
+                                                       float *__restrict__ out, int tiles_x, int ntiles) {
+  __shared__ __attribute__((aligned(16))) float s_z[DW_WIN * DW_WIN];
+  __shared__ uint16_t s_w[DW_WIN * DW_WIN];
+  int b = blockIdx.x, tile;
+  {
+    int xcd = b & 7, j = b >> 3;
+    int q = ntiles >> 3, rem = ntiles & 7;
+    tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + j;
+  }
+  const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+  const int wy0 = tyi * DW_CORE - DW_M, wx0 = txi * DW_CORE - DW_M;
+  const bool vec = (W % 4 == 0) && (((uintptr_t)dem & 15) == 0) && (((uintptr_t)fdr & 3) == 0);
+  // 112 rows x 28 groups of 4 cells (wx0 is a multiple of 8: float4 / uchar4 stay aligned)
+  for (int i = threadIdx.x; i < DW_WIN * (DW_WIN / 4); i += 1024) {
+    int r = i / (DW_WIN / 4), c4 = (i - r * (DW_WIN / 4)) * 4;
+    int gy = wy0 + r, gx = wx0 + c4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t codes = 0;
+    if (gy >= 0 && gy < H) {
+      if (vec && gx >= 0 && gx + 3 < W) {
+        v = *reinterpret_cast<const float4 *>(dem + (size_t)gy * W + gx);
+        codes = *reinterpret_cast<const uint32_t *>(fdr + (size_t)gy * W + gx);
+      } else {
+        const float *p = dem + (size_t)gy * W;
+        const uint8_t *f = fdr + (size_t)gy * W;
+        if (gx >= 0 && gx < W) { v.x = p[gx]; codes |= (uint32_t)f[gx]; }
+        if (gx + 1 >= 0 && gx + 1 < W) { v.y = p[gx + 1]; codes |= (uint32_t)f[gx + 1] << 8; }
+        if (gx + 2 >= 0 && gx + 2 < W) { v.z = p[gx + 2]; codes |= (uint32_t)f[gx + 2] << 16; }
+        if (gx + 3 >= 0 && gx + 3 < W) { v.w = p[gx + 3]; codes |= (uint32_t)f[gx + 3] << 24; }
+      }
+    }
+    *reinterpret_cast<float4 *>(&s_z[r * DW_WIN + c4]) = v;
+    uint32_t w[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      uint32_t code = (codes >> (8 * k)) & 0xFFu;
+      int x = gx + k, rx = c4 + k;
+      uint32_t mw;
+      if (!dt_d8_valid(code)) {
+        mw = MW_BADCODE | 256u;
+      } else {
+        int dy, dx;
+        dt_d8_delta(code, dy, dx);
+        mw = (uint32_t)(dy * DW_WIN + dx + 256);
+        if (dy != 0 && dx != 0) mw |= MW_DIAG;
+        if (gy + dy < 0 || gy + dy >= H || x + dx < 0 || x + dx >= W) mw |= MW_EDGE;
+      }
+      if (r == 0 || r == DW_WIN - 1 || rx == 0 || rx == DW_WIN - 1) mw |= MW_RING;
+      w[k] = mw;
+    }
+    *reinterpret_cast<uint2 *>(&s_w[r * DW_WIN + c4]) = make_uint2(w[0] | (w[1] << 16), w[2] | (w[3] << 16));
+  }
+  __syncthreads();
+  const double dcard = px, ddiag = px * sqrt(2.0);
+  for (int j = 0; j < (DW_CORE * DW_CORE) / 1024; j++) {
+    int c = threadIdx.x + 1024 * j;
+    int cy = c / DW_CORE, cx = c - cy * DW_CORE;
+    int y0 = tyi * DW_CORE + cy, x0 = txi * DW_CORE + cx;
+    if (y0 >= H || x0 >= W) continue;
+    int pos = (cy + DW_M) * DW_WIN + cx + DW_M;
+    float z0 = s_z[pos];
+    size_t o = (size_t)y0 * W + x0;
+    if (z0 <= DT_NODATA) {
+      out[o] = DT_NODATA;
+      continue;
+    }
+    double dist = 0.0;
+    float drop = 0.0f;
+    int loop = 0;
+    bool failed = false, slow = false;
+    // Fast walk inside the window: one loop, one exit test, everything else predicated (the lanes
+    // of a wave iterate until the longest walk ends anyway).  (double)drop < dz  <=>  drop < dzf
+    // (dzf = smallest float >= dz).  The next cell's height and move word are fetched together.
+    uint32_t mw = s_w[pos];
+    bool nodata_ahead = false;
+    bool running = drop < dzf;
+    while (running) {
+      bool stop = (mw & MW_STOP) != 0u;
+      int np = stop ? pos : pos + (int)(mw & 0x1FFu) - 256;
+      float zt = s_z[np];
+      uint32_t mwn = s_w[np];
+      bool nod = !stop && zt == DT_NODATA;  // :231-281: stop without moving
+      bool ok = !stop && !nod;
+      nodata_ahead = nodata_ahead || nod;
+      dist += ok ? ((mw & MW_DIAG) ? ddiag : dcard) : 0.0;
+      drop = ok ? z0 - zt : drop;
+      pos = ok ? np : pos;
+      mw = ok ? mwn : mw;
+      loop += ok ? 1 : 0;
+      running = ok && loop != 5000 && drop < dzf;
+    }
+    if (loop == 5000 || nodata_ahead) failed = true;  // :303-304 / :518-521 (cap precedes the drop test)
+    else if (drop < dzf) {
+      // stopped on a move word: a non-D8 code never moves again (the reference spins to its cap),
+      // a move off the raster stops the walk (downslope.py:209-228); the ring continues below
+      if (mw & (MW_BADCODE | MW_EDGE)) failed = true;
+      else slow = true;
+    }
+    if (slow) {  // on the window ring: finish on global memory
+      int y = wy0 + pos / DW_WIN, x = wx0 + pos % DW_WIN;
+      while ((double)drop < dz) {
+        uint32_t code = fdr[(size_t)y * W + x];
+        if (!dt_d8_valid(code)) { failed = true; break; }
+        int dy, dx;
+        dt_d8_delta(code, dy, dx);
+        int ny = y + dy, nx = x + dx;
+        if (ny < 0 || ny >= H || nx < 0 || nx >= W) { failed = true; break; }
+        float zt = dem[(size_t)ny * W + nx];
+        if (zt == DT_NODATA) { failed = true; break; }
+        y = ny;
+        x = nx;
+        dist += (dy != 0 && dx != 0) ? ddiag : dcard;
+        drop = z0 - zt;
+        if (++loop == 5000) { failed = true; break; }
+      }
+    }
+    if (raw && failed) out[o] = -50.0f;
+    else out[o] = dist == 0.0 ? 0.0f : (float)((double)drop / dist);
+  }
+}
+
 int dt_launch_downslope(hipStream_t s, const float *dem, const uint8_t *fdr, int64_t H, int64_t W,
                         double px, double dz, int raw, float *out) {
+  int64_t n = H * W;
+  if (n == 0) return DT_OK;
+  int tiles_x = (int)((W + DW_CORE - 1) / DW_CORE), tiles_y = (int)((H + DW_CORE - 1) / DW_CORE);
+  int64_t ntiles = (int64_t)tiles_x * tiles_y;
+  // (double)drop < dz  <=>  drop < dzf with dzf the smallest float >= dz
+  float dzf = (float)dz;
+  if ((double)dzf < dz) dzf = nextafterf(dzf, INFINITY);
+  hipLaunchKernelGGL(k_downslope_win, dim3((unsigned)ntiles), dim3(1024), 0, s, dem, fdr, (int)H, (int)W, px,
+                     dz, dzf, raw, out, tiles_x, (int)ntiles);
+  return DT_OK;
+}
+int dt_launch_downslope_v1(hipStream_t s, const float *dem, const uint8_t *fdr, int64_t H, int64_t W,
+                           double px, double dz, int raw, float *out) {
   int64_t n = H * W;
   if (n == 0) return DT_OK;
   hipLaunchKernelGGL(k_downslope, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dem, fdr, (int)H,
