@@ -29,8 +29,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 ach
 # op -> (algorithmic bytes per cell).  "d8" writes fdr only (slope comes out of the
 # fused slope+TWI stencil: dem 4 + fac 4 read, slope 4 + slope_rad 4 + TI 4 + MTI 4 written; the
 # north_star's 20 B/cell figure counts slope+TI+MTI, slope_rad is an extra 4 B we also write).
-OPS = [("d8", 5), ("flowacc", 5), ("river_mask", 5), ("flowhand", 18 + 4), ("slope_twi", 20 + 4),
-       ("gfi", 12), ("lnhlh", 12), ("downslope", 9)]
+OPS = [("d8", 5), ("flowacc_river", 5 + 1), ("flowhand", 18 + 4), ("slope_twi", 20 + 4),
+       ("gfi_lnhlh", 4 + 4 + 4 + 4 + 4), ("downslope", 9)]
 
 
 def main():
@@ -98,14 +98,14 @@ def main():
     def op_calls():
         return [
             ("d8", lambda: L.dt_dev_slope_d8(c, dem.data_ptr(), H, W, ch.px, None, p("fdr"), None)),
-            ("flowacc", lambda: L.dt_dev_flowacc(c, p("fdr"), dem.data_ptr(), H, W, p("fac"))),
-            ("river_mask", lambda: L.dt_dev_river_mask(c, p("fac"), N, ch.river_threshold, p("river"))),
+            ("flowacc_river", lambda: L.dt_dev_flowacc_river(c, p("fdr"), dem.data_ptr(), H, W,
+                                                             ch.river_threshold, p("fac"), p("river"))),
             ("flowhand", lambda: L.dt_dev_flowhand(c, dem.data_ptr(), p("fdr"), p("river"), p("fac"), H, W,
                                                    ch.px, p("fdist"), p("idx"), p("hand"), p("a_river"))),
             ("slope_twi", lambda: L.dt_dev_slope_twi(c, dem.data_ptr(), p("fac"), H, W, ch.px, ch.n_top,
                                                      p("slope"), p("slope_rad"), p("ti"), p("mti"))),
-            ("gfi", lambda: L.dt_dev_gfi(c, p("hand"), p("a_river"), N, ch.n_gfi, ch.b, ch.px, p("gfi"))),
-            ("lnhlh", lambda: L.dt_dev_lnhlh(c, p("hand"), p("fac"), N, ch.n_gfi, ch.b, ch.px, p("lnhlh"))),
+            ("gfi_lnhlh", lambda: L.dt_dev_gfi_lnhlh(c, p("hand"), p("a_river"), p("fac"), N, ch.n_gfi, ch.b,
+                                                     ch.px, p("gfi"), p("lnhlh"))),
             ("downslope", lambda: L.dt_dev_downslope(c, dem.data_ptr(), p("fdr"), H, W, ch.px, ch.dz, 0,
                                                      p("down"))),
         ]
@@ -179,7 +179,7 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(seed, n=2048):
+def cpu_baseline(seed, n=3072):
     """The oracle (the reference's per-cell algorithms restated in C, single thread) timed on a
     bounded sample: the same chain on an n x n DEM from the same generator.  Baseline only."""
     import oracle

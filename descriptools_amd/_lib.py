@@ -56,6 +56,8 @@ _SIGS = {
     "dt_dev_slope_twi": (ci, [vp, vp, vp, i64, i64, f64, f64, vp, vp, vp, vp]),
     "dt_dev_flowacc": (ci, [vp, vp, vp, i64, i64, vp]),
     "dt_dev_river_mask": (ci, [vp, vp, i64, i64, vp]),
+    "dt_dev_flowacc_river": (ci, [vp, vp, vp, i64, i64, i64, vp, vp]),
+    "dt_dev_gfi_lnhlh": (ci, [vp, vp, vp, vp, i64, f64, f64, f64, vp, vp]),
     "dt_dev_flowhand": (ci, [vp, vp, vp, vp, vp, i64, i64, f64, vp, vp, vp, vp]),
     "dt_dev_twi": (ci, [vp, vp, vp, i64, f64, f64, vp, vp]),
     "dt_dev_gfi": (ci, [vp, vp, vp, i64, f64, f64, f64, vp]),

@@ -41,14 +41,13 @@ class Chain:
         L, c, H, W, N = _lib.lib(), self.ctx.h, self.H, self.W, self.N
         p = self.p
         check(L.dt_dev_slope_d8(c, dem_ptr, H, W, self.px, None, p("fdr"), None))
-        check(L.dt_dev_flowacc(c, p("fdr"), dem_ptr, H, W, p("fac")))
-        check(L.dt_dev_river_mask(c, p("fac"), N, self.river_threshold, p("river")))
+        check(L.dt_dev_flowacc_river(c, p("fdr"), dem_ptr, H, W, self.river_threshold, p("fac"), p("river")))
         check(L.dt_dev_flowhand(c, dem_ptr, p("fdr"), p("river"), p("fac"), H, W, self.px, p("fdist"),
                                 p("idx"), p("hand"), p("a_river")))
         check(L.dt_dev_slope_twi(c, dem_ptr, p("fac"), H, W, self.px, self.n_top, p("slope"),
                                  p("slope_rad"), p("ti"), p("mti")))
-        check(L.dt_dev_gfi(c, p("hand"), p("a_river"), N, self.n_gfi, self.b, self.px, p("gfi")))
-        check(L.dt_dev_lnhlh(c, p("hand"), p("fac"), N, self.n_gfi, self.b, self.px, p("lnhlh")))
+        check(L.dt_dev_gfi_lnhlh(c, p("hand"), p("a_river"), p("fac"), N, self.n_gfi, self.b, self.px,
+                                 p("gfi"), p("lnhlh")))
         check(L.dt_dev_downslope(c, dem_ptr, p("fdr"), H, W, self.px, self.dz, 0, p("down")))
 
     def free(self):

@@ -284,6 +284,32 @@ extern "C" int dt_dev_lnhlh(dt_ctx *c, const float *hand, const int32_t *acc32, 
   return DT_OK;
 }
 
+extern "C" int dt_dev_gfi_lnhlh(dt_ctx *c, const float *hand, const int32_t *a_river, const int32_t *acc32,
+                                int64_t N, double n_gfi, double b, double size, float *gfi, float *lnhlh) {
+  DT_CTX(c);
+  DT_REQUIRE((hand && a_river && acc32 && gfi && lnhlh) || N == 0, "NULL raster");
+  DT_TRY(dt_launch_gfi_both(c->stream, hand, a_river, acc32, N, n_gfi, b, size, gfi, lnhlh));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+
+extern "C" int dt_dev_flowacc_river(dt_ctx *c, const uint8_t *fdr, const float *dem, int64_t H, int64_t W,
+                                    int64_t threshold, int32_t *acc32, int8_t *river) {
+  DT_CTX(c);
+  DT_TRY(dt_check_hw(H, W));
+  DT_REQUIRE((fdr && acc32 && river) || H * W == 0, "NULL raster");
+  if (dt_flow_impl() == 1) {
+    DT_TRY(dt_dev_flowacc(c, fdr, dem, H, W, acc32));
+    return dt_dev_river_mask(c, acc32, H * W, threshold, river);
+  }
+  size_t need = dt_flowacc_tiled_scratch(H, W);
+  DT_TRY(dt_scratch_reset(c, need));
+  void *scr = dt_scratch_take(c, need);
+  DT_TRY(dt_launch_flowacc_tiled(c->stream, fdr, dem, H, W, scr, need, acc32, threshold, river));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+
 extern "C" int dt_dev_downslope(dt_ctx *c, const float *dem, const uint8_t *fdr, int64_t H, int64_t W,
                                 double px, double dz, int raw, float *out) {
   DT_CTX(c);

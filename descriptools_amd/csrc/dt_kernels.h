@@ -43,3 +43,5 @@ int dt_launch_flowhand_tiled(hipStream_t s, const float *dem, const uint8_t *fdr
                              const int32_t *acc32, int64_t H, int64_t W, double px, void *scratch,
                              size_t scratch_bytes, float *fdist, int32_t *idx32, float *hand,
                              int32_t *a_river);
+int dt_launch_gfi_both(hipStream_t s, const float *hand, const int32_t *a_river, const int32_t *fac,
+                       int64_t n, double expo, double b, double size, float *gfi, float *lnhlh);

@@ -603,6 +603,34 @@ __global__ __launch_bounds__(256) void k_gfi(const float *__restrict__ hand,
   double la = (OWN_CELL && ar == 0) ? 0.0 : log((double)ar);
   out[i] = (float)(c0 + expo * la - log((double)h + 0.01));
 }
+// GFI and ln(hl/H) in one pass: hand is read once and ln(h + 0.01) evaluated once (3 logs / cell
+// instead of 4, 12 + 4 bytes / cell instead of 24)
+__global__ __launch_bounds__(256) void k_gfi_both(const float *__restrict__ hand,
+                                                 const int32_t *__restrict__ a_river,
+                                                 const int32_t *__restrict__ fac, int64_t n, double expo,
+                                                 double c0, float *__restrict__ gfi,
+                                                 float *__restrict__ lnhlh) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float h = hand[i];
+  if (h <= DT_NODATA) {
+    gfi[i] = DT_NODATA;
+    lnhlh[i] = DT_NODATA;
+    return;
+  }
+  double lh = c0 - log((double)h + 0.01);
+  int32_t f = fac[i];
+  gfi[i] = (float)(lh + expo * log((double)a_river[i]));
+  lnhlh[i] = (float)(lh + (f == 0 ? 0.0 : expo * log((double)f)));
+}
+int dt_launch_gfi_both(hipStream_t s, const float *hand, const int32_t *a_river, const int32_t *fac,
+                       int64_t n, double expo, double b, double size, float *gfi, float *lnhlh) {
+  if (n == 0) return DT_OK;
+  hipLaunchKernelGGL(k_gfi_both, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, hand, a_river, fac, n,
+                     expo, log(b) + expo * log(size * size), gfi, lnhlh);
+  return DT_OK;
+}
+
 int dt_launch_gfi(hipStream_t s, const float *hand, const int32_t *area, int64_t n, double expo,
                   double b, double size, float *out, int own_cell) {
   if (n == 0) return DT_OK;

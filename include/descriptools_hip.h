@@ -133,6 +133,10 @@ int dt_dev_slope_twi(dt_ctx *ctx, const float *dem, const int32_t *acc32, int64_
 /* acc32: int32 accumulation (H*W < 2^31); dem may be NULL. */
 int dt_dev_flowacc(dt_ctx *ctx, const uint8_t *fdr, const float *dem, int64_t H, int64_t W,
                    int32_t *acc32);
+/* flow accumulation with the river mask (acc > threshold, Example/example.py:52) written by the
+ * same final pass */
+int dt_dev_flowacc_river(dt_ctx *ctx, const uint8_t *fdr, const float *dem, int64_t H, int64_t W,
+                         int64_t threshold, int32_t *acc32, int8_t *river);
 int dt_dev_river_mask(dt_ctx *ctx, const int32_t *acc32, int64_t N, int64_t threshold,
                       int8_t *river);
 /* idx32: local flat index of the drained-to river cell (int32), -100 = none; a_river (may be
@@ -147,6 +151,9 @@ int dt_dev_gfi(dt_ctx *ctx, const float *hand, const int32_t *a_river, int64_t N
                double scale_factor, double size, float *gfi);
 int dt_dev_lnhlh(dt_ctx *ctx, const float *hand, const int32_t *acc32, int64_t N, double n_gfi,
                  double scale_factor, double size, float *out);
+/* GFI and ln(hl/H) fused: one read of hand, ln(hand + 0.01) evaluated once */
+int dt_dev_gfi_lnhlh(dt_ctx *ctx, const float *hand, const int32_t *a_river, const int32_t *acc32,
+                     int64_t N, double n_gfi, double scale_factor, double size, float *gfi, float *lnhlh);
 int dt_dev_downslope(dt_ctx *ctx, const float *dem, const uint8_t *fdr, int64_t H, int64_t W,
                      double px, double elevation_difference, int raw, float *out);
 /* counts4_dev: device int64[nth*4], zeroed by the call */
