@@ -1,0 +1,91 @@
+"""CPU (not gpu): the C-ABI library builds, loads without a GPU, and exports every symbol that
+include/descriptools_hip.h declares; the Python binding table matches the header; the product path
+fails loudly (no CPU fallback) when no GPU is visible."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "descriptools_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(dt_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_builds_and_exports_header_symbols():
+    from descriptools_amd import build
+    so = build.build()
+    lib = ctypes.CDLL(so)
+    syms = header_symbols()
+    assert len(syms) > 35
+    for s in syms:
+        assert hasattr(lib, s), "header declares %s but the library does not export it" % s
+
+
+def test_binding_table_matches_header():
+    from descriptools_amd import _lib
+    bound = set(_lib.exported_symbols())
+    declared = set(header_symbols())
+    assert bound <= declared, "bound but not declared: %s" % sorted(bound - declared)
+    # every host-tier entry point of the header is bound
+    missing = {s for s in declared - bound if not s.startswith("dt_dev_") and not s.startswith("dt_ctx_")}
+    assert not missing, "declared but not bound: %s" % sorted(missing)
+    L = _lib.lib()
+    assert L.dt_version().startswith(b"descriptools_hip")
+
+
+def test_no_cpu_fallback_without_gpu():
+    from descriptools_amd import _lib, slope, flowhand, topoindexes
+    if _lib.lib().dt_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        slope.sloper(np.zeros((8, 8), np.float32), 10.0)
+    with pytest.raises(RuntimeError):
+        flowhand.flow_hand_index(np.zeros((8, 8), np.int16), np.ones((8, 8), np.uint8),
+                                 np.zeros((8, 8), np.int8), 10.0)
+    with pytest.raises(RuntimeError):
+        topoindexes.topographic_index(np.ones((8, 8), np.int64), np.zeros((8, 8), np.float32), 10.0, 0.1)
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under descriptools_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "descriptools_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, f
+                assert "dt_oracle" not in txt or f in ("dt_kernels.hip",), f
+
+
+def test_helpers_divisor_matches_golden():
+    from conftest import golden
+    from descriptools_amd import helpers
+    g = golden("edge")
+    r, c = helpers.divisor(100, 37, 3, 2)
+    assert np.array_equal(r, g["div_a"]) and np.array_equal(c, g["div_b"])
+    r, c = helpers.divisor(10, 10, 0, 0)
+    assert r.size == 0 and c.size == 0
+
+
+def test_evaluation_host_functions_match_golden():
+    """minMaxScale / binary_map / avaliacao keep the reference's numpy semantics (no GPU needed)."""
+    from conftest import golden
+    from descriptools_amd import evaluation
+    g = golden("eval")
+    for k in range(3):
+        under = str(g["e%d_under" % k])
+        desc = evaluation.minMaxScale(g["e%d_hand" % k], g["e%d_mn" % k], g["e%d_mx" % k], -100)
+        assert np.array_equal(desc, g["e%d_desc" % k], equal_nan=True)
+        binary = evaluation.binary_map(desc, float(g["e%d_th" % k]), under)
+        assert np.array_equal(binary, g["e%d_binary" % k])
+        flood = g["e%d_flood" % k].copy()
+        c, f, cm = evaluation.avaliacao(binary, flood)
+        assert c == float(g["e%d_c" % k]) and f == float(g["e%d_f" % k])
+        assert np.array_equal(cm, g["e%d_class" % k])
+        assert np.array_equal(flood, g["e%d_flood_after" % k])

@@ -167,3 +167,22 @@ def test_synth_dem_properties():
         assert np.array_equal(win, dem[100:150, 37:98])
         _, fdr = oracle.slope_d8(dem, 10.0)
         assert (fdr != 0).all()
+
+
+def test_example_known_answer_oracle():
+    """The reference's KAT through the oracle: HAND -> calibration counts -> class map equals
+    Example/output/hand_class.tif and the full-size reference outputs (example_full.npz)."""
+    dem, fdr, fac, river, flood, klass = load_example()
+    g = golden("example_full")
+    idx, nc, nd = oracle.flowhand_fast(fdr, river)
+    assert np.array_equal(idx, g["idx"].astype(np.int64))
+    d32 = dem.astype(np.float32).reshape(-1)
+    hand = np.where((d32 != -100) & (idx.reshape(-1) != -100), d32 - d32[idx.reshape(-1)], -100)
+    hand = np.where((hand < 0) & (hand != -100), 0, hand).reshape(dem.shape)
+    assert np.array_equal(hand.astype(np.int16), g["hand"])
+    desc = np.where(hand == -100, np.nan, (hand - float(g["mn"])) / (float(g["mx"]) - float(g["mn"])))
+    desc[0, 0] = np.nan
+    counts = oracle.confusion_multi(np.nan_to_num(desc, nan=-7.0), flood, [float(g["th"])], True)
+    # nodata was mapped to -7 and desc[0] == -7 marks it as the nodata value (evaluation.py:111)
+    assert np.array_equal(counts[0], g["counts"])
+    assert np.array_equal(np.bincount(klass.reshape(-1).astype(np.int64), minlength=4), g["counts"])
