@@ -64,9 +64,22 @@ _SIGS = {
     "dt_dev_lnhlh": (ci, [vp, vp, vp, i64, f64, f64, f64, vp]),
     "dt_dev_downslope": (ci, [vp, vp, vp, i64, i64, f64, f64, ci, vp]),
     "dt_dev_confusion_multi": (ci, [vp, vp, vp, i64, f64, c_f64p, ci, ci, vp]),
+    "dt_perim_cells": (i64, [i64, i64]),
+    "dt_dev_slope_d8_w": (ci, [vp, vp, vp, f64, vp, vp, vp]),
+    "dt_dev_slope_twi_w": (ci, [vp, vp, vp, vp, f64, f64, vp, vp, vp, vp]),
+    "dt_dev_downslope_w": (ci, [vp, vp, vp, vp, f64, f64, ci, vp, vp]),
+    "dt_dev_flowacc_local_w": (ci, [vp, vp, vp, vp, vp, vp, vp]),
+    "dt_dev_flowacc_finish_w": (ci, [vp, vp, vp, vp, vp, i64, vp, vp]),
+    "dt_dev_flowhand_local_w": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "dt_dev_flowhand_finish_w": (ci, [vp, vp, vp, vp, vp, vp, f64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "dt_dev_i32_to_i64": (ci, [vp, vp, i64, vp]),
     "dt_dev_i64_to_i32": (ci, [vp, vp, i64, vp]),
 }
+
+
+class Window(C.Structure):
+    """dt_window: one rank's core window of a global raster (see include/descriptools_hip.h)."""
+    _fields_ = [(n, C.c_int64) for n in ("H", "W", "ld", "gy0", "gx0", "Hg", "Wg", "halo")]
 
 
 def exported_symbols():

@@ -126,6 +126,25 @@ extern "C" int dt_set_flow_impl(int impl) {
   return DT_OK;
 }
 
+static DtWin dt_full_window(int64_t H, int64_t W) {
+  DtWin w;
+  w.H = (int)H; w.W = (int)W; w.ld = W; w.gy0 = 0; w.gx0 = 0; w.Hg = (int)H; w.Wg = (int)W; w.halo = 0;
+  return w;
+}
+static int dt_convert_window(const dt_window *in, DtWin *out) {
+  DT_REQUIRE(in != nullptr, "window is NULL");
+  DT_REQUIRE(in->H >= 0 && in->W >= 0 && in->H * in->W < (1ll << 31), "bad core shape");
+  DT_REQUIRE(in->ld >= in->W, "ld < W");
+  DT_REQUIRE(in->Hg < (1ll << 31) && in->Wg < (1ll << 31) && in->gy0 >= 0 && in->gx0 >= 0 &&
+                 in->gy0 + in->H <= in->Hg && in->gx0 + in->W <= in->Wg, "core window outside the global raster");
+  DT_REQUIRE(in->halo >= 0, "negative halo");
+  bool touches_all = in->gy0 == 0 && in->gx0 == 0 && in->gy0 + in->H == in->Hg && in->gx0 + in->W == in->Wg;
+  DT_REQUIRE(touches_all || in->halo >= 1, "a window inside a larger raster needs a halo of >= 1 cell");
+  out->H = (int)in->H; out->W = (int)in->W; out->ld = in->ld; out->gy0 = (int)in->gy0; out->gx0 = (int)in->gx0;
+  out->Hg = (int)in->Hg; out->Wg = (int)in->Wg; out->halo = (int)in->halo;
+  return DT_OK;
+}
+
 static int dt_check_hw(int64_t H, int64_t W) {
   DT_REQUIRE(H >= 0 && W >= 0, "negative raster shape");
   DT_REQUIRE(H * W < (1ll << 31), "rasters of >= 2^31 cells must be tiled (one tile per GPU)");
@@ -170,7 +189,8 @@ extern "C" int dt_dev_slope_twi(dt_ctx *c, const float *dem, const int32_t *acc3
   DT_CTX(c);
   DT_TRY(dt_check_hw(H, W));
   DT_REQUIRE((dem && acc32 && ti && mti) || H * W == 0, "NULL raster");
-  DT_TRY(dt_launch_stencil(c->stream, dem, H, W, px, slope, nullptr, slope_rad, acc32, n_top, ti, mti));
+  DT_TRY(dt_launch_stencil(c->stream, dt_full_window(H, W), dem, px, slope, nullptr, slope_rad, acc32, n_top, ti,
+                           mti));
   DT_HIP(hipGetLastError());
   return DT_OK;
 }
@@ -201,7 +221,8 @@ extern "C" int dt_dev_slope_d8(dt_ctx *c, const float *dem, int64_t H, int64_t W
   DT_TRY(dt_check_hw(H, W));
   DT_REQUIRE(dem || H * W == 0, "dem is NULL");
   DT_REQUIRE(slope || fdr || slope_rad, "no output requested");
-  DT_TRY(dt_launch_stencil(c->stream, dem, H, W, px, slope, fdr, slope_rad, nullptr, 0.0, nullptr, nullptr));
+  DT_TRY(dt_launch_stencil(c->stream, dt_full_window(H, W), dem, px, slope, fdr, slope_rad, nullptr, 0.0, nullptr,
+                           nullptr));
   DT_HIP(hipGetLastError());
   return DT_OK;
 }
@@ -219,7 +240,9 @@ extern "C" int dt_dev_flowacc(dt_ctx *c, const uint8_t *fdr, const float *dem, i
     size_t need = dt_flowacc_tiled_scratch(H, W);
     DT_TRY(dt_scratch_reset(c, need));
     void *scr = dt_scratch_take(c, need);
-    DT_TRY(dt_launch_flowacc_tiled(c->stream, fdr, dem, H, W, scr, need, acc32, 0, nullptr));
+    DtWin w = dt_full_window(H, W);
+    DT_TRY(dt_launch_fa_local(c->stream, w, fdr, scr, need, acc32, 0));
+    DT_TRY(dt_launch_fa_finish(c->stream, w, fdr, dem, scr, nullptr, 0, acc32, nullptr));
   }
   DT_HIP(hipGetLastError());
   return DT_OK;
@@ -250,8 +273,10 @@ extern "C" int dt_dev_flowhand(dt_ctx *c, const float *dem, const uint8_t *fdr, 
     size_t need = dt_flowhand_tiled_scratch(H, W);
     DT_TRY(dt_scratch_reset(c, need));
     void *scr = dt_scratch_take(c, need);
-    DT_TRY(dt_launch_flowhand_tiled(c->stream, dem, fdr, river, acc32, H, W, px, scr, need, fdist, idx32, hand,
-                                    a_river));
+    DtWin w = dt_full_window(H, W);
+    DT_TRY(dt_launch_fh_local(c->stream, w, fdr, river, scr, need));
+    DT_TRY(dt_launch_fh_finish(c->stream, w, dem, fdr, river, acc32, px, scr, nullptr, nullptr, nullptr, nullptr,
+                               nullptr, nullptr, fdist, idx32, nullptr, hand, a_river));
   }
   DT_HIP(hipGetLastError());
   return DT_OK;
@@ -305,7 +330,9 @@ extern "C" int dt_dev_flowacc_river(dt_ctx *c, const uint8_t *fdr, const float *
   size_t need = dt_flowacc_tiled_scratch(H, W);
   DT_TRY(dt_scratch_reset(c, need));
   void *scr = dt_scratch_take(c, need);
-  DT_TRY(dt_launch_flowacc_tiled(c->stream, fdr, dem, H, W, scr, need, acc32, threshold, river));
+  DtWin w = dt_full_window(H, W);
+  DT_TRY(dt_launch_fa_local(c->stream, w, fdr, scr, need, acc32, 0));
+  DT_TRY(dt_launch_fa_finish(c->stream, w, fdr, dem, scr, nullptr, threshold, acc32, river));
   DT_HIP(hipGetLastError());
   return DT_OK;
 }
@@ -315,7 +342,7 @@ extern "C" int dt_dev_downslope(dt_ctx *c, const float *dem, const uint8_t *fdr,
   DT_CTX(c);
   DT_TRY(dt_check_hw(H, W));
   DT_REQUIRE((dem && fdr && out) || H * W == 0, "NULL raster");
-  DT_TRY(dt_launch_downslope(c->stream, dem, fdr, H, W, px, dz, raw, out));
+  DT_TRY(dt_launch_downslope(c->stream, dt_full_window(H, W), dem, fdr, px, dz, raw, out, nullptr));
   DT_HIP(hipGetLastError());
   return DT_OK;
 }
@@ -341,6 +368,112 @@ extern "C" int dt_dev_i32_to_i64(dt_ctx *c, const int32_t *src, int64_t N, int64
 extern "C" int dt_dev_i64_to_i32(dt_ctx *c, const int64_t *src, int64_t N, int32_t *dst) {
   DT_CTX(c);
   DT_TRY(dt_launch_i64_to_i32(c->stream, src, N, dst));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+
+// ---- windowed device tier (one rank's core window of a larger raster; multi-GPU) ------------------
+extern "C" int64_t dt_perim_cells(int64_t H, int64_t W) { return dt_perim_count((int)H, (int)W); }
+
+extern "C" int dt_dev_slope_d8_w(dt_ctx *c, const dt_window *win, const float *dem, double px, float *slope,
+                                 uint8_t *fdr, float *slope_rad) {
+  DT_CTX(c);
+  DtWin w;
+  DT_TRY(dt_convert_window(win, &w));
+  DT_REQUIRE(dem && (slope || fdr || slope_rad), "NULL raster");
+  DT_TRY(dt_launch_stencil(c->stream, w, dem, px, slope, fdr, slope_rad, nullptr, 0.0, nullptr, nullptr));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+
+extern "C" int dt_dev_slope_twi_w(dt_ctx *c, const dt_window *win, const float *dem, const int32_t *acc32,
+                                  double px, double n_top, float *slope, float *slope_rad, float *ti,
+                                  float *mti) {
+  DT_CTX(c);
+  DtWin w;
+  DT_TRY(dt_convert_window(win, &w));
+  DT_REQUIRE(dem && acc32 && ti && mti, "NULL raster");
+  DT_TRY(dt_launch_stencil(c->stream, w, dem, px, slope, nullptr, slope_rad, acc32, n_top, ti, mti));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+
+extern "C" int dt_dev_downslope_w(dt_ctx *c, const dt_window *win, const float *dem, const uint8_t *fdr,
+                                  double px, double dz, int raw, float *out, int32_t *n_unresolved_dev) {
+  DT_CTX(c);
+  DtWin w;
+  DT_TRY(dt_convert_window(win, &w));
+  DT_REQUIRE(dem && fdr && out, "NULL raster");
+  if (n_unresolved_dev) DT_HIP(hipMemsetAsync(n_unresolved_dev, 0, sizeof(int32_t), c->stream));
+  DT_TRY(dt_launch_downslope(c->stream, w, dem, fdr, px, dz, raw, out, (int *)n_unresolved_dev));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+
+extern "C" int dt_dev_flowacc_local_w(dt_ctx *c, const dt_window *win, const uint8_t *fdr, int32_t *acc32,
+                                      int64_t *A_perim, int32_t *xr_perim, uint8_t *code_perim) {
+  DT_CTX(c);
+  DtWin w;
+  DT_TRY(dt_convert_window(win, &w));
+  DT_REQUIRE(fdr && acc32 && A_perim && xr_perim && code_perim, "NULL pointer");
+  size_t need = dt_flowacc_tiled_scratch(w.H, w.W);
+  DT_TRY(dt_scratch_reset(c, need));
+  void *scr = dt_scratch_take(c, need);
+  DT_TRY(dt_launch_fa_local(c->stream, w, fdr, scr, need, acc32, 1));
+  DT_TRY(dt_launch_fa_summary(c->stream, w, scr, A_perim, xr_perim, code_perim));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+
+// must follow dt_dev_flowacc_local_w on the same context with no other scratch-using call in between
+extern "C" int dt_dev_flowacc_finish_w(dt_ctx *c, const dt_window *win, const uint8_t *fdr, const float *dem,
+                                       const uint64_t *ext_perim, int64_t threshold, int32_t *acc32,
+                                       int8_t *river) {
+  DT_CTX(c);
+  DtWin w;
+  DT_TRY(dt_convert_window(win, &w));
+  DT_REQUIRE(fdr && acc32, "NULL raster");
+  DT_REQUIRE(c->scratch && c->scratch_bytes >= dt_flowacc_tiled_scratch(w.H, w.W), "no local phase before finish");
+  DT_TRY(dt_launch_fa_finish(c->stream, w, fdr, dem, c->scratch, (const unsigned long long *)ext_perim, threshold,
+                             acc32, river));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+
+extern "C" int dt_dev_flowhand_local_w(dt_ctx *c, const dt_window *win, const float *dem, const uint8_t *fdr,
+                                       const int8_t *river, const int32_t *acc32, uint8_t *kind, int32_t *ref,
+                                       int32_t *nc, int32_t *nd, float *zr, int32_t *ar) {
+  DT_CTX(c);
+  DtWin w;
+  DT_TRY(dt_convert_window(win, &w));
+  DT_REQUIRE(fdr && river && kind && ref && nc && nd && zr && ar, "NULL pointer");
+  size_t need = dt_flowhand_tiled_scratch(w.H, w.W);
+  DT_TRY(dt_scratch_reset(c, need));
+  void *scr = dt_scratch_take(c, need);
+  DT_TRY(dt_launch_fh_local(c->stream, w, fdr, river, scr, need));
+  DT_TRY(dt_launch_fh_summary(c->stream, w, scr, dem, acc32, kind, ref, nc, nd, zr, ar));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+
+// must follow dt_dev_flowhand_local_w on the same context with no other scratch-using call in between
+extern "C" int dt_dev_flowhand_finish_w(dt_ctx *c, const dt_window *win, const float *dem, const uint8_t *fdr,
+                                        const int8_t *river, const int32_t *acc32, double px,
+                                        const uint8_t *res_ok, const int32_t *res_nc, const int32_t *res_nd,
+                                        const int64_t *rem_gidx, const float *rem_zr, const int32_t *rem_ar,
+                                        float *fdist, int32_t *idx32, int64_t *idx64, float *hand,
+                                        int32_t *a_river) {
+  DT_CTX(c);
+  DtWin w;
+  DT_TRY(dt_convert_window(win, &w));
+  DT_REQUIRE(fdr && river, "NULL raster");
+  DT_REQUIRE(!hand || dem, "hand needs dem");
+  DT_REQUIRE(!a_river || acc32, "a_river needs acc32");
+  DT_REQUIRE(!res_ok || (res_nc && res_nd && rem_gidx && rem_zr && rem_ar), "incomplete rank-exit results");
+  DT_REQUIRE(c->scratch && c->scratch_bytes >= dt_flowhand_tiled_scratch(w.H, w.W), "no local phase before finish");
+  DT_TRY(dt_launch_fh_finish(c->stream, w, dem, fdr, river, acc32, px, c->scratch, res_ok, res_nc, res_nd,
+                             (const long long *)rem_gidx, rem_zr, rem_ar, fdist, idx32, (long long *)idx64, hand,
+                             a_river));
   DT_HIP(hipGetLastError());
   return DT_OK;
 }

@@ -71,3 +71,52 @@ __device__ __forceinline__ void dt_d8_delta(uint32_t code, int &dy, int &dx) {
   dx = (int)((DT_DX_PACK >> (2 * i)) & 3u) - 1;
   dy = (int)((DT_DY_PACK >> (2 * i)) & 3u) - 1;
 }
+
+// ---- raster window -------------------------------------------------------------------------------
+// A core window of H x W cells inside rasters of row stride ld, placed at (gy0, gx0) of a global
+// Hg x Wg raster.  Raster pointers are relative to the core origin: cell (y, x) is p[y * ld + x].
+// `halo` cells beyond the core are present in memory on every side (0 for a single-GPU raster, where
+// the core IS the global raster: ld = W, gy0 = gx0 = 0, Hg = H, Wg = W).
+struct DtWin {
+  int H, W;
+  long long ld;
+  int gy0, gx0, Hg, Wg;
+  int halo;
+};
+__host__ __device__ __forceinline__ bool dt_in_core(const DtWin &w, int y, int x) {
+  return y >= 0 && y < w.H && x >= 0 && x < w.W;
+}
+// inside the global raster AND present in memory
+__host__ __device__ __forceinline__ bool dt_readable(const DtWin &w, int y, int x) {
+  int gy = w.gy0 + y, gx = w.gx0 + x;
+  return gy >= 0 && gy < w.Hg && gx >= 0 && gx < w.Wg && y >= -w.halo && y < w.H + w.halo && x >= -w.halo &&
+         x < w.W + w.halo;
+}
+__host__ __device__ __forceinline__ bool dt_in_global(const DtWin &w, int y, int x) {
+  int gy = w.gy0 + y, gx = w.gx0 + x;
+  return gy >= 0 && gy < w.Hg && gx >= 0 && gx < w.Wg;
+}
+// ring of the core window ("rank perimeter"), P cells: top row, bottom row, left column, right column
+__host__ __device__ __forceinline__ long long dt_perim_count(int H, int W) {
+  if (H <= 0 || W <= 0) return 0;
+  if (H == 1) return W;
+  if (W == 1) return H;
+  return 2ll * W + 2ll * (H - 2);
+}
+__host__ __device__ __forceinline__ long long dt_perim_index(int H, int W, int y, int x) {
+  if (H == 1) return x;
+  if (W == 1) return y;
+  if (y == 0) return x;
+  if (y == H - 1) return (long long)W + x;
+  if (x == 0) return 2ll * W + (y - 1);
+  if (x == W - 1) return 2ll * W + (H - 2) + (y - 1);
+  return -1;
+}
+__host__ __device__ __forceinline__ void dt_perim_cell(int H, int W, long long i, int &y, int &x) {
+  if (H == 1) { y = 0; x = (int)i; return; }
+  if (W == 1) { y = (int)i; x = 0; return; }
+  if (i < W) { y = 0; x = (int)i; }
+  else if (i < 2ll * W) { y = H - 1; x = (int)(i - W); }
+  else if (i < 2ll * W + (H - 2)) { y = (int)(i - 2ll * W) + 1; x = 0; }
+  else { y = (int)(i - 2ll * W - (H - 2)) + 1; x = W - 1; }
+}

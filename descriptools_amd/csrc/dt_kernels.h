@@ -4,7 +4,7 @@
 
 int dt_launch_synth_dem(hipStream_t s, uint32_t seed, int O, int64_t Hg, int64_t y0, int64_t x0,
                         int64_t h, int64_t w, int nodata_pct, float *out);
-int dt_launch_stencil(hipStream_t s, const float *dem, int64_t H, int64_t W, double px, float *slope,
+int dt_launch_stencil(hipStream_t s, const DtWin &w, const float *dem, double px, float *slope,
                       uint8_t *fdr, float *slope_rad, const int32_t *acc32, double n_top, float *ti,
                       float *mti);
 int dt_launch_flowacc(hipStream_t s, const uint8_t *fdr, const float *dem, int64_t H, int64_t W,
@@ -24,8 +24,10 @@ int dt_launch_gfi_i64(hipStream_t s, const float *hand, const int64_t *area, int
                       double b, double size, float *out, int own_cell);
 int dt_launch_river_acc_i64(hipStream_t s, const int64_t *fac, const int64_t *idx, int64_t n,
                             int64_t *out);
-int dt_launch_downslope(hipStream_t s, const float *dem, const uint8_t *fdr, int64_t H, int64_t W,
-                        double px, double dz, int raw, float *out);
+int dt_launch_downslope(hipStream_t s, const DtWin &w, const float *dem, const uint8_t *fdr, double px,
+                        double dz, int raw, float *out, int *n_unresolved);
+int dt_launch_downslope_v1(hipStream_t s, const float *dem, const uint8_t *fdr, int64_t H, int64_t W,
+                           double px, double dz, int raw, float *out);
 int dt_launch_hand_i64(hipStream_t s, const float *dem, const int64_t *idx, int64_t n, float *hand);
 int dt_launch_confusion(hipStream_t s, const double *desc, const int8_t *flood, int64_t n,
                         double nodata, const double *th_host, int nth, int under,
@@ -33,15 +35,24 @@ int dt_launch_confusion(hipStream_t s, const double *desc, const int8_t *flood, 
 int dt_launch_i32_to_i64(hipStream_t s, const int32_t *a, int64_t n, int64_t *b);
 int dt_launch_i64_to_i32(hipStream_t s, const int64_t *a, int64_t n, int32_t *b);
 
-// tile-hierarchical versions (dt_tiles.hip)
+// tile-hierarchical versions (dt_tiles.hip); two phases so that a multi-GPU run can exchange the
+// rank-level summaries in between (single GPU: local + finish with no injection)
 size_t dt_flowacc_tiled_scratch(int64_t H, int64_t W);
-int dt_launch_flowacc_tiled(hipStream_t s, const uint8_t *fdr, const float *dem, int64_t H, int64_t W,
-                            void *scratch, size_t scratch_bytes, int32_t *acc32, int64_t river_thr,
-                            int8_t *river);
+int dt_launch_fa_local(hipStream_t s, const DtWin &w, const uint8_t *fdr, void *scratch, size_t scratch_bytes,
+                       int32_t *acc32, int rank_level);
+int dt_launch_fa_summary(hipStream_t s, const DtWin &w, void *scratch, int64_t *A, int32_t *xr, uint8_t *code);
+int dt_launch_fa_finish(hipStream_t s, const DtWin &w, const uint8_t *fdr, const float *dem, void *scratch,
+                        const unsigned long long *ext_perim, int64_t river_thr, int32_t *acc32,
+                        int8_t *river);
 size_t dt_flowhand_tiled_scratch(int64_t H, int64_t W);
-int dt_launch_flowhand_tiled(hipStream_t s, const float *dem, const uint8_t *fdr, const int8_t *river,
-                             const int32_t *acc32, int64_t H, int64_t W, double px, void *scratch,
-                             size_t scratch_bytes, float *fdist, int32_t *idx32, float *hand,
-                             int32_t *a_river);
+int dt_launch_fh_local(hipStream_t s, const DtWin &w, const uint8_t *fdr, const int8_t *river, void *scratch,
+                       size_t scratch_bytes);
+int dt_launch_fh_summary(hipStream_t s, const DtWin &w, void *scratch, const float *dem, const int32_t *acc32,
+                         uint8_t *kind, int32_t *ref, int32_t *nc, int32_t *nd, float *zr, int32_t *ar);
+int dt_launch_fh_finish(hipStream_t s, const DtWin &w, const float *dem, const uint8_t *fdr,
+                        const int8_t *river, const int32_t *acc32, double px, void *scratch,
+                        const uint8_t *res_ok, const int32_t *res_nc, const int32_t *res_nd,
+                        const long long *rem_gidx, const float *rem_zr, const int32_t *rem_ar, float *fdist,
+                        int32_t *idx32, long long *idx64, float *hand, int32_t *a_river);
 int dt_launch_gfi_both(hipStream_t s, const float *hand, const int32_t *a_river, const int32_t *fac,
                        int64_t n, double expo, double b, double size, float *gfi, float *lnhlh);

@@ -176,7 +176,7 @@ __device__ __forceinline__ float dt_slope_rad(float slope_pct, float dem) {
 }
 
 template <bool W_SLOPE, bool W_FDR, bool W_RAD, bool W_TWI>
-__global__ __launch_bounds__(256) void k_stencil(const float *__restrict__ dem, int H, int W,
+__global__ __launch_bounds__(256) void k_stencil(const float *__restrict__ dem, DtWin w,
                                                 double px, float *__restrict__ slope,
                                                 uint8_t *__restrict__ fdr,
                                                 float *__restrict__ slope_rad,
@@ -200,20 +200,24 @@ __global__ __launch_bounds__(256) void k_stencil(const float *__restrict__ dem, 
   int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
   int x0 = txi * SD_TX, y0 = tyi * SD_TY;
 
-  // ---- stage (SD_TY + 2) x (SD_TX + 2) cells; outside the raster = -100 ring (slope.py:175) ----
+  const int H = w.H, W = w.W;
+  // ---- stage (SD_TY + 2) x (SD_TX + 2) cells; outside the GLOBAL raster = -100 ring (slope.py:175);
+  // cells outside the core but inside the global raster come from the halo of the window ----
+  const int ylo = -(w.gy0 > 0 ? 1 : 0), yhi = H + (w.gy0 + H < w.Hg ? 1 : 0);  // readable rows [ylo, yhi)
+  const int xlo = -(w.gx0 > 0 ? 1 : 0), xhi = W + (w.gx0 + W < w.Wg ? 1 : 0);
   for (int i = threadIdx.x; i < (SD_TY + 2) * (SD_TX / 4); i += 256) {
     int r = i / (SD_TX / 4), c4 = i - r * (SD_TX / 4);
     int gy = y0 - 1 + r, gx = x0 + c4 * 4;
     float4 v = make_float4(DT_NODATA, DT_NODATA, DT_NODATA, DT_NODATA);
-    if (gy >= 0 && gy < H) {
-      const float *p = dem + (size_t)gy * W + gx;
-      if (vec_ok && gx + 3 < W) {
+    if (gy >= ylo && gy < yhi) {
+      const float *p = dem + (long long)gy * w.ld + gx;
+      if (vec_ok && gx + 3 < xhi) {
         v = *reinterpret_cast<const float4 *>(p);
       } else {
-        if (gx < W) v.x = p[0];
-        if (gx + 1 < W) v.y = p[1];
-        if (gx + 2 < W) v.z = p[2];
-        if (gx + 3 < W) v.w = p[3];
+        if (gx < xhi) v.x = p[0];
+        if (gx + 1 < xhi) v.y = p[1];
+        if (gx + 2 < xhi) v.z = p[2];
+        if (gx + 3 < xhi) v.w = p[3];
       }
     }
     *reinterpret_cast<float4 *>(&t[r * SD_LDW + 4 + c4 * 4]) = v;
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(256) void k_stencil(const float *__restrict__ dem, 
     int r = i >> 1, side = i & 1;
     int gy = y0 - 1 + r, gx = side ? x0 + SD_TX : x0 - 1;
     float v = DT_NODATA;
-    if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = dem[(size_t)gy * W + gx];
+    if (gy >= ylo && gy < yhi && gx >= xlo && gx < xhi) v = dem[(long long)gy * w.ld + gx];
     t[r * SD_LDW + (side ? 4 + SD_TX : 3)] = v;
   }
   __syncthreads();
@@ -263,23 +267,23 @@ __global__ __launch_bounds__(256) void k_stencil(const float *__restrict__ dem, 
         uint32_t code = sc.code;
         if (W_FDR) {
           // N1 border rule: a border cell with no lower neighbour drains out of the raster
-          int xx = gx + k;
+          int gyy = w.gy0 + gy, gxx = w.gx0 + gx + k;  // global position
           if (code == 0u && bb[k + 1] > DT_NODATA) {
-            if (gy == H - 1) code = 4u;
-            else if (gy == 0) code = 64u;
-            else if (xx == 0) code = 16u;
-            else if (xx == W - 1) code = 1u;
+            if (gyy == w.Hg - 1) code = 4u;
+            else if (gyy == 0) code = 64u;
+            else if (gxx == 0) code = 16u;
+            else if (gxx == w.Wg - 1) code = 1u;
           }
           codes |= code << (8 * k);
         }
         if (W_RAD || W_TWI) ro[k] = dt_slope_rad(sc.slope, bb[k + 1]);
         if (W_TWI) {
           int xx = gx + k;
-          int64_t f = xx < W ? (int64_t)acc32[(size_t)gy * W + xx] : -100;
+          int64_t f = xx < W ? (int64_t)acc32[(long long)gy * w.ld + xx] : -100;
           dt_twi_cell(f, ro[k], lnpx2, n_top, tio[k], mtio[k]);
         }
       }
-      size_t o = (size_t)gy * W + gx;
+      long long o = (long long)gy * w.ld + gx;
       bool full = vec_ok && gx + 3 < W;
       if (full) {
         if (W_SLOPE) *reinterpret_cast<float4 *>(slope + o) = make_float4(so[0], so[1], so[2], so[3]);
@@ -312,21 +316,22 @@ __global__ __launch_bounds__(256) void k_stencil(const float *__restrict__ dem, 
   }
 }
 
-int dt_launch_stencil(hipStream_t s, const float *dem, int64_t H, int64_t W, double px, float *slope,
+int dt_launch_stencil(hipStream_t s, const DtWin &w, const float *dem, double px, float *slope,
                       uint8_t *fdr, float *slope_rad, const int32_t *acc32, double n_top, float *ti,
                       float *mti) {
+  const int64_t H = w.H, W = w.W;
   if (H == 0 || W == 0) return DT_OK;
   int tiles_x = (int)((W + SD_TX - 1) / SD_TX), tiles_y = (int)((H + SD_TY - 1) / SD_TY);
   int64_t ntiles = (int64_t)tiles_x * tiles_y;
   DT_REQUIRE(ntiles < (1ll << 31), "raster too large for one launch");
   // 16-byte vector path needs W % 4 == 0 and 16-byte aligned bases
-  int vec_ok = (W % 4 == 0) && (((uintptr_t)dem & 15) == 0) && (!slope || ((uintptr_t)slope & 15) == 0) &&
+  int vec_ok = (W % 4 == 0) && (w.ld % 4 == 0) && (((uintptr_t)dem & 15) == 0) && (!slope || ((uintptr_t)slope & 15) == 0) &&
                (!slope_rad || ((uintptr_t)slope_rad & 15) == 0) && (!ti || ((uintptr_t)ti & 15) == 0) &&
                (!mti || ((uintptr_t)mti & 15) == 0) && (!fdr || ((uintptr_t)fdr & 3) == 0);
   dim3 g((unsigned)ntiles), b(256);
   bool ws = slope != nullptr, wf = fdr != nullptr, wr = slope_rad != nullptr, wt = ti != nullptr;
 #define DT_GO(S, F, R, T)                                                                          \
-  hipLaunchKernelGGL((k_stencil<S, F, R, T>), g, b, 0, s, dem, (int)H, (int)W, px, slope, fdr,     \
+  hipLaunchKernelGGL((k_stencil<S, F, R, T>), g, b, 0, s, dem, w, px, slope, fdr,                  \
                      slope_rad, acc32, n_top, log(px * px), ti, mti, tiles_x, tiles_y, vec_ok)
   if (wt) {
     DT_REQUIRE(acc32 && mti, "fused TWI needs acc32, ti and mti");
@@ -719,9 +724,10 @@ __global__ __launch_bounds__(256) void k_downslope(const float *__restrict__ dem
 #define MW_STOP (MW_BADCODE | MW_EDGE | MW_RING)
 
 __global__ __launch_bounds__(1024) void k_downslope_win(const float *__restrict__ dem,
-                                                       const uint8_t *__restrict__ fdr, int H, int W,
+                                                       const uint8_t *__restrict__ fdr, DtWin w,
                                                        double px, double dz, float dzf, int raw,
-                                                       float *__restrict__ out, int tiles_x, int ntiles) {
+                                                       float *__restrict__ out, int tiles_x, int ntiles,
+                                                       int *__restrict__ n_unresolved) {
   __shared__ __attribute__((aligned(16))) float s_z[DW_WIN * DW_WIN];
   __shared__ uint16_t s_w[DW_WIN * DW_WIN];
   int b = blockIdx.x, tile;
@@ -732,32 +738,33 @@ __global__ __launch_bounds__(1024) void k_downslope_win(const float *__restrict_
   }
   const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
   const int wy0 = tyi * DW_CORE - DW_M, wx0 = txi * DW_CORE - DW_M;
-  const bool vec = (W % 4 == 0) && (((uintptr_t)dem & 15) == 0) && (((uintptr_t)fdr & 3) == 0);
+  const bool vec = (w.ld % 4 == 0) && (((uintptr_t)dem & 15) == 0) && (((uintptr_t)fdr & 3) == 0);
   // 112 rows x 28 groups of 4 cells (wx0 is a multiple of 8: float4 / uchar4 stay aligned)
   for (int i = threadIdx.x; i < DW_WIN * (DW_WIN / 4); i += 1024) {
     int r = i / (DW_WIN / 4), c4 = (i - r * (DW_WIN / 4)) * 4;
     int gy = wy0 + r, gx = wx0 + c4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     uint32_t codes = 0;
-    if (gy >= 0 && gy < H) {
-      if (vec && gx >= 0 && gx + 3 < W) {
-        v = *reinterpret_cast<const float4 *>(dem + (size_t)gy * W + gx);
-        codes = *reinterpret_cast<const uint32_t *>(fdr + (size_t)gy * W + gx);
-      } else {
-        const float *p = dem + (size_t)gy * W;
-        const uint8_t *f = fdr + (size_t)gy * W;
-        if (gx >= 0 && gx < W) { v.x = p[gx]; codes |= (uint32_t)f[gx]; }
-        if (gx + 1 >= 0 && gx + 1 < W) { v.y = p[gx + 1]; codes |= (uint32_t)f[gx + 1] << 8; }
-        if (gx + 2 >= 0 && gx + 2 < W) { v.z = p[gx + 2]; codes |= (uint32_t)f[gx + 2] << 16; }
-        if (gx + 3 >= 0 && gx + 3 < W) { v.w = p[gx + 3]; codes |= (uint32_t)f[gx + 3] << 24; }
-      }
+    bool rd[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) rd[k] = dt_readable(w, gy, gx + k);
+    if (vec && rd[0] && rd[3]) {
+      v = *reinterpret_cast<const float4 *>(dem + (long long)gy * w.ld + gx);
+      codes = *reinterpret_cast<const uint32_t *>(fdr + (long long)gy * w.ld + gx);
+    } else {
+      const float *p = dem + (long long)gy * w.ld;
+      const uint8_t *f = fdr + (long long)gy * w.ld;
+      if (rd[0]) { v.x = p[gx]; codes |= (uint32_t)f[gx]; }
+      if (rd[1]) { v.y = p[gx + 1]; codes |= (uint32_t)f[gx + 1] << 8; }
+      if (rd[2]) { v.z = p[gx + 2]; codes |= (uint32_t)f[gx + 2] << 16; }
+      if (rd[3]) { v.w = p[gx + 3]; codes |= (uint32_t)f[gx + 3] << 24; }
     }
     *reinterpret_cast<float4 *>(&s_z[r * DW_WIN + c4]) = v;
-    uint32_t w[4];
+    uint32_t mwv[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       uint32_t code = (codes >> (8 * k)) & 0xFFu;
-      int x = gx + k, rx = c4 + k;
+      int rx = c4 + k;
       uint32_t mw;
       if (!dt_d8_valid(code)) {
         mw = MW_BADCODE | 256u;
@@ -766,12 +773,14 @@ __global__ __launch_bounds__(1024) void k_downslope_win(const float *__restrict_
         dt_d8_delta(code, dy, dx);
         mw = (uint32_t)(dy * DW_WIN + dx + 256);
         if (dy != 0 && dx != 0) mw |= MW_DIAG;
-        if (gy + dy < 0 || gy + dy >= H || x + dx < 0 || x + dx >= W) mw |= MW_EDGE;
+        if (!dt_in_global(w, gy + dy, gx + k + dx)) mw |= MW_EDGE;
       }
-      if (r == 0 || r == DW_WIN - 1 || rx == 0 || rx == DW_WIN - 1) mw |= MW_RING;
-      w[k] = mw;
+      // ring of the window, or the edge of what is in memory: hand over to the global walk
+      if (r == 0 || r == DW_WIN - 1 || rx == 0 || rx == DW_WIN - 1 || !rd[k]) mw |= MW_RING;
+      mwv[k] = mw;
     }
-    *reinterpret_cast<uint2 *>(&s_w[r * DW_WIN + c4]) = make_uint2(w[0] | (w[1] << 16), w[2] | (w[3] << 16));
+    *reinterpret_cast<uint2 *>(&s_w[r * DW_WIN + c4]) =
+        make_uint2(mwv[0] | (mwv[1] << 16), mwv[2] | (mwv[3] << 16));
   }
   __syncthreads();
   const double dcard = px, ddiag = px * sqrt(2.0);
@@ -779,10 +788,10 @@ __global__ __launch_bounds__(1024) void k_downslope_win(const float *__restrict_
     int c = threadIdx.x + 1024 * j;
     int cy = c / DW_CORE, cx = c - cy * DW_CORE;
     int y0 = tyi * DW_CORE + cy, x0 = txi * DW_CORE + cx;
-    if (y0 >= H || x0 >= W) continue;
+    if (y0 >= w.H || x0 >= w.W) continue;
     int pos = (cy + DW_M) * DW_WIN + cx + DW_M;
     float z0 = s_z[pos];
-    size_t o = (size_t)y0 * W + x0;
+    long long o = (long long)y0 * w.ld + x0;
     if (z0 <= DT_NODATA) {
       out[o] = DT_NODATA;
       continue;
@@ -790,7 +799,7 @@ __global__ __launch_bounds__(1024) void k_downslope_win(const float *__restrict_
     double dist = 0.0;
     float drop = 0.0f;
     int loop = 0;
-    bool failed = false, slow = false;
+    bool failed = false, slow = false, unresolved = false;
     // Fast walk inside the window: one loop, one exit test, everything else predicated (the lanes
     // of a wave iterate until the longest walk ends anyway).  (double)drop < dz  <=>  drop < dzf
     // (dzf = smallest float >= dz).  The next cell's height and move word are fetched together.
@@ -822,13 +831,15 @@ __global__ __launch_bounds__(1024) void k_downslope_win(const float *__restrict_
     if (slow) {  // on the window ring: finish on global memory
       int y = wy0 + pos / DW_WIN, x = wx0 + pos % DW_WIN;
       while ((double)drop < dz) {
-        uint32_t code = fdr[(size_t)y * W + x];
+        if (!dt_readable(w, y, x)) { unresolved = true; break; }  // beyond this rank's halo
+        uint32_t code = fdr[(long long)y * w.ld + x];
         if (!dt_d8_valid(code)) { failed = true; break; }
         int dy, dx;
         dt_d8_delta(code, dy, dx);
         int ny = y + dy, nx = x + dx;
-        if (ny < 0 || ny >= H || nx < 0 || nx >= W) { failed = true; break; }
-        float zt = dem[(size_t)ny * W + nx];
+        if (!dt_in_global(w, ny, nx)) { failed = true; break; }
+        if (!dt_readable(w, ny, nx)) { unresolved = true; break; }
+        float zt = dem[(long long)ny * w.ld + nx];
         if (zt == DT_NODATA) { failed = true; break; }
         y = ny;
         x = nx;
@@ -837,13 +848,17 @@ __global__ __launch_bounds__(1024) void k_downslope_win(const float *__restrict_
         if (++loop == 5000) { failed = true; break; }
       }
     }
-    if (raw && failed) out[o] = -50.0f;
+    if (unresolved) {  // the walk left the memory of this rank: a wider halo is needed
+      out[o] = -50.0f;
+      if (n_unresolved) atomicAdd(n_unresolved, 1);
+    } else if (raw && failed) out[o] = -50.0f;
     else out[o] = dist == 0.0 ? 0.0f : (float)((double)drop / dist);
   }
 }
 
-int dt_launch_downslope(hipStream_t s, const float *dem, const uint8_t *fdr, int64_t H, int64_t W,
-                        double px, double dz, int raw, float *out) {
+int dt_launch_downslope(hipStream_t s, const DtWin &w, const float *dem, const uint8_t *fdr, double px,
+                        double dz, int raw, float *out, int *n_unresolved) {
+  const int64_t H = w.H, W = w.W;
   int64_t n = H * W;
   if (n == 0) return DT_OK;
   int tiles_x = (int)((W + DW_CORE - 1) / DW_CORE), tiles_y = (int)((H + DW_CORE - 1) / DW_CORE);
@@ -851,8 +866,8 @@ int dt_launch_downslope(hipStream_t s, const float *dem, const uint8_t *fdr, int
   // (double)drop < dz  <=>  drop < dzf with dzf the smallest float >= dz
   float dzf = (float)dz;
   if ((double)dzf < dz) dzf = nextafterf(dzf, INFINITY);
-  hipLaunchKernelGGL(k_downslope_win, dim3((unsigned)ntiles), dim3(1024), 0, s, dem, fdr, (int)H, (int)W, px,
-                     dz, dzf, raw, out, tiles_x, (int)ntiles);
+  hipLaunchKernelGGL(k_downslope_win, dim3((unsigned)ntiles), dim3(1024), 0, s, dem, fdr, w, px, dz, dzf, raw,
+                     out, tiles_x, (int)ntiles, n_unresolved);
   return DT_OK;
 }
 int dt_launch_downslope_v1(hipStream_t s, const float *dem, const uint8_t *fdr, int64_t H, int64_t W,

@@ -13,10 +13,16 @@
 //                            rasters, coalesced
 //
 // HBM traffic is ~2 reads of the 1-byte direction raster plus the outputs; everything else is LDS.
-// The same perimeter records are what a multi-GPU run exchanges.
 //
-// Integer accumulation is order-independent, and path counts are integers, so results are
-// bit-identical to the v1 kernels and to the oracle.
+// The same machinery is the multi-GPU exchange format: every kernel works on a DtWin -- a core
+// window inside a larger (global) raster -- and a path that leaves the core into another rank's
+// window ends on a "rank exit".  Pass 2 then has a stage between ranks (descriptools_amd/tiling.py):
+// each rank publishes one summary row per cell of its core ring, the small rank-level graph is
+// resolved redundantly by everybody, and the result is injected back (flow accumulation: external
+// inflow per ring cell; HAND: the resolved river cell of every rank exit).
+//
+// Integer accumulation is order-independent and path counts are integers, so results are
+// bit-identical to the v1 kernels and to the oracle for any tiling.
 #include "dt_common.h"
 #include "dt_kernels.h"
 
@@ -26,8 +32,9 @@
 #define PS (2 * TW + 2 * (TH - 2)) /* perimeter slots per tile: 252 */
 #define CPT (NT / 256)             /* cells per thread: 16 */
 
-#define NX_SINK 0xFFFFu /* no in-raster / valid D8 target */
-#define NX_EXIT 0xFFFEu /* target is in the raster but in another tile */
+#define NX_SINK 0xFFFFu  /* no D8 successor inside the global raster */
+#define NX_EXIT 0xFFFEu  /* successor is in the core but in another tile */
+#define NX_REXIT 0xFFFDu /* successor is outside the core, inside the global raster (another rank) */
 #define X_NONE 0xFFFFu
 
 // perimeter slot <-> local cell
@@ -44,43 +51,45 @@ __device__ __forceinline__ void dt_cell_of_slot(int s, int &ly, int &lx) {
   else if (s < 2 * TW + (TH - 2)) { ly = s - 2 * TW + 1; lx = 0; }
   else { ly = s - 2 * TW - (TH - 2) + 1; lx = TW - 1; }
 }
+// node id of the perimeter cell at core coordinates (y, x)
+__device__ __forceinline__ uint32_t dt_node_of(int y, int x, int tiles_x) {
+  int ty = y / TH, tx = x / TW;
+  return (uint32_t)((ty * tiles_x + tx) * PS + dt_slot_of(y - ty * TH, x - tx * TW));
+}
 
 // ---- tile staging -----------------------------------------------------------------------------
-// loads the tile's direction codes into LDS (0 outside the raster) and derives the local successor
-// of every cell: local index, NX_EXIT or NX_SINK.
-__device__ __forceinline__ void dt_tile_load_fdr(const uint8_t *__restrict__ fdr, int H, int W, int y0,
+// direction codes of the tile's core cells into LDS (0 outside the core)
+__device__ __forceinline__ void dt_tile_load_fdr(const uint8_t *__restrict__ fdr, const DtWin &w, int y0,
                                                  int x0, uint8_t *s_fdr) {
-  // 256 threads x 16 bytes = one 64-byte row per 4 threads
-  int t = threadIdx.x;
+  int t = threadIdx.x;  // 256 threads x 16 bytes: one 64-byte row per 4 threads
   int r = t >> 2, c = (t & 3) * 16;
   int gy = y0 + r, gx = x0 + c;
   uint4 v = make_uint4(0, 0, 0, 0);
-  if (gy < H) {
-    const uint8_t *p = fdr + (size_t)gy * W + gx;
-    if (gx + 15 < W && (((uintptr_t)p) & 15) == 0) {
+  if (gy < w.H) {
+    const uint8_t *p = fdr + (long long)gy * w.ld + gx;
+    if (gx + 15 < w.W && (((uintptr_t)p) & 15) == 0) {
       v = *reinterpret_cast<const uint4 *>(p);
     } else {
-      uint8_t b[16];
+      uint32_t w4[4] = {0, 0, 0, 0};
 #pragma unroll
-      for (int k = 0; k < 16; k++) b[k] = (gx + k < W) ? p[k] : 0;
-      v.x = b[0] | (b[1] << 8) | (b[2] << 16) | ((uint32_t)b[3] << 24);
-      v.y = b[4] | (b[5] << 8) | (b[6] << 16) | ((uint32_t)b[7] << 24);
-      v.z = b[8] | (b[9] << 8) | (b[10] << 16) | ((uint32_t)b[11] << 24);
-      v.w = b[12] | (b[13] << 8) | (b[14] << 16) | ((uint32_t)b[15] << 24);
+      for (int k = 0; k < 16; k++)
+        if (gx + k < w.W) w4[k >> 2] |= (uint32_t)p[k] << (8 * (k & 3));
+      v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
     }
   }
   *reinterpret_cast<uint4 *>(&s_fdr[r * TW + c]) = v;
 }
 
-__device__ __forceinline__ uint32_t dt_tile_next(uint32_t code, int ly, int lx, int y0, int x0, int H,
-                                                int W) {
-  int gy = y0 + ly, gx = x0 + lx;
-  if (gy >= H || gx >= W || !dt_d8_valid(code)) return NX_SINK;
+// local successor of tile cell (ly, lx): local index, NX_EXIT, NX_REXIT or NX_SINK
+__device__ __forceinline__ uint32_t dt_tile_next(uint32_t code, int ly, int lx, int y0, int x0,
+                                                const DtWin &w) {
+  int y = y0 + ly, x = x0 + lx;
+  if (y >= w.H || x >= w.W || !dt_d8_valid(code)) return NX_SINK;
   int dy, dx;
   dt_d8_delta(code, dy, dx);
+  int ty = y + dy, tx = x + dx;
+  if (!dt_in_core(w, ty, tx)) return dt_in_global(w, ty, tx) ? NX_REXIT : NX_SINK;
   int ny = ly + dy, nx = lx + dx;
-  int ty = gy + dy, tx = gx + dx;
-  if (ty < 0 || ty >= H || tx < 0 || tx >= W) return NX_SINK;
   if (ny < 0 || ny >= TH || nx < 0 || nx >= TW) return NX_EXIT;
   return (uint32_t)(ny * TW + nx);
 }
@@ -142,17 +151,23 @@ __device__ __forceinline__ void dt_tile_sums(uint16_t *s_ptr, uint32_t *s_val, u
 }
 
 // perimeter record (8 bytes):  W:32 | xslot:16 | code:8 | flags:8
-//   code  = the cell's D8 code when its successor is in ANOTHER tile (an "exit" cell), else 0
+//   code  = the cell's D8 code when its successor is in another tile or rank (an "exit" cell)
+//   flags = bit 0: rank exit (the successor is outside the core window)
 //   W     = cells draining through the exit cell inside the tile, itself included
 //   xslot = perimeter slot of the exit cell reached by a path entering the tile at this cell
 //           (X_NONE when that path ends inside the tile)
-__device__ __forceinline__ unsigned long long fa_rec(uint32_t W_, uint32_t xslot, uint32_t code) {
+#define REC_RANK_EXIT 1ull
+__device__ __forceinline__ unsigned long long fa_rec(uint32_t W_, uint32_t xslot, uint32_t code,
+                                                    uint32_t flags) {
   return ((unsigned long long)W_ << 32) | ((unsigned long long)(xslot & 0xFFFFu) << 16) |
-         ((unsigned long long)(code & 0xFFu) << 8);
+         ((unsigned long long)(code & 0xFFu) << 8) | (unsigned long long)(flags & 0xFFu);
 }
+#define REC_W(r) ((uint32_t)((r) >> 32))
+#define REC_XSLOT(r) ((uint32_t)(((r) >> 16) & 0xFFFFu))
+#define REC_CODE(r) ((uint32_t)(((r) >> 8) & 0xFFu))
 
-__global__ __launch_bounds__(256) void k_fa_tile1(const uint8_t *__restrict__ fdr, int H, int W,
-                                                 int tiles_x, unsigned long long *__restrict__ rec,
+__global__ __launch_bounds__(256) void k_fa_tile1(const uint8_t *__restrict__ fdr, DtWin w, int tiles_x,
+                                                 unsigned long long *__restrict__ rec,
                                                  int32_t *__restrict__ acc32) {
   __shared__ __attribute__((aligned(16))) uint8_t s_fdr[NT];  // reused as the in-tile cycle mask
   __shared__ uint16_t s_ptr[NT];                               // idx:12 | PT_EXIT | PT_ALIVE
@@ -161,19 +176,21 @@ __global__ __launch_bounds__(256) void k_fa_tile1(const uint8_t *__restrict__ fd
   const int tile = blockIdx.x;
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int y0 = ty * TH, x0 = tx * TW;
-  dt_tile_load_fdr(fdr, H, W, y0, x0, s_fdr);
+  dt_tile_load_fdr(fdr, w, y0, x0, s_fdr);
   __syncthreads();
   uint32_t nx[CPT];
   for (int j = 0; j < CPT; j++) {
     int c = threadIdx.x + 256 * j;
-    nx[j] = dt_tile_next(s_fdr[c], c / TW, c % TW, y0, x0, H, W);
+    nx[j] = dt_tile_next(s_fdr[c], c / TW, c % TW, y0, x0, w);
   }
-  uint32_t my_code = 0;  // D8 code of my perimeter cell when it is an exit cell
+  uint32_t my_code = 0, my_flags = 0;  // D8 code of my perimeter cell when it is an exit cell
   if (threadIdx.x < PS) {
     int ly, lx;
     dt_cell_of_slot(threadIdx.x, ly, lx);
     uint32_t code = s_fdr[ly * TW + lx];
-    if (dt_tile_next(code, ly, lx, y0, x0, H, W) == NX_EXIT) my_code = code;
+    uint32_t n = dt_tile_next(code, ly, lx, y0, x0, w);
+    if (n == NX_EXIT || n == NX_REXIT) my_code = code;
+    if (n == NX_REXIT) my_flags = (uint32_t)REC_RANK_EXIT;
   }
   __syncthreads();
   uint8_t *s_cyc = s_fdr;
@@ -182,7 +199,8 @@ __global__ __launch_bounds__(256) void k_fa_tile1(const uint8_t *__restrict__ fd
     uint32_t n = nx[j];
     // terminals point at themselves; an exit terminal carries PT_EXIT, which every cell whose
     // in-tile path ends there inherits through the jumps
-    s_ptr[c] = (uint16_t)(n < NT ? (n | PT_ALIVE) : ((uint32_t)c | (n == NX_EXIT ? PT_EXIT : 0u)));
+    bool ex = (n == NX_EXIT || n == NX_REXIT);
+    s_ptr[c] = (uint16_t)(n < NT ? (n | PT_ALIVE) : ((uint32_t)c | (ex ? PT_EXIT : 0u)));
     s_val[c] = 1u;
     s_recv[c] = 0u;
     s_cyc[c] = 0;
@@ -199,46 +217,45 @@ __global__ __launch_bounds__(256) void k_fa_tile1(const uint8_t *__restrict__ fd
       uint32_t f = p & PT_IDX;
       xs = (uint32_t)dt_slot_of((int)f / TW, (int)f % TW);
     }
-    rec[(size_t)tile * PS + threadIdx.x] = fa_rec(my_code ? s_val[c] : 0u, xs, my_code);
+    rec[(size_t)tile * PS + threadIdx.x] = fa_rec(my_code ? s_val[c] : 0u, xs, my_code, my_flags);
   }
   // in-tile accumulation (upstream cells of this tile only); pass 3 adds what enters from outside
   for (int j = 0; j < CPT; j++) {
     int c = threadIdx.x + 256 * j;
-    int gy = y0 + c / TW, gx = x0 + c % TW;
-    if (gy < H && gx < W) acc32[(size_t)gy * W + gx] = s_cyc[c] ? -100 : (int32_t)(s_val[c] - 1u);
+    int y = y0 + c / TW, x = x0 + c % TW;
+    if (y < w.H && x < w.W) acc32[(long long)y * w.ld + x] = s_cyc[c] ? -100 : (int32_t)(s_val[c] - 1u);
   }
 }
 
-// perimeter graph: node id = tile * PS + slot.  For every exit node find the entry node it feeds
-// (the neighbouring tile's perimeter cell its D8 step lands on) and the exit node that entry's
-// in-tile path leads to (its parent in the reduced forest).
+// perimeter graph: node id = tile * PS + slot.  For every in-core exit node find the entry node it
+// feeds (the neighbouring tile's perimeter cell its D8 step lands on) and the exit node that entry's
+// in-tile path leads to (its parent in the reduced forest).  Rank exits have neither.
 #define FA_NONE 0xFFFFFFFFu
 #define FA2_SH 56
 #define FA2_MASK ((1ull << FA2_SH) - 1ull)
 #define FA_CYCLE (1ull << 63) /* ext flag: this entry cell is fed by a cross-tile D8 cycle */
+#define FA_VALUE(e) ((e) & ~FA_CYCLE)
 
 __global__ __launch_bounds__(256) void k_fa_link(const unsigned long long *__restrict__ rec, int64_t nnodes,
-                                                int tiles_x, int H, int W, uint32_t *__restrict__ entry_of,
+                                                int tiles_x, uint32_t *__restrict__ entry_of,
                                                 uint32_t *__restrict__ parent,
                                                 unsigned long long *__restrict__ state) {
   int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (n >= nnodes) return;
   unsigned long long r = rec[n];
-  uint32_t code = (uint32_t)((r >> 8) & 0xFFu);
+  uint32_t code = REC_CODE(r);
   uint32_t ent = FA_NONE, par = FA_NONE;
-  if (code) {
+  if (code && !(r & REC_RANK_EXIT)) {
     int tile = (int)(n / PS), slot = (int)(n - (int64_t)tile * PS);
     int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     int ly, lx, dy, dx;
     dt_cell_of_slot(slot, ly, lx);
     dt_d8_delta(code, dy, dx);
-    int gy = ty * TH + ly + dy, gx = tx * TW + lx + dx;  // inside the raster by construction
-    int t2y = gy / TH, t2x = gx / TW;
-    int s2 = dt_slot_of(gy - t2y * TH, gx - t2x * TW);
-    ent = (uint32_t)((t2y * tiles_x + t2x) * PS + s2);
-    uint32_t xs = (uint32_t)((rec[ent] >> 16) & 0xFFFFu);
+    int y = ty * TH + ly + dy, x = tx * TW + lx + dx;  // inside the core by construction
+    ent = dt_node_of(y, x, tiles_x);
+    uint32_t xs = REC_XSLOT(rec[ent]);
     if (xs != X_NONE) {
-      par = (uint32_t)((t2y * tiles_x + t2x) * PS) + xs;
+      par = (ent / PS) * PS + xs;
       atomicAdd(&state[par], 1ull << FA2_SH);
     }
   }
@@ -246,28 +263,32 @@ __global__ __launch_bounds__(256) void k_fa_link(const unsigned long long *__res
   parent[n] = par;
 }
 
-// countdown over the reduced forest; A(q) = W(q) + sum of A over the exit nodes feeding q's tile
-// entry cells whose in-tile path leads to q.  ext[entry] accumulates the inflow arriving at an
-// entry cell from other tiles.
+// countdown over the reduced forest; A(q) = W(q) + winj(q) + sum of A over the exit nodes feeding
+// q's tile through entry cells whose in-tile path leads to q.  ext[entry] accumulates the inflow
+// arriving at an entry cell from other tiles.  winj (may be NULL) = inflow injected from other
+// ranks that reaches q inside its tile.
 __global__ __launch_bounds__(256) void k_fa_reduce(const unsigned long long *__restrict__ rec, int64_t nnodes,
                                                   const uint32_t *__restrict__ entry_of,
                                                   const uint32_t *__restrict__ parent,
+                                                  const unsigned long long *__restrict__ winj,
                                                   unsigned long long *__restrict__ state,
                                                   unsigned long long *__restrict__ ext) {
   int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (n >= nnodes) return;
   unsigned long long r = rec[n];
-  if (((r >> 8) & 0xFFu) == 0) return;  // not an exit node
-  if (state[n] != 0ull) return;         // not a source of the reduced forest
+  if (REC_CODE(r) == 0) return;  // not an exit node
+  if (state[n] != 0ull) return;  // not a source of the reduced forest (a source's word stays 0)
   uint32_t q = (uint32_t)n;
-  unsigned long long A = r >> 32;
+  unsigned long long A = REC_W(r) + (winj ? winj[q] : 0ull);
   for (int64_t it = 0; it < nnodes; it++) {
-    atomicAdd(&ext[entry_of[q]], A);
+    uint32_t e = entry_of[q];
+    if (e == FA_NONE) break;  // rank exit: its total stays in (rec, winj, state)
+    atomicAdd(&ext[e], A);
     uint32_t p = parent[q];
     if (p == FA_NONE) break;
     unsigned long long old = atomicAdd(&state[p], A - (1ull << FA2_SH));
     if ((old >> FA2_SH) != 1ull) break;
-    A = (rec[p] >> 32) + (old & FA2_MASK) + A;
+    A = REC_W(rec[p]) + (winj ? winj[p] : 0ull) + (old & FA2_MASK) + A;
     q = p;
   }
 }
@@ -280,7 +301,7 @@ __global__ __launch_bounds__(256) void k_fa_poison(const unsigned long long *__r
                                                   unsigned long long *__restrict__ ext) {
   int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (n >= nnodes) return;
-  if (((rec[n] >> 8) & 0xFFu) == 0) return;
+  if (REC_CODE(rec[n]) == 0 || entry_of[n] == FA_NONE) return;
   if ((state[n] >> FA2_SH) != 0ull) atomicOr(&ext[entry_of[n]], FA_CYCLE);
 }
 
@@ -289,7 +310,7 @@ __global__ __launch_bounds__(256) void k_fa_poison(const unsigned long long *__r
 // an LDS delta raster (integer adds: order-free), then delta is added to pass 1's in-tile counts.
 template <bool HAS_DEM, bool W_RIVER>
 __global__ __launch_bounds__(256) void k_fa_tile3(const uint8_t *__restrict__ fdr,
-                                                 const float *__restrict__ dem, int H, int W, int tiles_x,
+                                                 const float *__restrict__ dem, DtWin w, int tiles_x,
                                                  const unsigned long long *__restrict__ ext,
                                                  int32_t *__restrict__ acc32, int32_t river_thr,
                                                  int8_t *__restrict__ river) {
@@ -299,14 +320,14 @@ __global__ __launch_bounds__(256) void k_fa_tile3(const uint8_t *__restrict__ fd
   const int tile = blockIdx.x;
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int y0 = ty * TH, x0 = tx * TW;
-  dt_tile_load_fdr(fdr, H, W, y0, x0, s_fdr);
+  dt_tile_load_fdr(fdr, w, y0, x0, s_fdr);
   unsigned long long e = 0ull;
   if (threadIdx.x < PS) e = ext[(size_t)tile * PS + threadIdx.x];
   __syncthreads();
   uint32_t nx[CPT];
   for (int j = 0; j < CPT; j++) {
     int c = threadIdx.x + 256 * j;
-    nx[j] = dt_tile_next(s_fdr[c], c / TW, c % TW, y0, x0, H, W);
+    nx[j] = dt_tile_next(s_fdr[c], c / TW, c % TW, y0, x0, w);
   }
   __syncthreads();
   uint8_t *s_cyc = s_fdr;
@@ -332,9 +353,9 @@ __global__ __launch_bounds__(256) void k_fa_tile3(const uint8_t *__restrict__ fd
   __syncthreads();
   for (int j = 0; j < CPT; j++) {
     int c = threadIdx.x + 256 * j;
-    int gy = y0 + c / TW, gx = x0 + c % TW;
-    if (gy >= H || gx >= W) continue;
-    size_t o = (size_t)gy * W + gx;
+    int y = y0 + c / TW, x = x0 + c % TW;
+    if (y >= w.H || x >= w.W) continue;
+    long long o = (long long)y * w.ld + x;
     int32_t v = acc32[o];
     if (v != -100) v += (int32_t)s_delta[c];
     if (s_cyc[c]) v = -100;
@@ -344,41 +365,174 @@ __global__ __launch_bounds__(256) void k_fa_tile3(const uint8_t *__restrict__ fd
   }
 }
 
-int dt_launch_flowacc_tiled(hipStream_t s, const uint8_t *fdr, const float *dem, int64_t H, int64_t W,
-                            void *scratch, size_t scratch_bytes, int32_t *acc32, int64_t river_thr,
-                            int8_t *river) {
-  if (H == 0 || W == 0) return DT_OK;
-  int tiles_x = (int)((W + TW - 1) / TW), tiles_y = (int)((H + TH - 1) / TH);
-  int64_t ntiles = (int64_t)tiles_x * tiles_y;
-  int64_t nnodes = ntiles * PS;
-  DT_REQUIRE(nnodes < 0xFFFFFFF0ll, "raster too large for one device tile");
-  DT_REQUIRE(scratch_bytes >= dt_flowacc_tiled_scratch(H, W), "scratch too small");
-  char *p = (char *)scratch;
-  unsigned long long *rec = (unsigned long long *)p;  p += dt_align256((size_t)nnodes * 8);
-  unsigned long long *state = (unsigned long long *)p;  p += dt_align256((size_t)nnodes * 8);
-  unsigned long long *ext = (unsigned long long *)p;  p += dt_align256((size_t)nnodes * 8);
-  uint32_t *entry_of = (uint32_t *)p;  p += dt_align256((size_t)nnodes * 4);
-  uint32_t *parent = (uint32_t *)p;
-  // state and ext are contiguous: one memset
-  DT_HIP(hipMemsetAsync(state, 0, dt_align256((size_t)nnodes * 8) * 2, s));
-  hipLaunchKernelGGL(k_fa_tile1, dim3((unsigned)ntiles), dim3(256), 0, s, fdr, (int)H, (int)W, tiles_x, rec, acc32);
-  dim3 gn((unsigned)((nnodes + 255) / 256)), b(256);
-  hipLaunchKernelGGL(k_fa_link, gn, b, 0, s, rec, nnodes, tiles_x, (int)H, (int)W, entry_of, parent, state);
-  hipLaunchKernelGGL(k_fa_reduce, gn, b, 0, s, rec, nnodes, entry_of, parent, state, ext);
-  hipLaunchKernelGGL(k_fa_poison, gn, b, 0, s, rec, nnodes, entry_of, state, ext);
-  int32_t thr = river_thr > 2147483647ll ? 2147483647 : (river_thr < -2147483647ll ? -2147483647 : (int32_t)river_thr);
-  dim3 gt((unsigned)ntiles);
-  if (dem && river) hipLaunchKernelGGL((k_fa_tile3<true, true>), gt, b, 0, s, fdr, dem, (int)H, (int)W, tiles_x, ext, acc32, thr, river);
-  else if (dem) hipLaunchKernelGGL((k_fa_tile3<true, false>), gt, b, 0, s, fdr, dem, (int)H, (int)W, tiles_x, ext, acc32, thr, river);
-  else if (river) hipLaunchKernelGGL((k_fa_tile3<false, true>), gt, b, 0, s, fdr, dem, (int)H, (int)W, tiles_x, ext, acc32, thr, river);
-  else hipLaunchKernelGGL((k_fa_tile3<false, false>), gt, b, 0, s, fdr, dem, (int)H, (int)W, tiles_x, ext, acc32, thr, river);
-  return DT_OK;
+// ---- rank level (multi-GPU) ------------------------------------------------------------------------
+// jump[n]: the exit node the path entering the core at perimeter node n leaves its tile through,
+// followed across tiles until it reaches a rank exit (bit 31 set: terminal) or ends (FA_NONE).
+#define J_TERM 0x80000000u
+__global__ __launch_bounds__(256) void k_fa_jump_init(const unsigned long long *__restrict__ rec,
+                                                     int64_t nnodes, const uint32_t *__restrict__ entry_of,
+                                                     uint32_t *__restrict__ jump) {
+  int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= nnodes) return;
+  uint32_t xs = REC_XSLOT(rec[n]);
+  uint32_t j = FA_NONE;
+  if (xs != X_NONE) {
+    uint32_t q = (uint32_t)(n / PS) * PS + xs;
+    j = (rec[q] & REC_RANK_EXIT) ? (q | J_TERM) : entry_of[q];
+  }
+  jump[n] = j;
+}
+__global__ __launch_bounds__(256) void k_fa_jump(uint32_t *__restrict__ jump, int64_t nnodes) {
+  int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= nnodes) return;
+  uint32_t j = __hip_atomic_load(&jump[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (j == FA_NONE || (j & J_TERM)) return;
+  uint32_t t = __hip_atomic_load(&jump[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(&jump[n], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// one row per cell of the core ring: A = cells of this rank draining out through the cell (0 unless
+// it is a rank exit), code = its D8 code if rank exit, xr = ring index of the rank exit reached by a
+// path ENTERING the rank at this cell (-1: ends inside; -2: unresolved, i.e. a cycle inside the rank)
+__global__ __launch_bounds__(256) void k_fa_rank_summary(DtWin w, int tiles_x,
+                                                        const unsigned long long *__restrict__ rec,
+                                                        const unsigned long long *__restrict__ state,
+                                                        const uint32_t *__restrict__ jump, int64_t P,
+                                                        int64_t *__restrict__ A, int32_t *__restrict__ xr,
+                                                        uint8_t *__restrict__ code) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= P) return;
+  int y, x;
+  dt_perim_cell(w.H, w.W, i, y, x);
+  uint32_t n = dt_node_of(y, x, tiles_x);
+  unsigned long long r = rec[n];
+  bool rex = (r & REC_RANK_EXIT) != 0ull;
+  A[i] = rex ? (int64_t)(REC_W(r) + (state[n] & FA2_MASK)) : 0;
+  code[i] = rex ? (uint8_t)REC_CODE(r) : 0;
+  uint32_t j = jump[n];
+  int32_t out = -1;
+  if (j != FA_NONE) {
+    if (j & J_TERM) {
+      uint32_t q = j & ~J_TERM;
+      int tile = (int)(q / PS), slot = (int)(q - (uint32_t)tile * PS);
+      int ly, lx;
+      dt_cell_of_slot(slot, ly, lx);
+      out = (int32_t)dt_perim_index(w.H, w.W, (tile / tiles_x) * TH + ly, (tile % tiles_x) * TW + lx);
+    } else {
+      out = -2;
+    }
+  }
+  xr[i] = out;
+}
+
+// inject the inflow other ranks deliver at ring cell i: it enters tile entry node n (ext) and reaches
+// that tile's exit X(n) (winj) -- from there the normal countdown carries it on.
+__global__ __launch_bounds__(256) void k_fa_inject(DtWin w, int tiles_x,
+                                                  const unsigned long long *__restrict__ rec,
+                                                  const unsigned long long *__restrict__ ext_perim, int64_t P,
+                                                  unsigned long long *__restrict__ ext,
+                                                  unsigned long long *__restrict__ winj) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= P) return;
+  unsigned long long v = ext_perim[i];
+  if (v == 0ull) return;
+  int y, x;
+  dt_perim_cell(w.H, w.W, i, y, x);
+  uint32_t n = dt_node_of(y, x, tiles_x);
+  if (v & FA_CYCLE) atomicOr(&ext[n], FA_CYCLE);
+  unsigned long long val = FA_VALUE(v);
+  if (val) {
+    atomicAdd(&ext[n], val);
+    uint32_t xs = REC_XSLOT(rec[n]);
+    if (xs != X_NONE) atomicAdd(&winj[(n / PS) * PS + xs], val);
+  }
+}
+
+struct FaScratch {
+  unsigned long long *rec, *state, *ext, *winj;
+  uint32_t *entry_of, *parent, *jump;
+  int64_t nnodes, ntiles;
+  int tiles_x;
+};
+static FaScratch fa_layout(const DtWin &w, void *scratch) {
+  FaScratch f;
+  f.tiles_x = (w.W + TW - 1) / TW;
+  f.ntiles = (int64_t)f.tiles_x * ((w.H + TH - 1) / TH);
+  f.nnodes = f.ntiles * PS;
+  char *p = (char *)scratch;
+  size_t n8 = dt_align256((size_t)f.nnodes * 8), n4 = dt_align256((size_t)f.nnodes * 4);
+  f.rec = (unsigned long long *)p;  p += n8;
+  f.state = (unsigned long long *)p;  p += n8;  // state, ext, winj contiguous: one memset
+  f.ext = (unsigned long long *)p;  p += n8;
+  f.winj = (unsigned long long *)p;  p += n8;
+  f.entry_of = (uint32_t *)p;  p += n4;
+  f.parent = (uint32_t *)p;  p += n4;
+  f.jump = (uint32_t *)p;
+  return f;
+}
 size_t dt_flowacc_tiled_scratch(int64_t H, int64_t W) {
   int64_t ntiles = ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
   size_t nn = (size_t)ntiles * PS;
-  return dt_align256(nn * 8) * 3 + dt_align256(nn * 4) * 2 + 256;
+  return dt_align256(nn * 8) * 4 + dt_align256(nn * 4) * 3 + 256;
+}
+
+// phase 1: tile pass + local perimeter graph.  With `rank_level` the rank-exit jumps are resolved too
+// (needed for dt_launch_fa_summary).
+int dt_launch_fa_local(hipStream_t s, const DtWin &w, const uint8_t *fdr, void *scratch, size_t scratch_bytes,
+                       int32_t *acc32, int rank_level) {
+  if (w.H == 0 || w.W == 0) return DT_OK;
+  DT_REQUIRE(scratch_bytes >= dt_flowacc_tiled_scratch(w.H, w.W), "scratch too small");
+  FaScratch f = fa_layout(w, scratch);
+  DT_REQUIRE(f.nnodes < 0x7FFFFFF0ll, "raster too large for one device tile");
+  DT_HIP(hipMemsetAsync(f.state, 0, dt_align256((size_t)f.nnodes * 8) * 3, s));
+  dim3 gt((unsigned)f.ntiles), b(256), gn((unsigned)((f.nnodes + 255) / 256));
+  hipLaunchKernelGGL(k_fa_tile1, gt, b, 0, s, fdr, w, f.tiles_x, f.rec, acc32);
+  hipLaunchKernelGGL(k_fa_link, gn, b, 0, s, f.rec, f.nnodes, f.tiles_x, f.entry_of, f.parent, f.state);
+  hipLaunchKernelGGL(k_fa_reduce, gn, b, 0, s, f.rec, f.nnodes, f.entry_of, f.parent,
+                     (const unsigned long long *)nullptr, f.state, f.ext);
+  if (rank_level) {
+    hipLaunchKernelGGL(k_fa_jump_init, gn, b, 0, s, f.rec, f.nnodes, f.entry_of, f.jump);
+    // a path crosses each tile perimeter node at most once; 2^24 tile crossings inside one rank
+    // would need a path longer than any raster this library accepts per device
+    for (int r = 0; r < 24; r++) hipLaunchKernelGGL(k_fa_jump, gn, b, 0, s, f.jump, f.nnodes);
+  }
+  return DT_OK;
+}
+
+int dt_launch_fa_summary(hipStream_t s, const DtWin &w, void *scratch, int64_t *A, int32_t *xr,
+                         uint8_t *code) {
+  int64_t P = dt_perim_count(w.H, w.W);
+  if (P == 0) return DT_OK;
+  FaScratch f = fa_layout(w, scratch);
+  hipLaunchKernelGGL(k_fa_rank_summary, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, w, f.tiles_x,
+                     f.rec, f.state, f.jump, P, A, xr, code);
+  return DT_OK;
+}
+
+// phase 2: optional injection of the inflow from other ranks (re-runs the perimeter countdown with
+// it), then the final tile pass.
+int dt_launch_fa_finish(hipStream_t s, const DtWin &w, const uint8_t *fdr, const float *dem, void *scratch,
+                        const unsigned long long *ext_perim, int64_t river_thr, int32_t *acc32,
+                        int8_t *river) {
+  if (w.H == 0 || w.W == 0) return DT_OK;
+  FaScratch f = fa_layout(w, scratch);
+  dim3 gt((unsigned)f.ntiles), b(256), gn((unsigned)((f.nnodes + 255) / 256));
+  if (ext_perim) {
+    int64_t P = dt_perim_count(w.H, w.W);
+    DT_HIP(hipMemsetAsync(f.state, 0, dt_align256((size_t)f.nnodes * 8) * 3, s));
+    hipLaunchKernelGGL(k_fa_link, gn, b, 0, s, f.rec, f.nnodes, f.tiles_x, f.entry_of, f.parent, f.state);
+    hipLaunchKernelGGL(k_fa_inject, dim3((unsigned)((P + 255) / 256)), b, 0, s, w, f.tiles_x, f.rec, ext_perim,
+                       P, f.ext, f.winj);
+    hipLaunchKernelGGL(k_fa_reduce, gn, b, 0, s, f.rec, f.nnodes, f.entry_of, f.parent,
+                       (const unsigned long long *)f.winj, f.state, f.ext);
+  }
+  hipLaunchKernelGGL(k_fa_poison, gn, b, 0, s, f.rec, f.nnodes, f.entry_of, f.state, f.ext);
+  int32_t thr = river_thr > 2147483647ll ? 2147483647 : (river_thr < -2147483647ll ? -2147483647 : (int32_t)river_thr);
+  if (dem && river) hipLaunchKernelGGL((k_fa_tile3<true, true>), gt, b, 0, s, fdr, dem, w, f.tiles_x, f.ext, acc32, thr, river);
+  else if (dem) hipLaunchKernelGGL((k_fa_tile3<true, false>), gt, b, 0, s, fdr, dem, w, f.tiles_x, f.ext, acc32, thr, river);
+  else if (river) hipLaunchKernelGGL((k_fa_tile3<false, true>), gt, b, 0, s, fdr, dem, w, f.tiles_x, f.ext, acc32, thr, river);
+  else hipLaunchKernelGGL((k_fa_tile3<false, false>), gt, b, 0, s, fdr, dem, w, f.tiles_x, f.ext, acc32, thr, river);
+  return DT_OK;
 }
 
 // ===========================================================================================
@@ -388,21 +542,24 @@ size_t dt_flowacc_tiled_scratch(int64_t H, int64_t W) {
 //   ptr:32 | n_diag:16 | done:1 n_card:15
 // "the path from here to `ptr` takes n_card cardinal and n_diag diagonal moves".
 //   in a tile : ptr = local cell (bits 0-11) | kind << 12, kind of a finished path's end:
-//               1 river cell, 2 dead (-100), 3 exit (the end cell steps into another tile)
-//   node      : ptr = perimeter node id while unresolved; when done, the GLOBAL flat index of
-//               the river cell, or FH_DEAD
+//               1 river cell, 2 dead (-100), 3 exit (steps into another tile), 4 rank exit
+//   node      : ptr = node id while unresolved; when done: the core-local flat index y*W+x of the
+//               river cell, or (bit 31) a key into the rank-exit payload table, or FHT_DEAD.
+//               Nodes [nnodes, nnodes + P) are GHOSTS, one per core-ring cell: a rank exit points at
+//               its ghost, which is a fixed point until the rank-level result is written into it.
 #define FHT_DEAD 0xFFFFFFFFu
+#define FHT_REMOTE 0x80000000u
 #define FHT_DONE 0x8000u
 #define FHT_CAP 20000u
 #define K_RIVER 1u
 #define K_DEAD 2u
 #define K_EXIT 3u
+#define K_REXIT 4u
 
 __device__ __forceinline__ unsigned long long fht_pack(uint32_t ptr, uint32_t nd, uint32_t ncf) {
   return ((unsigned long long)ptr << 32) | ((unsigned long long)nd << 16) | (unsigned long long)ncf;
 }
 
-// stage fdr (with a one-cell halo ring) and the river mask; build and resolve the in-tile words.
 struct FhTile {
   uint8_t *s_fdr;   // [NT]
   uint8_t *s_halo;  // [2 * (TW + 2) + 2 * TH]: top row, bottom row, left col, right col
@@ -417,35 +574,36 @@ __device__ __forceinline__ uint32_t fht_fdr_at(const FhTile &T, int ly, int lx) 
   return T.s_halo[2 * (TW + 2) + TH + ly];
 }
 
+// stage fdr (with a one-cell halo ring, read from the neighbouring rank's halo where the tile touches
+// the core border) and the river mask; build and resolve the in-tile words.
 __device__ __forceinline__ void fht_solve_tile(const FhTile &T, const uint8_t *__restrict__ fdr,
-                                               const int8_t *__restrict__ river, int H, int W, int y0,
+                                               const int8_t *__restrict__ river, const DtWin &w, int y0,
                                                int x0) {
-  dt_tile_load_fdr(fdr, H, W, y0, x0, T.s_fdr);
+  dt_tile_load_fdr(fdr, w, y0, x0, T.s_fdr);
   for (int i = threadIdx.x; i < 2 * (TW + 2) + 2 * TH; i += 256) {
-    int gy, gx;
-    if (i < TW + 2) { gy = y0 - 1; gx = x0 - 1 + i; }
-    else if (i < 2 * (TW + 2)) { gy = y0 + TH; gx = x0 - 1 + (i - (TW + 2)); }
-    else if (i < 2 * (TW + 2) + TH) { gy = y0 + (i - 2 * (TW + 2)); gx = x0 - 1; }
-    else { gy = y0 + (i - 2 * (TW + 2) - TH); gx = x0 + TW; }
+    int y, x;
+    if (i < TW + 2) { y = y0 - 1; x = x0 - 1 + i; }
+    else if (i < 2 * (TW + 2)) { y = y0 + TH; x = x0 - 1 + (i - (TW + 2)); }
+    else if (i < 2 * (TW + 2) + TH) { y = y0 + (i - 2 * (TW + 2)); x = x0 - 1; }
+    else { y = y0 + (i - 2 * (TW + 2) - TH); x = x0 + TW; }
     uint8_t v = 0;
-    if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = fdr[(size_t)gy * W + gx];
+    if (dt_readable(w, y, x)) v = fdr[(long long)y * w.ld + x];
     T.s_halo[i] = v;
   }
-  // river mask of my 16 cells (row-contiguous per wave)
-  uint32_t riv = 0;
+  uint32_t riv = 0;  // river mask of my 16 cells (row-contiguous per wave)
   for (int j = 0; j < CPT; j++) {
     int c = threadIdx.x + 256 * j;
-    int gy = y0 + c / TW, gx = x0 + c % TW;
-    if (gy < H && gx < W && river[(size_t)gy * W + gx] == 1) riv |= 1u << j;
+    int y = y0 + c / TW, x = x0 + c % TW;
+    if (y < w.H && x < w.W && river[(long long)y * w.ld + x] == 1) riv |= 1u << j;
   }
   __syncthreads();
   for (int j = 0; j < CPT; j++) {
     int c = threadIdx.x + 256 * j;
     int ly = c / TW, lx = c % TW;
-    int gy = y0 + ly, gx = x0 + lx;
+    int y = y0 + ly, x = x0 + lx;
     uint32_t code = T.s_fdr[c];
     unsigned long long s;
-    if (gy >= H || gx >= W || code == 0u) {
+    if (y >= w.H || x >= w.W || code == 0u) {
       s = fht_pack((uint32_t)c | (K_DEAD << 12), 0, FHT_DONE);  // flowhand.py:601
     } else if ((riv >> j) & 1u) {
       s = fht_pack((uint32_t)c | (K_RIVER << 12), 0, FHT_DONE);  // flowhand.py:609-612
@@ -454,9 +612,11 @@ __device__ __forceinline__ void fht_solve_tile(const FhTile &T, const uint8_t *_
     } else {
       int dy, dx;
       dt_d8_delta(code, dy, dx);
-      int ty = gy + dy, tx = gx + dx;
-      if (ty < 0 || ty >= H || tx < 0 || tx >= W || fht_fdr_at(T, ly + dy, lx + dx) == 0u) {
+      int ty = y + dy, tx = x + dx;
+      if (!dt_in_global(w, ty, tx) || fht_fdr_at(T, ly + dy, lx + dx) == 0u) {
         s = fht_pack((uint32_t)c | (K_DEAD << 12), 0, FHT_DONE);  // raster exit / arrival on fdr==0
+      } else if (!dt_in_core(w, ty, tx)) {
+        s = fht_pack((uint32_t)c | (K_REXIT << 12), 0, FHT_DONE);
       } else if (ly + dy < 0 || ly + dy >= TH || lx + dx < 0 || lx + dx >= TW) {
         s = fht_pack((uint32_t)c | (K_EXIT << 12), 0, FHT_DONE);  // the step itself is added by the user
       } else {
@@ -492,8 +652,8 @@ __device__ __forceinline__ void fht_solve_tile(const FhTile &T, const uint8_t *_
 
 // pass 1: perimeter node words
 __global__ __launch_bounds__(256) void k_fh_tile1(const uint8_t *__restrict__ fdr,
-                                                 const int8_t *__restrict__ river, int H, int W,
-                                                 int tiles_x, unsigned long long *__restrict__ nodes) {
+                                                 const int8_t *__restrict__ river, DtWin w, int tiles_x,
+                                                 uint32_t nnodes, unsigned long long *__restrict__ nodes) {
   __shared__ __attribute__((aligned(16))) uint8_t s_fdr[NT];
   __shared__ uint8_t s_halo[2 * (TW + 2) + 2 * TH];
   __shared__ unsigned long long s_st[NT];
@@ -501,111 +661,37 @@ __global__ __launch_bounds__(256) void k_fh_tile1(const uint8_t *__restrict__ fd
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int y0 = ty * TH, x0 = tx * TW;
   FhTile T{s_fdr, s_halo, s_st};
-  fht_solve_tile(T, fdr, river, H, W, y0, x0);
+  fht_solve_tile(T, fdr, river, w, y0, x0);
   if (threadIdx.x < PS) {
     int ly, lx;
     dt_cell_of_slot(threadIdx.x, ly, lx);
     unsigned long long s = s_st[ly * TW + lx];
     uint32_t ptr = (uint32_t)(s >> 32), nd = (uint32_t)((s >> 16) & 0xFFFFu);
     uint32_t ncf = (uint32_t)(s & 0xFFFFu), nc = ncf & 0x7FFFu;
-    uint32_t kind = (ptr >> 12) & 3u, f = ptr & 0xFFFu;
+    uint32_t kind = (ptr >> 12) & 7u, f = ptr & 0xFFFu;
+    int fy = (int)f / TW, fx = (int)f % TW;
     unsigned long long o = fht_pack(FHT_DEAD, 0, FHT_DONE);
-    if ((ncf & FHT_DONE) && kind == K_RIVER) {
-      o = fht_pack((uint32_t)((y0 + (int)f / TW) * W + x0 + (int)f % TW), nd, nc | FHT_DONE);
-    } else if ((ncf & FHT_DONE) && kind == K_EXIT) {
-      int fy = (int)f / TW, fx = (int)f % TW, dy, dx;
+    if (!(ncf & FHT_DONE)) {
+      // unreachable: every in-tile path is finished after the doubling rounds
+    } else if (kind == K_RIVER) {
+      o = fht_pack((uint32_t)((y0 + fy) * w.W + x0 + fx), nd, nc | FHT_DONE);
+    } else if (kind == K_EXIT || kind == K_REXIT) {
+      int dy, dx;
       dt_d8_delta(s_fdr[f], dy, dx);
-      int gy = y0 + fy + dy, gx = x0 + fx + dx;
-      int t2y = gy / TH, t2x = gx / TW;
-      uint32_t node = (uint32_t)((t2y * tiles_x + t2x) * PS + dt_slot_of(gy - t2y * TH, gx - t2x * TW));
       bool diag = dy != 0 && dx != 0;
+      uint32_t node = kind == K_EXIT ? dt_node_of(y0 + fy + dy, x0 + fx + dx, tiles_x)
+                                     : nnodes + (uint32_t)dt_perim_index(w.H, w.W, y0 + fy, x0 + fx);
       o = fht_pack(node, nd + (diag ? 1u : 0u), nc + (diag ? 0u : 1u));
     }
     nodes[(size_t)tile * PS + threadIdx.x] = o;
   }
 }
 
-// pass 3: resolved node words -> rasters
-__global__ __launch_bounds__(256) void k_fh_tile3(const uint8_t *__restrict__ fdr,
-                                                 const int8_t *__restrict__ river,
-                                                 const float *__restrict__ dem,
-                                                 const int32_t *__restrict__ acc32, int H, int W,
-                                                 int tiles_x, const unsigned long long *__restrict__ nodes,
-                                                 double px, float *__restrict__ fdist,
-                                                 int32_t *__restrict__ idx32, float *__restrict__ hand,
-                                                 int32_t *__restrict__ a_river) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_fdr[NT];
-  __shared__ uint8_t s_halo[2 * (TW + 2) + 2 * TH];
-  __shared__ unsigned long long s_st[NT];
-  __shared__ unsigned long long s_x[PS];  // resolved word of the node each exit cell steps onto (+ the step)
-  const int tile = blockIdx.x;
-  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-  const int y0 = ty * TH, x0 = tx * TW;
-  FhTile T{s_fdr, s_halo, s_st};
-  fht_solve_tile(T, fdr, river, H, W, y0, x0);
-  if (threadIdx.x < PS) {
-    int ly, lx;
-    dt_cell_of_slot(threadIdx.x, ly, lx);
-    int f = ly * TW + lx;
-    unsigned long long s = s_st[f];
-    unsigned long long o = fht_pack(FHT_DEAD, 0, FHT_DONE);
-    // only exit cells (a finished word pointing at itself with kind EXIT) are looked up
-    if ((uint32_t)(s >> 32) == ((uint32_t)f | (K_EXIT << 12))) {
-      int dy, dx;
-      dt_d8_delta(s_fdr[f], dy, dx);
-      int gy = y0 + ly + dy, gx = x0 + lx + dx;
-      int t2y = gy / TH, t2x = gx / TW;
-      size_t node = (size_t)(t2y * tiles_x + t2x) * PS + dt_slot_of(gy - t2y * TH, gx - t2x * TW);
-      unsigned long long ns = nodes[node];
-      uint32_t nptr = (uint32_t)(ns >> 32), nnd = (uint32_t)((ns >> 16) & 0xFFFFu);
-      uint32_t nncf = (uint32_t)(ns & 0xFFFFu);
-      bool diag = dy != 0 && dx != 0;
-      // not done after all rounds == longer than the cap
-      if ((nncf & FHT_DONE) && nptr != FHT_DEAD)
-        o = fht_pack(nptr, nnd + (diag ? 1u : 0u), ((nncf & 0x7FFFu) + (diag ? 0u : 1u)) | FHT_DONE);
-    }
-    s_x[threadIdx.x] = o;
-  }
-  __syncthreads();
-  const double dcard = px, ddiag = px * sqrt(2.0);
-  for (int j = 0; j < CPT; j++) {
-    int c = threadIdx.x + 256 * j;
-    int gy = y0 + c / TW, gx = x0 + c % TW;
-    if (gy >= H || gx >= W) continue;
-    unsigned long long s = s_st[c];
-    uint32_t ptr = (uint32_t)(s >> 32), nd = (uint32_t)((s >> 16) & 0xFFFFu);
-    uint32_t ncf = (uint32_t)(s & 0xFFFFu), nc = ncf & 0x7FFFu;
-    uint32_t kind = (ptr >> 12) & 3u, f = ptr & 0xFFFu;
-    bool ok = false;
-    uint32_t ridx = 0;
-    if (ncf & FHT_DONE) {
-      if (kind == K_RIVER) {
-        ok = true;
-        ridx = (uint32_t)((y0 + (int)f / TW) * W + x0 + (int)f % TW);
-      } else if (kind == K_EXIT) {
-        unsigned long long xs = s_x[dt_slot_of((int)f / TW, (int)f % TW)];
-        uint32_t xptr = (uint32_t)(xs >> 32);
-        if (xptr != FHT_DEAD) {
-          nc += (uint32_t)(xs & 0x7FFFu);
-          nd += (uint32_t)((xs >> 16) & 0xFFFFu);
-          ok = nc + nd <= FHT_CAP;  // flowhand.py:834-837
-          ridx = xptr;
-        }
-      }
-    }
-    size_t o = (size_t)gy * W + gx;
-    if (fdist) fdist[o] = ok ? (float)(dcard * (double)nc + ddiag * (double)nd) : DT_NODATA;
-    if (idx32) idx32[o] = ok ? (int32_t)ridx : -100;
-    if (hand) {
-      float h = DT_NODATA, z = dem[o];
-      if (z != DT_NODATA && ok) {  // flowhand.py:436
-        h = z - dem[ridx];
-        if (h < 0.0f && h != DT_NODATA) h = 0.0f;  // flowhand.py:438
-      }
-      hand[o] = h;
-    }
-    if (a_river) a_river[o] = ok ? acc32[ridx] : acc32[0];  // gfi.py:141-143
-  }
+// ghost g of ring cell i: a fixed point (ptr = itself, no moves, not done) until resolved
+__global__ __launch_bounds__(256) void k_fh_ghost_init(unsigned long long *__restrict__ nodes, uint32_t nnodes,
+                                                      int64_t P) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < P) nodes[nnodes + i] = fht_pack(nnodes + (uint32_t)i, 0, 0);
 }
 
 // pass 2: pointer doubling over the perimeter nodes (same word format as the v1 raster kernel)
@@ -616,37 +702,230 @@ __global__ __launch_bounds__(256) void k_fh_node_jump(unsigned long long *__rest
   uint32_t ncf = (uint32_t)(s & 0xFFFFu);
   if (ncf & FHT_DONE) return;
   uint32_t ptr = (uint32_t)(s >> 32), nd = (uint32_t)((s >> 16) & 0xFFFFu);
+  if (ptr == (uint32_t)i) return;  // unresolved ghost
   unsigned long long t = __hip_atomic_load(&state[ptr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   uint32_t tptr = (uint32_t)(t >> 32), tnd = (uint32_t)((t >> 16) & 0xFFFFu);
   uint32_t tncf = (uint32_t)(t & 0xFFFFu);
   uint32_t nnc = ncf + (tncf & 0x7FFFu), nnd = nd + tnd;
   unsigned long long o;
-  if (tptr == FHT_DEAD || nnc + nnd > FHT_CAP) o = fht_pack(FHT_DEAD, 0, FHT_DONE);
+  if (((tncf & FHT_DONE) && tptr == FHT_DEAD) || nnc + nnd > FHT_CAP) o = fht_pack(FHT_DEAD, 0, FHT_DONE);
   else o = fht_pack(tptr, nnd, nnc | (tncf & FHT_DONE));
   __hip_atomic_store(&state[i], o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-size_t dt_flowhand_tiled_scratch(int64_t H, int64_t W) {
-  int64_t ntiles = ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
-  return dt_align256((size_t)ntiles * PS * 8) + 256;
+// rank level: one row per core-ring cell describing the path that ENTERS the rank there:
+//   kind 1 river (ref = core-local flat index, zr / ar = its height / accumulation), 2 dead,
+//   4 leaves the rank again through ring cell `ref` after (nc, nd) moves INCLUDING the crossing step
+__global__ __launch_bounds__(256) void k_fh_rank_summary(DtWin w, int tiles_x, uint32_t nnodes,
+                                                        const unsigned long long *__restrict__ nodes,
+                                                        const float *__restrict__ dem,
+                                                        const int32_t *__restrict__ acc32, int64_t P,
+                                                        uint8_t *__restrict__ kind, int32_t *__restrict__ ref,
+                                                        int32_t *__restrict__ nc, int32_t *__restrict__ nd,
+                                                        float *__restrict__ zr, int32_t *__restrict__ ar) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= P) return;
+  int y, x;
+  dt_perim_cell(w.H, w.W, i, y, x);
+  unsigned long long s = nodes[dt_node_of(y, x, tiles_x)];
+  uint32_t ptr = (uint32_t)(s >> 32), ncf = (uint32_t)(s & 0xFFFFu);
+  uint8_t k = (uint8_t)K_DEAD;
+  int32_t r = -1;
+  float z = DT_NODATA;
+  int32_t a = 0;
+  if (ncf & FHT_DONE) {
+    if (ptr != FHT_DEAD) {
+      k = (uint8_t)K_RIVER;
+      r = (int32_t)ptr;
+      long long o = (long long)(ptr / (uint32_t)w.W) * w.ld + (ptr % (uint32_t)w.W);
+      if (dem) z = dem[o];
+      if (acc32) a = acc32[o];
+    }
+  } else if (ptr >= nnodes) {  // parked on a ghost: leaves the rank
+    k = (uint8_t)K_REXIT;
+    r = (int32_t)(ptr - nnodes);
+  }  // else: not resolved within the cap -> dead
+  kind[i] = k;
+  ref[i] = r;
+  nc[i] = (int32_t)(ncf & 0x7FFFu);
+  nd[i] = (int32_t)((s >> 16) & 0xFFFFu);
+  zr[i] = z;
+  ar[i] = a;
 }
 
-int dt_launch_flowhand_tiled(hipStream_t s, const float *dem, const uint8_t *fdr, const int8_t *river,
-                             const int32_t *acc32, int64_t H, int64_t W, double px, void *scratch,
-                             size_t scratch_bytes, float *fdist, int32_t *idx32, float *hand,
-                             int32_t *a_river) {
-  if (H == 0 || W == 0) return DT_OK;
-  int tiles_x = (int)((W + TW - 1) / TW), tiles_y = (int)((H + TH - 1) / TH);
-  int64_t ntiles = (int64_t)tiles_x * tiles_y;
-  int64_t nnodes = ntiles * PS;
-  DT_REQUIRE(nnodes < 0xFFFFFFF0ll, "raster too large for one device tile");
-  DT_REQUIRE(scratch_bytes >= dt_flowhand_tiled_scratch(H, W), "scratch too small");
-  unsigned long long *nodes = (unsigned long long *)scratch;
-  dim3 gt((unsigned)ntiles), b(256), gn((unsigned)((nnodes + 255) / 256));
-  hipLaunchKernelGGL(k_fh_tile1, gt, b, 0, s, fdr, river, (int)H, (int)W, tiles_x, nodes);
+// write the rank-level result of every rank exit into its ghost: res_ok[i] != 0 -> the path leaving
+// through ring cell i ends on a river cell after (res_nc, res_nd) further moves (payload key = i)
+__global__ __launch_bounds__(256) void k_fh_ghost_set(unsigned long long *__restrict__ nodes, uint32_t nnodes,
+                                                     int64_t P, const uint8_t *__restrict__ res_ok,
+                                                     const int32_t *__restrict__ res_nc,
+                                                     const int32_t *__restrict__ res_nd) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= P) return;
+  unsigned long long o = fht_pack(FHT_DEAD, 0, FHT_DONE);
+  if (res_ok[i]) o = fht_pack(FHT_REMOTE | (uint32_t)i, (uint32_t)res_nd[i], (uint32_t)res_nc[i] | FHT_DONE);
+  nodes[nnodes + i] = o;
+}
+
+// pass 3: resolved node words -> rasters
+struct FhRemote {  // payload of rank exits (multi-GPU), all indexed by core-ring index; NULL when unused
+  const long long *gidx;
+  const float *zr;
+  const int32_t *ar;
+};
+
+__global__ __launch_bounds__(256) void k_fh_tile3(const uint8_t *__restrict__ fdr,
+                                                 const int8_t *__restrict__ river,
+                                                 const float *__restrict__ dem,
+                                                 const int32_t *__restrict__ acc32, DtWin w, int tiles_x,
+                                                 uint32_t nnodes, const unsigned long long *__restrict__ nodes,
+                                                 FhRemote rem, double px, float *__restrict__ fdist,
+                                                 int32_t *__restrict__ idx32, long long *__restrict__ idx64,
+                                                 float *__restrict__ hand, int32_t *__restrict__ a_river) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_fdr[NT];
+  __shared__ uint8_t s_halo[2 * (TW + 2) + 2 * TH];
+  __shared__ unsigned long long s_st[NT];
+  __shared__ unsigned long long s_x[PS];  // resolved word of the node each exit cell steps onto (+ the step)
+  const int tile = blockIdx.x;
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const int y0 = ty * TH, x0 = tx * TW;
+  FhTile T{s_fdr, s_halo, s_st};
+  fht_solve_tile(T, fdr, river, w, y0, x0);
+  if (threadIdx.x < PS) {
+    int ly, lx;
+    dt_cell_of_slot(threadIdx.x, ly, lx);
+    int f = ly * TW + lx;
+    unsigned long long s = s_st[f];
+    uint32_t sp = (uint32_t)(s >> 32);
+    unsigned long long o = fht_pack(FHT_DEAD, 0, FHT_DONE);
+    // only exit cells (a finished word pointing at itself with kind EXIT / REXIT) are looked up
+    bool ex = sp == ((uint32_t)f | (K_EXIT << 12)), rex = sp == ((uint32_t)f | (K_REXIT << 12));
+    if (ex || rex) {
+      int dy, dx;
+      dt_d8_delta(s_fdr[f], dy, dx);
+      size_t node = ex ? (size_t)dt_node_of(y0 + ly + dy, x0 + lx + dx, tiles_x)
+                       : (size_t)nnodes + (size_t)dt_perim_index(w.H, w.W, y0 + ly, x0 + lx);
+      unsigned long long ns = nodes[node];
+      uint32_t nptr = (uint32_t)(ns >> 32), nnd = (uint32_t)((ns >> 16) & 0xFFFFu);
+      uint32_t nncf = (uint32_t)(ns & 0xFFFFu);
+      bool diag = dy != 0 && dx != 0;
+      // not done after all rounds == longer than the cap (or an unresolved rank exit)
+      if ((nncf & FHT_DONE) && nptr != FHT_DEAD)
+        o = fht_pack(nptr, nnd + (diag ? 1u : 0u), ((nncf & 0x7FFFu) + (diag ? 0u : 1u)) | FHT_DONE);
+    }
+    s_x[threadIdx.x] = o;
+  }
+  __syncthreads();
+  const double dcard = px, ddiag = px * sqrt(2.0);
+  for (int j = 0; j < CPT; j++) {
+    int c = threadIdx.x + 256 * j;
+    int y = y0 + c / TW, x = x0 + c % TW;
+    if (y >= w.H || x >= w.W) continue;
+    unsigned long long s = s_st[c];
+    uint32_t ptr = (uint32_t)(s >> 32), nd = (uint32_t)((s >> 16) & 0xFFFFu);
+    uint32_t ncf = (uint32_t)(s & 0xFFFFu), nc = ncf & 0x7FFFu;
+    uint32_t kind = (ptr >> 12) & 7u, f = ptr & 0xFFFu;
+    bool ok = false;
+    uint32_t ridx = 0;  // core-local flat index of the river cell, or FHT_REMOTE | ring index
+    if (ncf & FHT_DONE) {
+      if (kind == K_RIVER) {
+        ok = true;
+        ridx = (uint32_t)((y0 + (int)f / TW) * w.W + x0 + (int)f % TW);
+      } else if (kind == K_EXIT || kind == K_REXIT) {
+        unsigned long long xs = s_x[dt_slot_of((int)f / TW, (int)f % TW)];
+        uint32_t xptr = (uint32_t)(xs >> 32);
+        if (xptr != FHT_DEAD) {
+          nc += (uint32_t)(xs & 0x7FFFu);
+          nd += (uint32_t)((xs >> 16) & 0xFFFFu);
+          ok = nc + nd <= FHT_CAP;  // flowhand.py:834-837
+          ridx = xptr;
+        }
+      }
+    }
+    const bool remote = ok && (ridx & FHT_REMOTE) != 0u;
+    const uint32_t key = ridx & ~FHT_REMOTE;
+    long long ro = 0;  // raster offset of a local river cell
+    if (ok && !remote) ro = (long long)(ridx / (uint32_t)w.W) * w.ld + (ridx % (uint32_t)w.W);
+    long long o = (long long)y * w.ld + x;
+    if (fdist) fdist[o] = ok ? (float)(dcard * (double)nc + ddiag * (double)nd) : DT_NODATA;
+    if (idx32) idx32[o] = (ok && !remote) ? (int32_t)ridx : -100;
+    if (idx64) {
+      long long g = -100;
+      if (ok) g = remote ? rem.gidx[key]
+                         : (long long)(w.gy0 + (int)(ridx / (uint32_t)w.W)) * w.Wg + w.gx0 + (int)(ridx % (uint32_t)w.W);
+      idx64[o] = g;
+    }
+    if (hand) {
+      float h = DT_NODATA, z = dem[o];
+      if (z != DT_NODATA && ok) {  // flowhand.py:436
+        h = z - (remote ? rem.zr[key] : dem[ro]);
+        if (h < 0.0f && h != DT_NODATA) h = 0.0f;  // flowhand.py:438
+      }
+      hand[o] = h;
+    }
+    if (a_river) a_river[o] = ok ? (remote ? rem.ar[key] : acc32[ro]) : acc32[0];  // gfi.py:141-143
+  }
+}
+
+struct FhScratch {
+  unsigned long long *nodes;
+  int64_t nnodes, ntiles, P;
+  int tiles_x;
+};
+static FhScratch fh_layout(const DtWin &w, void *scratch) {
+  FhScratch f;
+  f.tiles_x = (w.W + TW - 1) / TW;
+  f.ntiles = (int64_t)f.tiles_x * ((w.H + TH - 1) / TH);
+  f.nnodes = f.ntiles * PS;
+  f.P = dt_perim_count(w.H, w.W);
+  f.nodes = (unsigned long long *)scratch;
+  return f;
+}
+size_t dt_flowhand_tiled_scratch(int64_t H, int64_t W) {
+  int64_t ntiles = ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
+  return dt_align256(((size_t)ntiles * PS + (size_t)dt_perim_count((int)H, (int)W)) * 8) + 256;
+}
+
+// phase 1: tile pass + perimeter node doubling (rank exits park on their ghosts)
+int dt_launch_fh_local(hipStream_t s, const DtWin &w, const uint8_t *fdr, const int8_t *river, void *scratch,
+                       size_t scratch_bytes) {
+  if (w.H == 0 || w.W == 0) return DT_OK;
+  DT_REQUIRE(scratch_bytes >= dt_flowhand_tiled_scratch(w.H, w.W), "scratch too small");
+  FhScratch f = fh_layout(w, scratch);
+  DT_REQUIRE(f.nnodes + f.P < 0x7FFFFFF0ll, "raster too large for one device tile");
+  dim3 gt((unsigned)f.ntiles), b(256), gn((unsigned)((f.nnodes + f.P + 255) / 256));
+  hipLaunchKernelGGL(k_fh_tile1, gt, b, 0, s, fdr, river, w, f.tiles_x, (uint32_t)f.nnodes, f.nodes);
+  hipLaunchKernelGGL(k_fh_ghost_init, dim3((unsigned)((f.P + 255) / 256)), b, 0, s, f.nodes, (uint32_t)f.nnodes, f.P);
   // 15 rounds resolve every chain of <= 20000 moves (each node hop is >= 1 move; 2^15 > 20000)
-  for (int r = 0; r < 15; r++) hipLaunchKernelGGL(k_fh_node_jump, gn, b, 0, s, nodes, nnodes);
-  hipLaunchKernelGGL(k_fh_tile3, gt, b, 0, s, fdr, river, dem, acc32, (int)H, (int)W, tiles_x, nodes, px,
-                     fdist, idx32, hand, a_river);
+  for (int r = 0; r < 15; r++) hipLaunchKernelGGL(k_fh_node_jump, gn, b, 0, s, f.nodes, f.nnodes + f.P);
+  return DT_OK;
+}
+
+int dt_launch_fh_summary(hipStream_t s, const DtWin &w, void *scratch, const float *dem, const int32_t *acc32,
+                         uint8_t *kind, int32_t *ref, int32_t *nc, int32_t *nd, float *zr, int32_t *ar) {
+  FhScratch f = fh_layout(w, scratch);
+  if (f.P == 0) return DT_OK;
+  hipLaunchKernelGGL(k_fh_rank_summary, dim3((unsigned)((f.P + 255) / 256)), dim3(256), 0, s, w, f.tiles_x,
+                     (uint32_t)f.nnodes, f.nodes, dem, acc32, f.P, kind, ref, nc, nd, zr, ar);
+  return DT_OK;
+}
+
+// phase 2: optional rank-exit results (res_* and rem_* indexed by core-ring index), final tile pass
+int dt_launch_fh_finish(hipStream_t s, const DtWin &w, const float *dem, const uint8_t *fdr,
+                        const int8_t *river, const int32_t *acc32, double px, void *scratch,
+                        const uint8_t *res_ok, const int32_t *res_nc, const int32_t *res_nd,
+                        const long long *rem_gidx, const float *rem_zr, const int32_t *rem_ar, float *fdist,
+                        int32_t *idx32, long long *idx64, float *hand, int32_t *a_river) {
+  if (w.H == 0 || w.W == 0) return DT_OK;
+  FhScratch f = fh_layout(w, scratch);
+  dim3 gt((unsigned)f.ntiles), b(256), gn((unsigned)((f.nnodes + f.P + 255) / 256));
+  if (res_ok) {
+    hipLaunchKernelGGL(k_fh_ghost_set, dim3((unsigned)((f.P + 255) / 256)), b, 0, s, f.nodes, (uint32_t)f.nnodes,
+                       f.P, res_ok, res_nc, res_nd);
+    // nodes parked on a ghost pick up its result (they point at it directly: one hop; two for safety)
+    for (int r = 0; r < 2; r++) hipLaunchKernelGGL(k_fh_node_jump, gn, b, 0, s, f.nodes, f.nnodes + f.P);
+  }
+  FhRemote rem{rem_gidx, rem_zr, rem_ar};
+  hipLaunchKernelGGL(k_fh_tile3, gt, b, 0, s, fdr, river, dem, acc32, w, f.tiles_x, (uint32_t)f.nnodes, f.nodes,
+                     rem, px, fdist, idx32, idx64, hand, a_river);
   return DT_OK;
 }

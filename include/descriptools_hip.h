@@ -35,6 +35,14 @@ extern "C" {
 
 typedef struct dt_ctx dt_ctx;
 
+/* One rank's CORE window (H x W cells) of a global Hg x Wg raster, at global offset (gy0, gx0).
+ * Every raster pointer passed with a window addresses the core origin with row stride ld; `halo`
+ * cells beyond the core exist in memory on every side (>= 1 when the global raster is larger).
+ * Single GPU: ld = W, gy0 = gx0 = 0, Hg = H, Wg = W, halo = 0. */
+typedef struct dt_window {
+  int64_t H, W, ld, gy0, gx0, Hg, Wg, halo;
+} dt_window;
+
 /* ---- runtime ------------------------------------------------------------------------- */
 const char *dt_last_error(void);
 int dt_device_count(void);
@@ -160,6 +168,42 @@ int dt_dev_downslope(dt_ctx *ctx, const float *dem, const uint8_t *fdr, int64_t 
 int dt_dev_confusion_multi(dt_ctx *ctx, const double *desc, const int8_t *flood, int64_t N,
                            double nodata_value, const double *th_host, int nth, int under,
                            int64_t *counts4_dev);
+/* ---- windowed device tier: the same kernels on one rank's window of a larger raster (multi-GPU).
+ * Flow accumulation and HAND are split in two phases so the ranks can exchange one summary row per
+ * cell of their core ring in between (descriptools_amd/tiling.py).  Ring order: top row, bottom row,
+ * left column, right column (dt_perim_cells(H, W) rows). ------------------------------------------ */
+int64_t dt_perim_cells(int64_t H, int64_t W);
+int dt_dev_slope_d8_w(dt_ctx *ctx, const dt_window *win, const float *dem, double px, float *slope,
+                      uint8_t *fdr, float *slope_rad);
+int dt_dev_slope_twi_w(dt_ctx *ctx, const dt_window *win, const float *dem, const int32_t *acc32, double px,
+                       double n_top, float *slope, float *slope_rad, float *ti, float *mti);
+/* n_unresolved_dev (device int32, may be NULL): walks that left this rank's halo (marked -50) */
+int dt_dev_downslope_w(dt_ctx *ctx, const dt_window *win, const float *dem, const uint8_t *fdr, double px,
+                       double elevation_difference, int raw, float *out, int32_t *n_unresolved_dev);
+/* phase 1: in-rank accumulation; per ring cell: A = cells of this rank draining OUT through it (0 unless
+ * its D8 step leaves the core), code = that step's D8 code, xr = ring index of the rank exit reached by
+ * a path ENTERING at this cell (-1 none, -2 cycle inside the rank) */
+int dt_dev_flowacc_local_w(dt_ctx *ctx, const dt_window *win, const uint8_t *fdr, int32_t *acc32,
+                           int64_t *A_perim, int32_t *xr_perim, uint8_t *code_perim);
+/* phase 2: ext_perim[i] = inflow arriving at ring cell i from other ranks (bit 63: fed by a D8 cycle
+ * spanning ranks); NULL = none.  Must directly follow phase 1 on the same context. */
+int dt_dev_flowacc_finish_w(dt_ctx *ctx, const dt_window *win, const uint8_t *fdr, const float *dem,
+                            const uint64_t *ext_perim, int64_t threshold, int32_t *acc32, int8_t *river);
+/* phase 1: per ring cell, the path ENTERING the rank there: kind 1 = ends on river cell `ref` (core-local
+ * flat index; zr / ar = its height / accumulation), 2 = dead, 4 = leaves the rank again through ring
+ * cell `ref`; nc / nd = cardinal / diagonal moves (kind 4: including the step out of the rank) */
+int dt_dev_flowhand_local_w(dt_ctx *ctx, const dt_window *win, const float *dem, const uint8_t *fdr,
+                            const int8_t *river, const int32_t *acc32, uint8_t *kind, int32_t *ref,
+                            int32_t *nc, int32_t *nd, float *zr, int32_t *ar);
+/* phase 2: for every ring cell whose step leaves the rank: res_ok != 0 -> that path ends on a river
+ * cell after res_nc / res_nd further moves, global flat index rem_gidx, height rem_zr, accumulation
+ * rem_ar (all NULL = no other ranks).  idx64 (may be NULL) receives GLOBAL flat indices. */
+int dt_dev_flowhand_finish_w(dt_ctx *ctx, const dt_window *win, const float *dem, const uint8_t *fdr,
+                             const int8_t *river, const int32_t *acc32, double px, const uint8_t *res_ok,
+                             const int32_t *res_nc, const int32_t *res_nd, const int64_t *rem_gidx,
+                             const float *rem_zr, const int32_t *rem_ar, float *fdist, int32_t *idx32,
+                             int64_t *idx64, float *hand, int32_t *a_river);
+
 /* widen / narrow helpers for the int64 API dtypes */
 int dt_dev_i32_to_i64(dt_ctx *ctx, const int32_t *src, int64_t N, int64_t *dst);
 int dt_dev_i64_to_i32(dt_ctx *ctx, const int64_t *src, int64_t N, int32_t *dst);
