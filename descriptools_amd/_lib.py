@@ -86,11 +86,32 @@ def exported_symbols():
     return sorted(_SIGS)
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.  Two HIP runtimes in one process do not
+    share the GPU (whichever initialises second sees "no HIP GPUs"), so if torch is installed but not
+    imported yet, load ITS runtime first: our library then binds to the same one, whatever the
+    import order.  Without torch the system runtime (/opt/rocm) is used."""
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:  # pragma: no cover - best effort
+        pass
+
+
 def lib():
     """Load (building in-tree if the .so is missing) the HIP library; raises if impossible."""
     global _lib
     if _lib is not None:
         return _lib
+    _preload_torch_hip_runtime()
     if not os.path.exists(_SO):
         from . import build as _build  # hipcc cross-compiles; raises CalledProcessError on failure
         _build.build()

@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256) void k_fh_final(const unsigned long long *__re
     }
     hand[i] = h;
   }
-  if (a_river) a_river[i] = ok ? acc32[ptr] : acc32[0];  // gfi.py:141-143
+  if (a_river) a_river[i] = ok ? acc32[ptr] : -100;  // payload for GFI; -100 where hand is -100
 }
 
 int dt_launch_flowhand(hipStream_t s, const float *dem, const uint8_t *fdr, const int8_t *river,

@@ -862,7 +862,9 @@ __global__ __launch_bounds__(256) void k_fh_tile3(const uint8_t *__restrict__ fd
       }
       hand[o] = h;
     }
-    if (a_river) a_river[o] = ok ? (remote ? rem.ar[key] : acc32[ro]) : acc32[0];  // gfi.py:141-143
+    // A_river = fac[idx] carried as payload; cells without a river cell get -100 (GFI is -100 there
+    // anyway: their hand is -100, gfi.py:289)
+    if (a_river) a_river[o] = ok ? (remote ? rem.ar[key] : acc32[ro]) : -100;
   }
 }
 

@@ -1,0 +1,458 @@
+"""Multi-GPU tiling of the descriptor chain: one process per GPU, one core tile per rank.
+
+The reference "tiles" on the host to fit a small GPU (division_* arguments) and stitches with CPU
+pre-solves / repairs (flowhand.py:282-286, downslope.py:373-374).  Here a large DEM is tiled across
+the GPUs of a node; what crosses a tile border is exchanged once per descriptor:
+
+  slope / D8      a halo of the DEM (point-to-point with the <= 8 neighbouring ranks; synthetic DEMs
+                  generate their halo locally)
+  flow accum.     phase 1 per rank (dt_dev_flowacc_local_w) -> ALL-GATHER of one summary row per cell of
+                  the core ring -> every rank solves the small rank-level graph redundantly
+                  (solve_flowacc) -> phase 2 injects the inflow from other ranks
+  HAND            same shape: phase 1 -> all-gather ring summaries -> solve_flowhand (pointer doubling
+                  over ring entries) -> phase 2 with the resolved river cell (global index, height,
+                  accumulation carried as payload: no remote gathers)
+  downslope       walks are short: a 64-cell halo of dem + fdr; a walk that leaves it is counted and
+                  reported (none on the benchmark DEMs)
+  TI/MTI, GFI ... local
+
+Messages are tiny (a ring row is 13-25 bytes per border cell), so the exchanges are latency-bound:
+one all-gather each, no ring all-reduce.  The rank-level solves are plain numpy on every rank and are
+shared with the single-process simulation (`simulate`) that proves tiled == untiled on one GPU, and
+with the gloo CPU tests.
+"""
+import ctypes as C
+
+import numpy as np
+
+FA_CYCLE = np.uint64(1 << 63)
+CAP = 20000
+K_RIVER, K_DEAD, K_REXIT = 1, 2, 4
+HALO = 64
+
+_DY = {1: 0, 2: 1, 4: 1, 8: 1, 16: 0, 32: -1, 64: -1, 128: -1}
+_DX = {1: 1, 2: 1, 4: 0, 8: -1, 16: -1, 32: -1, 64: 0, 128: 1}
+_DY_LUT = np.zeros(256, np.int64)
+_DX_LUT = np.zeros(256, np.int64)
+for _c in _DY:
+    _DY_LUT[_c], _DX_LUT[_c] = _DY[_c], _DX[_c]
+
+
+# ---------------------------------------------------------------------------------------------------
+# geometry
+# ---------------------------------------------------------------------------------------------------
+class Layout:
+    """ty x tx grid of rank tiles; rank r owns rows [ys[r//tx], ys[r//tx+1]) x cols [xs[r%tx], ...)."""
+
+    def __init__(self, heights, widths):
+        self.heights, self.widths = [int(h) for h in heights], [int(w) for w in widths]
+        self.ty, self.tx = len(self.heights), len(self.widths)
+        self.ys = np.concatenate([[0], np.cumsum(self.heights)]).astype(np.int64)
+        self.xs = np.concatenate([[0], np.cumsum(self.widths)]).astype(np.int64)
+        self.Hg, self.Wg = int(self.ys[-1]), int(self.xs[-1])
+        self.size = self.ty * self.tx
+        # rank borders must fall on the 64-cell tile grid of each rank (the in-LDS tiles are anchored
+        # at the core origin); only the last row / column of ranks may be ragged
+        assert all(h % 64 == 0 for h in self.heights[:-1]) and all(w % 64 == 0 for w in self.widths[:-1]), \
+            "rank tile heights / widths must be multiples of 64 (except the last row / column)"
+
+    @staticmethod
+    def uniform(world, H, W):
+        tx = 1
+        while tx * tx < world:
+            tx *= 2
+        ty = (world + tx - 1) // tx
+        assert ty * tx == world, "world size must be a power of two (or fill a ty x tx grid)"
+        return Layout([H] * ty, [W] * tx)
+
+    def origin(self, r):
+        return int(self.ys[r // self.tx]), int(self.xs[r % self.tx])
+
+    def shape(self, r):
+        return self.heights[r // self.tx], self.widths[r % self.tx]
+
+    def owner(self, gy, gx):
+        """rank owning global cells (vectorised)."""
+        ry = np.searchsorted(self.ys, gy, side="right") - 1
+        rx = np.searchsorted(self.xs, gx, side="right") - 1
+        return ry * self.tx + rx
+
+
+def perim_count(H, W):
+    if H <= 0 or W <= 0:
+        return 0
+    if H == 1:
+        return W
+    if W == 1:
+        return H
+    return 2 * W + 2 * (H - 2)
+
+
+def ring_coords(H, W):
+    """core-local (y, x) of the ring cells in the library's order (dt_perim_cell)."""
+    if H == 1:
+        return np.zeros(W, np.int64), np.arange(W, dtype=np.int64)
+    if W == 1:
+        return np.arange(H, dtype=np.int64), np.zeros(H, np.int64)
+    y = np.concatenate([np.zeros(W), np.full(W, H - 1), np.arange(1, H - 1), np.arange(1, H - 1)])
+    x = np.concatenate([np.arange(W), np.arange(W), np.zeros(H - 2), np.full(H - 2, W - 1)])
+    return y.astype(np.int64), x.astype(np.int64)
+
+
+def ring_index(H, W, y, x):
+    """inverse of ring_coords (vectorised); -1 for interior cells."""
+    y, x = np.asarray(y, np.int64), np.asarray(x, np.int64)
+    if H == 1:
+        return x.copy()
+    if W == 1:
+        return y.copy()
+    out = np.full(y.shape, -1, np.int64)
+    m = x == W - 1
+    out[m] = 2 * W + (H - 2) + (y[m] - 1)
+    m = x == 0
+    out[m] = 2 * W + (y[m] - 1)
+    m = y == H - 1
+    out[m] = W + x[m]
+    m = y == 0
+    out[m] = x[m]
+    return out
+
+
+def _exit_targets(layout, r, codes):
+    """for ring cells of rank r whose D8 step (codes, 0 = none) leaves the core into another rank:
+    (ring indices i, owner rank, ring index in the owner)."""
+    H, W = layout.shape(r)
+    y0, x0 = layout.origin(r)
+    ys, xs = ring_coords(H, W)
+    codes = np.asarray(codes, np.uint8)
+    ty, tx = ys + _DY_LUT[codes], xs + _DX_LUT[codes]
+    leaves = (codes != 0) & ((ty < 0) | (ty >= H) | (tx < 0) | (tx >= W))
+    gy, gx = y0 + ty, x0 + tx
+    leaves &= (gy >= 0) & (gy < layout.Hg) & (gx >= 0) & (gx < layout.Wg)
+    i = np.nonzero(leaves)[0]
+    own = layout.owner(gy[i], gx[i])
+    tgt = np.empty(len(i), np.int64)
+    for o in np.unique(own):
+        m = own == o
+        oy0, ox0 = layout.origin(int(o))
+        oh, ow = layout.shape(int(o))
+        tgt[m] = ring_index(oh, ow, gy[i][m] - oy0, gx[i][m] - ox0)
+    assert (tgt >= 0).all()
+    return i, own, tgt
+
+
+# ---------------------------------------------------------------------------------------------------
+# rank-level solves (numpy, identical on every rank)
+# ---------------------------------------------------------------------------------------------------
+def solve_flowacc(layout, summaries, max_iter=4096):
+    """summaries[r] = (A int64[P_r], xr int32[P_r], code uint8[P_r]) from dt_dev_flowacc_local_w.
+    Returns ext[r] uint64[P_r]: inflow arriving at each ring cell from other ranks (bit 63 = fed by
+    a D8 cycle spanning ranks)."""
+    P = [len(s[0]) for s in summaries]
+    offs = np.concatenate([[0], np.cumsum(P)]).astype(np.int64)
+    n = int(offs[-1])
+    a_local = np.zeros(n, np.int64)
+    xr_node = np.full(n, -1, np.int64)
+    ex_nodes, ex_tgt = [], []
+    for r, (A, xr, code) in enumerate(summaries):
+        a_local[offs[r]:offs[r + 1]] = A
+        xr = np.asarray(xr, np.int64)
+        xr_node[offs[r]:offs[r + 1]] = np.where(xr >= 0, offs[r] + xr, -1)
+        i, own, tgt = _exit_targets(layout, r, code)
+        ex_nodes.append(offs[r] + i)
+        ex_tgt.append(offs[own] + tgt)
+    E = np.concatenate(ex_nodes) if ex_nodes else np.zeros(0, np.int64)
+    T = np.concatenate(ex_tgt) if ex_tgt else np.zeros(0, np.int64)
+    has = np.nonzero(xr_node >= 0)[0]
+    total = a_local.copy()
+    changed = np.zeros(n, bool)
+    ext = np.zeros(n, np.int64)
+    for _ in range(max_iter):
+        ext = np.zeros(n, np.int64)
+        np.add.at(ext, T, total[E])
+        recv = np.zeros(n, np.int64)
+        np.add.at(recv, xr_node[has], ext[has])
+        new = a_local + recv
+        changed = new != total
+        total = new
+        if not changed.any():
+            break
+    out = ext.astype(np.uint64)
+    if changed.any():  # exits whose total never settles sit on a cycle spanning ranks
+        cyc = changed[E]
+        out[T[cyc]] = out[T[cyc]] | FA_CYCLE
+    return [out[offs[r]:offs[r + 1]].copy() for r in range(len(summaries))]
+
+
+def solve_flowhand(layout, summaries, ring_codes):
+    """summaries[r] = (kind u8, ref i32, nc i32, nd i32, zr f32, ar i32)[P_r] from
+    dt_dev_flowhand_local_w; ring_codes[r] = D8 codes of rank r's ring cells.  Returns per rank
+    (res_ok u8, res_nc i32, res_nd i32, gidx i64, zr f32, ar i32)[P_r] for dt_dev_flowhand_finish_w."""
+    P = [len(s[0]) for s in summaries]
+    offs = np.concatenate([[0], np.cumsum(P)]).astype(np.int64)
+    n = int(offs[-1])
+    kind = np.concatenate([np.asarray(s[0], np.uint8) for s in summaries]) if n else np.zeros(0, np.uint8)
+    nc = np.concatenate([np.asarray(s[2], np.int64) for s in summaries]) if n else np.zeros(0, np.int64)
+    nd = np.concatenate([np.asarray(s[3], np.int64) for s in summaries]) if n else np.zeros(0, np.int64)
+    zr = np.concatenate([np.asarray(s[4], np.float32) for s in summaries]) if n else np.zeros(0, np.float32)
+    ar = np.concatenate([np.asarray(s[5], np.int32) for s in summaries]) if n else np.zeros(0, np.int32)
+    gidx = np.full(n, -100, np.int64)
+    step_tgt = np.full(n, -1, np.int64)  # entry node a ring cell's own D8 step lands on (other rank)
+    for r, s in enumerate(summaries):
+        ref = np.asarray(s[1], np.int64)
+        y0, x0 = layout.origin(r)
+        H, W = layout.shape(r)
+        riv = np.asarray(s[0]) == K_RIVER
+        g = np.full(P[r], -100, np.int64)
+        g[riv] = (y0 + ref[riv] // W) * layout.Wg + x0 + ref[riv] % W
+        gidx[offs[r]:offs[r + 1]] = g
+        i, own, tgt = _exit_targets(layout, r, ring_codes[r])
+        step_tgt[offs[r] + i] = offs[own] + tgt
+    # entry e of kind REXIT continues at the entry its exit ring cell `ref` steps onto
+    ptr = np.full(n, -1, np.int64)
+    for r, s in enumerate(summaries):
+        ref = np.asarray(s[1], np.int64)
+        rex = np.nonzero(np.asarray(s[0]) == K_REXIT)[0]
+        ptr[offs[r] + rex] = step_tgt[offs[r] + ref[rex]]
+    done = (kind == K_RIVER) | (kind == K_DEAD) | (ptr < 0)
+    dead = ~(kind == K_RIVER) & done
+    term = np.arange(n, dtype=np.int64)
+    for _ in range(17):  # pointer doubling, Jacobi; 2^16 rank crossings >> cap of 20000 moves
+        act = np.nonzero(~done)[0]
+        if len(act) == 0:
+            break
+        t = ptr[act]
+        nnc, nnd = nc[act] + nc[t], nd[act] + nd[t]
+        over = nnc + nnd > CAP
+        ndead = dead[t] & done[t] | over
+        ndone = done[t] | over
+        nterm, nptr = term[t], ptr[t]
+        nc[act], nd[act] = np.where(over, 0, nnc), np.where(over, 0, nnd)
+        dead[act], done[act], term[act], ptr[act] = ndead, ndone, nterm, nptr
+    dead |= ~done
+    ok_e = ~dead
+    out = []
+    for r in range(len(summaries)):
+        sl = slice(int(offs[r]), int(offs[r + 1]))
+        tgt = step_tgt[sl]
+        has = tgt >= 0
+        tt = np.where(has, tgt, 0)
+        ok = has & ok_e[tt]
+        tm = term[tt]
+        out.append((ok.astype(np.uint8), np.where(ok, nc[tt], 0).astype(np.int32),
+                    np.where(ok, nd[tt], 0).astype(np.int32), np.where(ok, gidx[tm], -100).astype(np.int64),
+                    np.where(ok, zr[tm], -100).astype(np.float32), np.where(ok, ar[tm], 0).astype(np.int32)))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# one rank's tile on its GPU
+# ---------------------------------------------------------------------------------------------------
+class RankTile:
+    """Extended rasters ((H + 2*HALO) x (W + 2*HALO)) of one rank and the windowed library calls."""
+
+    def __init__(self, layout, rank, device=0, stream=None, px=10.0, n_top=0.1, n_gfi=0.4, b=0.1, dz=5.0,
+                 river_threshold=None, halo=HALO):
+        import torch
+        from . import _lib
+        from .device import Context
+        self.torch, self._lib, self.L = torch, _lib, _lib.lib()
+        self.layout, self.rank, self.halo = layout, rank, halo
+        self.H, self.W = layout.shape(rank)
+        self.gy0, self.gx0 = layout.origin(rank)
+        self.He, self.We = self.H + 2 * halo, self.W + 2 * halo
+        self.dev = torch.device("cuda", device)
+        self.ctx = Context(device=device, stream=stream)
+        self.px, self.n_top, self.n_gfi, self.b, self.dz = px, n_top, n_gfi, b, dz
+        self.river_threshold = (layout.Hg * layout.Wg) // 512 if river_threshold is None else int(river_threshold)
+        self.P = perim_count(self.H, self.W)
+        t = {}
+        for name, dt in (("dem", torch.float32), ("fdr", torch.uint8), ("fac", torch.int32),
+                         ("river", torch.int8), ("fdist", torch.float32), ("idx", torch.int64),
+                         ("hand", torch.float32), ("a_river", torch.int32), ("slope", torch.float32),
+                         ("ti", torch.float32), ("mti", torch.float32), ("gfi", torch.float32),
+                         ("lnhlh", torch.float32), ("down", torch.float32)):
+            t[name] = torch.zeros((self.He, self.We), dtype=dt, device=self.dev)
+        self.t = t
+        self.n_unres = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self.win = _lib.Window(self.H, self.W, self.We, self.gy0, self.gx0, layout.Hg, layout.Wg, halo)
+        ys, xs = ring_coords(self.H, self.W)
+        self._ring_lin = torch.as_tensor((ys + halo) * self.We + xs + halo, device=self.dev)
+
+    # pointer of raster `name` at the core origin
+    def p(self, name):
+        t = self.t[name]
+        return t.data_ptr() + (self.halo * self.We + self.halo) * t.element_size()
+
+    def core(self, name):
+        h = self.halo
+        return self.t[name][h:h + self.H, h:h + self.W]
+
+    def _chk(self, rc):
+        self._lib.check(rc)
+
+    # ---- DEM ---------------------------------------------------------------------------------
+    def synth_dem(self, seed, nodata_pct=0):
+        """generate the core AND its halo from the global generator (clipped to the global raster)."""
+        h = self.halo
+        y0, x0 = max(self.gy0 - h, 0), max(self.gx0 - h, 0)
+        y1, x1 = min(self.gy0 + self.H + h, self.layout.Hg), min(self.gx0 + self.W + h, self.layout.Wg)
+        tmp = self.torch.empty((y1 - y0, x1 - x0), dtype=self.torch.float32, device=self.dev)
+        self._chk(self.L.dt_dev_synth_dem(self.ctx.h, seed, self.layout.Hg, self.layout.Wg, y0, x0, y1 - y0,
+                                          x1 - x0, nodata_pct, tmp.data_ptr()))
+        self.ctx.sync()
+        oy, ox = y0 - (self.gy0 - h), x0 - (self.gx0 - h)
+        self.t["dem"][oy:oy + (y1 - y0), ox:ox + (x1 - x0)] = tmp
+
+    def set_dem_ext(self, dem_ext):
+        """host array of the extended window (He x We); cells outside the global raster are ignored."""
+        self.t["dem"].copy_(self.torch.as_tensor(np.ascontiguousarray(dem_ext, np.float32)))
+
+    # ---- local stages ------------------------------------------------------------------------------
+    def d8(self):
+        """D8 over the core and the halo minus its outermost ring (needed by HAND's 1-cell look-ahead
+        and by downslope's margin)."""
+        h = self.halo
+        m = h - 1
+        y0, x0 = max(self.gy0 - m, 0), max(self.gx0 - m, 0)
+        y1, x1 = min(self.gy0 + self.H + m, self.layout.Hg), min(self.gx0 + self.W + m, self.layout.Wg)
+        win = self._lib.Window(y1 - y0, x1 - x0, self.We, y0, x0, self.layout.Hg, self.layout.Wg, 1)
+        off = ((y0 - (self.gy0 - h)) * self.We + (x0 - (self.gx0 - h)))
+        dem = self.t["dem"].data_ptr() + off * 4
+        fdr = self.t["fdr"].data_ptr() + off
+        self._chk(self.L.dt_dev_slope_d8_w(self.ctx.h, C.byref(win), dem, self.px, None, fdr, None))
+
+    def ring_codes(self):
+        self.ctx.sync()
+        return self.t["fdr"].reshape(-1)[self._ring_lin].cpu().numpy()
+
+    def fa_local(self):
+        tc = self.torch
+        A = tc.empty(self.P, dtype=tc.int64, device=self.dev)
+        xr = tc.empty(self.P, dtype=tc.int32, device=self.dev)
+        code = tc.empty(self.P, dtype=tc.uint8, device=self.dev)
+        self._chk(self.L.dt_dev_flowacc_local_w(self.ctx.h, C.byref(self.win), self.p("fdr"), self.p("fac"),
+                                                A.data_ptr(), xr.data_ptr(), code.data_ptr()))
+        self.ctx.sync()
+        return A, xr, code
+
+    def fa_finish(self, ext):
+        tc = self.torch
+        e = tc.as_tensor(ext.view(np.int64), device=self.dev) if ext is not None else None
+        self._keep = e
+        self._chk(self.L.dt_dev_flowacc_finish_w(self.ctx.h, C.byref(self.win), self.p("fdr"), self.p("dem"),
+                                                 e.data_ptr() if e is not None else None,
+                                                 self.river_threshold, self.p("fac"), self.p("river")))
+
+    def fh_local(self):
+        tc = self.torch
+        kind = tc.empty(self.P, dtype=tc.uint8, device=self.dev)
+        ref, nc, nd, ar = (tc.empty(self.P, dtype=tc.int32, device=self.dev) for _ in range(4))
+        zr = tc.empty(self.P, dtype=tc.float32, device=self.dev)
+        self._chk(self.L.dt_dev_flowhand_local_w(self.ctx.h, C.byref(self.win), self.p("dem"), self.p("fdr"),
+                                                 self.p("river"), self.p("fac"), kind.data_ptr(),
+                                                 ref.data_ptr(), nc.data_ptr(), nd.data_ptr(), zr.data_ptr(),
+                                                 ar.data_ptr()))
+        self.ctx.sync()
+        return kind, ref, nc, nd, zr, ar
+
+    def fh_finish(self, res):
+        tc = self.torch
+        ptrs = [None] * 6
+        if res is not None:
+            self._keep2 = [tc.as_tensor(np.ascontiguousarray(a), device=self.dev) for a in res]
+            ptrs = [a.data_ptr() for a in self._keep2]
+        self._chk(self.L.dt_dev_flowhand_finish_w(self.ctx.h, C.byref(self.win), self.p("dem"), self.p("fdr"),
+                                                  self.p("river"), self.p("fac"), self.px, ptrs[0], ptrs[1],
+                                                  ptrs[2], ptrs[3], ptrs[4], ptrs[5], self.p("fdist"), None,
+                                                  self.p("idx"), self.p("hand"), self.p("a_river")))
+
+    def pointwise(self):
+        """fused slope+TI+MTI on the core window, GFI+ln(hl/H) over the flat extended rasters (halo cells
+        are computed on garbage and never read), downslope on the core window."""
+        n = self.He * self.We
+        self._chk(self.L.dt_dev_slope_twi_w(self.ctx.h, C.byref(self.win), self.p("dem"), self.p("fac"), self.px,
+                                            self.n_top, self.p("slope"), None, self.p("ti"), self.p("mti")))
+        t = self.t
+        self._chk(self.L.dt_dev_gfi_lnhlh(self.ctx.h, t["hand"].data_ptr(), t["a_river"].data_ptr(),
+                                          t["fac"].data_ptr(), n, self.n_gfi, self.b, self.px,
+                                          t["gfi"].data_ptr(), t["lnhlh"].data_ptr()))
+        self._chk(self.L.dt_dev_downslope_w(self.ctx.h, C.byref(self.win), self.p("dem"), self.p("fdr"), self.px,
+                                            self.dz, 0, self.p("down"), self.n_unres.data_ptr()))
+
+    def unresolved_downslope(self):
+        self.ctx.sync()
+        return int(self.n_unres.item())
+
+    def host(self, name):
+        self.ctx.sync()
+        return self.core(name).cpu().numpy()
+
+
+# ---------------------------------------------------------------------------------------------------
+# communicators
+# ---------------------------------------------------------------------------------------------------
+def _pad_rows(arrs, pmax):
+    """concatenate 1-D tensors of different dtypes into one byte row of fixed length (for all_gather)."""
+    import torch
+    rows = []
+    for a in arrs:
+        b = a.contiguous().view(torch.uint8).reshape(-1)
+        pad = pmax * a.element_size() - b.numel()
+        rows.append(torch.cat([b, torch.zeros(pad, dtype=torch.uint8, device=b.device)]) if pad else b)
+    return torch.cat(rows)
+
+
+def all_gather_summaries(arrs, layout, rank, group=None):
+    """all-gather a tuple of per-ring-cell tensors (one row per ring cell) across ranks with
+    torch.distributed (RCCL on GPUs, gloo on CPU).  Returns summaries[r] = tuple of numpy arrays."""
+    import torch
+    import torch.distributed as dist
+    P = [perim_count(*layout.shape(r)) for r in range(layout.size)]
+    pmax = max(P)
+    row = _pad_rows(arrs, pmax)
+    out = torch.empty((layout.size, row.numel()), dtype=torch.uint8, device=row.device)
+    dist.all_gather_into_tensor(out, row, group=group)
+    host = out.cpu().numpy()
+    res = []
+    for r in range(layout.size):
+        o, items = 0, []
+        for a in arrs:
+            es = a.element_size()
+            np_dt = np.dtype(str(a.dtype).replace("torch.", ""))
+            items.append(host[r, o:o + P[r] * es].copy().view(np_dt))
+            o += pmax * es
+        res.append(tuple(items))
+    return res
+
+
+def run_rank(tile, layout, gather):
+    """the chain of one rank; `gather(tuple_of_tensors) -> summaries of all ranks` is the only
+    communication (two calls)."""
+    tile.d8()
+    fa = tile.fa_local()
+    ext = solve_flowacc(layout, gather(fa))
+    tile.fa_finish(ext[tile.rank])
+    codes = tile.torch.as_tensor(tile.ring_codes(), device=tile.dev)
+    fh = tile.fh_local()
+    allfh = gather(fh + (codes,))
+    res = solve_flowhand(layout, [s[:6] for s in allfh], [s[6] for s in allfh])
+    tile.fh_finish(res[tile.rank])
+    tile.pointwise()
+
+
+def simulate(tiles, layout):
+    """N logical ranks on ONE device, lock-step, with the all-gathers replaced by list collection:
+    what proves tiled == untiled without a multi-GPU node."""
+    for t in tiles:
+        t.d8()
+    fa = [tuple(a.cpu().numpy() for a in t.fa_local()) for t in tiles]
+    ext = solve_flowacc(layout, fa)
+    for t in tiles:
+        t.fa_finish(ext[t.rank])
+    codes = [t.ring_codes() for t in tiles]
+    fh = [tuple(a.cpu().numpy() for a in t.fh_local()) for t in tiles]
+    res = solve_flowhand(layout, fh, codes)
+    for t in tiles:
+        t.fh_finish(res[t.rank])
+        t.pointwise()

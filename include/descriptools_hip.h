@@ -148,7 +148,8 @@ int dt_dev_flowacc_river(dt_ctx *ctx, const uint8_t *fdr, const float *dem, int6
 int dt_dev_river_mask(dt_ctx *ctx, const int32_t *acc32, int64_t N, int64_t threshold,
                       int8_t *river);
 /* idx32: local flat index of the drained-to river cell (int32), -100 = none; a_river (may be
- * NULL, needs acc32) = acc32[idx] carried as payload (removes gfi.river_accumulation's gather) */
+ * NULL, needs acc32) = acc32[idx] carried as payload (removes gfi.river_accumulation's gather;
+ * -100 where there is no river cell, i.e. where hand is -100 and GFI is -100 whatever the area) */
 int dt_dev_flowhand(dt_ctx *ctx, const float *dem, const uint8_t *fdr, const int8_t *river,
                     const int32_t *acc32, int64_t H, int64_t W, double px, float *fdist,
                     int32_t *idx32, float *hand, int32_t *a_river);

@@ -1,0 +1,84 @@
+"""GPU (-m gpu): the multi-rank tiling run as N logical ranks on ONE device (the all-gathers replaced by
+list collection, everything else identical to the torch.distributed path) must reproduce the untiled
+single-GPU chain bit for bit -- the contract "tiled == untiled" (SURVEY.md 5 / 8e)."""
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ["fdr", "fac", "river", "fdist", "hand", "a_river", "slope", "ti", "mti", "gfi", "lnhlh", "down"]
+
+
+def _global_dem(seed, Hg, Wg, nod):
+    return oracle.synth_dem(seed, 2048, 2048, 300, 200, Hg, Wg, nod)
+
+
+@pytest.mark.parametrize("heights,widths,nod,seed", [
+    ([192, 192], [256, 256], 0, 1),        # 2 x 2
+    ([384], [192, 320], 3, 2),             # 1 x 2, uneven, nodata blobs
+    ([128, 256], [512], 0, 3),             # 2 x 1
+    ([192, 130], [256, 200], 2, 6),        # 2 x 2, ragged last row / column
+    ([128, 128, 128], [128, 256, 128], 2, 4),  # 3 x 3
+    ([384], [512], 0, 5),                  # 1 x 1 through the windowed entry points
+])
+def test_tiled_equals_untiled(heights, widths, nod, seed):
+    from descriptools_amd import chain, tiling
+    layout = tiling.Layout(heights, widths)
+    Hg, Wg = layout.Hg, layout.Wg
+    dem = _global_dem(seed, Hg, Wg, nod)
+    px, thr = 10.0, (Hg * Wg) // 512
+    ref = chain.run_host(dem, px, river_threshold=thr)
+    h = tiling.HALO
+    pad = np.full((Hg + 2 * h, Wg + 2 * h), np.nan, np.float32)  # NaN = must never be read
+    pad[h:h + Hg, h:h + Wg] = dem
+    tiles = []
+    for r in range(layout.size):
+        t = tiling.RankTile(layout, r, device=0, px=px, river_threshold=thr)
+        y0, x0 = layout.origin(r)
+        t.set_dem_ext(pad[y0:y0 + t.He, x0:x0 + t.We])
+        tiles.append(t)
+    tiling.simulate(tiles, layout)
+    for t in tiles:
+        assert t.unresolved_downslope() == 0
+        y0, x0 = layout.origin(t.rank)
+        sl = (slice(y0, y0 + t.H), slice(x0, x0 + t.W))
+        for name in NAMES:
+            got, want = t.host(name), ref[name][sl]
+            assert np.array_equal(got, want.astype(got.dtype), equal_nan=True), \
+                "rank %d %s: %d cells differ" % (t.rank, name, int((got != want).sum()))
+        # river index: global flat index of the untiled run
+        assert np.array_equal(t.host("idx"), ref["idx"][sl])
+
+
+def test_tiled_flowacc_cycles_across_ranks():
+    """arbitrary direction field (cycles inside tiles, across tiles and across ranks): the tiled
+    flow accumulation equals the oracle's."""
+    from descriptools_amd import tiling
+    import torch
+    rng = np.random.default_rng(11)
+    layout = tiling.Layout([128, 128], [128, 64, 64])
+    Hg, Wg = layout.Hg, layout.Wg
+    codes = np.array([1, 2, 4, 8, 16, 32, 64, 128], np.uint8)
+    fdr = codes[rng.integers(0, 8, size=(Hg, Wg))]
+    fdr[rng.random((Hg, Wg)) < 0.3] = 4
+    ref = oracle.flowacc(fdr)
+    h = tiling.HALO
+    pad = np.zeros((Hg + 2 * h, Wg + 2 * h), np.uint8)
+    pad[h:h + Hg, h:h + Wg] = fdr
+    tiles = []
+    for r in range(layout.size):
+        t = tiling.RankTile(layout, r, device=0, river_threshold=10)
+        y0, x0 = layout.origin(r)
+        t.t["fdr"].copy_(torch.as_tensor(pad[y0:y0 + t.He, x0:x0 + t.We]))
+        t.t["dem"].fill_(1.0)
+        tiles.append(t)
+    fa = [tuple(a.cpu().numpy() for a in t.fa_local()) for t in tiles]
+    ext = tiling.solve_flowacc(layout, fa)
+    for t in tiles:
+        t.fa_finish(ext[t.rank])
+        y0, x0 = layout.origin(t.rank)
+        got = t.host("fac")
+        want = ref[y0:y0 + t.H, x0:x0 + t.W]
+        assert np.array_equal(got, want), "rank %d: %d cells differ" % (t.rank, int((got != want).sum()))
