@@ -41,6 +41,10 @@ def main():
     ap.add_argument("--size", type=int, default=16384, help="tile edge per GPU")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tiled", action="store_true", help="N = 1 through the multi-rank path (1 x 1 layout): "
+                                                         "measures what the tiling machinery costs")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; default) or gloo (rehearsal of N > 1 "
+                                                        "with several ranks sharing one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -51,7 +55,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "gloo":
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -59,6 +67,9 @@ def main():
     from descriptools_amd import _lib, chain
     from descriptools_amd.device import Context
     L = _lib.lib()
+
+    if world > 1 or args.tiled:
+        return main_tiled(args, torch, dist, world, rank, local_rank, dev)
 
     S = args.size
     H = W = S
@@ -173,6 +184,70 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.seed)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def main_tiled(args, torch, dist, world, rank, local_rank, dev):
+    """N > 1: one S x S core tile per rank of a (ty*S) x (tx*S) DEM; halo generated locally from the
+    global generator; two RCCL all-gathers of ring summaries per step (flow accumulation, HAND)."""
+    from descriptools_amd import chain, tiling
+    S = args.size
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    layout = tiling.Layout.uniform(world, S, S)
+    tile = tiling.RankTile(layout, rank, device=local_rank, stream=stream.cuda_stream, px=10.0,
+                           river_threshold=(layout.Hg * layout.Wg) // 512)
+    tile.synth_dem(args.seed)
+
+    def gather(arrs):
+        if world == 1:
+            return [tuple(a.cpu().numpy() for a in arrs)]
+        return tiling.all_gather_summaries(arrs, layout, rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    cpu_red = world > 1 and dist.get_backend() == "gloo"
+
+    for _ in range(args.warmup):
+        tiling.run_rank(tile, layout, gather)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tiling.run_rank(tile, layout, gather)
+    barrier()
+    dt = time.perf_counter() - t0
+    unres = torch.tensor([tile.unresolved_downslope()], dtype=torch.int64, device="cpu" if cpu_red else dev)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if cpu_red else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        dist.all_reduce(unres)
+    cells = S * S * world
+    out = {
+        "metric": "Mcells/s full descriptor chain", "value": round(cells * args.steps / dt / 1e6, 1),
+        "unit": "Mcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%dx%d synthetic tilted-integer-fBm DEM per GPU, full chain, device-resident"
+                               % (S, S),
+                   "global_dem": "%dx%d" % (layout.Hg, layout.Wg), "px": 10.0,
+                   "river_threshold_cells": tile.river_threshold,
+                   "parallelism": "%dx%d rank tiles, 64-cell halo, 2 RCCL all-gathers of ring summaries per "
+                                  "step (flow accumulation inflow, HAND rank exits)" % (layout.ty, layout.tx)},
+        "roofline": {"bound": "hbm", "achieved": round(cells * args.steps * chain.ALGO_BYTES_PER_CELL / dt / 1e9
+                                                        / world, 1),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(cells * args.steps * chain.ALGO_BYTES_PER_CELL / dt / 1e9 / world
+                                   / HBM_PEAK_GBS, 4),
+                     "traffic": None, "kernel": "whole chain, per GPU (per-kernel figures: N = 1 run)"},
+        "downslope_walks_beyond_halo": int(unres.item()),
+    }
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

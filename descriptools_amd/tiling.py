@@ -411,9 +411,11 @@ def all_gather_summaries(arrs, layout, rank, group=None):
     P = [perim_count(*layout.shape(r)) for r in range(layout.size)]
     pmax = max(P)
     row = _pad_rows(arrs, pmax)
-    out = torch.empty((layout.size, row.numel()), dtype=torch.uint8, device=row.device)
+    if dist.get_backend(group) == "gloo":  # CPU rehearsal of the RCCL path
+        row = row.cpu()
+    out = torch.empty(layout.size * row.numel(), dtype=torch.uint8, device=row.device)
     dist.all_gather_into_tensor(out, row, group=group)
-    host = out.cpu().numpy()
+    host = out.cpu().numpy().reshape(layout.size, row.numel())
     res = []
     for r in range(layout.size):
         o, items = 0, []
