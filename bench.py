@@ -202,10 +202,7 @@ def main_tiled(args, torch, dist, world, rank, local_rank, dev):
                            river_threshold=(layout.Hg * layout.Wg) // 512)
     tile.synth_dem(args.seed)
 
-    def gather(arrs):
-        if world == 1:
-            return [tuple(a.cpu().numpy() for a in arrs)]
-        return tiling.all_gather_summaries(arrs, layout, rank)
+    exchange = tiling.Exchange(tile, layout, world)
 
     def barrier():
         if world > 1:
@@ -215,11 +212,11 @@ def main_tiled(args, torch, dist, world, rank, local_rank, dev):
     cpu_red = world > 1 and dist.get_backend() == "gloo"
 
     for _ in range(args.warmup):
-        tiling.run_rank(tile, layout, gather)
+        tiling.run_rank(tile, layout, exchange)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        tiling.run_rank(tile, layout, gather)
+        tiling.run_rank(tile, layout, exchange)
     barrier()
     dt = time.perf_counter() - t0
     unres = torch.tensor([tile.unresolved_downslope()], dtype=torch.int64, device="cpu" if cpu_red else dev)

@@ -168,10 +168,9 @@ def solve_flowacc(layout, summaries, max_iter=4096):
     changed = np.zeros(n, bool)
     ext = np.zeros(n, np.int64)
     for _ in range(max_iter):
-        ext = np.zeros(n, np.int64)
-        np.add.at(ext, T, total[E])
-        recv = np.zeros(n, np.int64)
-        np.add.at(recv, xr_node[has], ext[has])
+        # integer scatter-adds via bincount (float64 weights are exact below 2^53)
+        ext = np.bincount(T, weights=total[E].astype(np.float64), minlength=n).astype(np.int64)
+        recv = np.bincount(xr_node[has], weights=ext[has].astype(np.float64), minlength=n).astype(np.int64)
         new = a_local + recv
         changed = new != total
         total = new
@@ -322,18 +321,23 @@ class RankTile:
         fdr = self.t["fdr"].data_ptr() + off
         self._chk(self.L.dt_dev_slope_d8_w(self.ctx.h, C.byref(win), dem, self.px, None, fdr, None))
 
+    def ring_codes_dev(self):
+        """D8 codes of the ring cells (device tensor, no synchronisation)."""
+        return self.t["fdr"].reshape(-1)[self._ring_lin]
+
     def ring_codes(self):
         self.ctx.sync()
-        return self.t["fdr"].reshape(-1)[self._ring_lin].cpu().numpy()
+        return self.ring_codes_dev().cpu().numpy()
 
-    def fa_local(self):
+    def fa_local(self, sync=True):
         tc = self.torch
         A = tc.empty(self.P, dtype=tc.int64, device=self.dev)
         xr = tc.empty(self.P, dtype=tc.int32, device=self.dev)
         code = tc.empty(self.P, dtype=tc.uint8, device=self.dev)
         self._chk(self.L.dt_dev_flowacc_local_w(self.ctx.h, C.byref(self.win), self.p("fdr"), self.p("fac"),
                                                 A.data_ptr(), xr.data_ptr(), code.data_ptr()))
-        self.ctx.sync()
+        if sync:
+            self.ctx.sync()
         return A, xr, code
 
     def fa_finish(self, ext):
@@ -344,7 +348,7 @@ class RankTile:
                                                  e.data_ptr() if e is not None else None,
                                                  self.river_threshold, self.p("fac"), self.p("river")))
 
-    def fh_local(self):
+    def fh_local(self, sync=True):
         tc = self.torch
         kind = tc.empty(self.P, dtype=tc.uint8, device=self.dev)
         ref, nc, nd, ar = (tc.empty(self.P, dtype=tc.int32, device=self.dev) for _ in range(4))
@@ -353,7 +357,8 @@ class RankTile:
                                                  self.p("river"), self.p("fac"), kind.data_ptr(),
                                                  ref.data_ptr(), nc.data_ptr(), nd.data_ptr(), zr.data_ptr(),
                                                  ar.data_ptr()))
-        self.ctx.sync()
+        if sync:
+            self.ctx.sync()
         return kind, ref, nc, nd, zr, ar
 
     def fh_finish(self, res):
@@ -367,18 +372,27 @@ class RankTile:
                                                   ptrs[2], ptrs[3], ptrs[4], ptrs[5], self.p("fdist"), None,
                                                   self.p("idx"), self.p("hand"), self.p("a_river")))
 
-    def pointwise(self):
-        """fused slope+TI+MTI on the core window, GFI+ln(hl/H) over the flat extended rasters (halo cells
-        are computed on garbage and never read), downslope on the core window."""
-        n = self.He * self.We
+    def slope_twi(self):
+        """fused slope + TI + MTI on the core window (needs fac)."""
         self._chk(self.L.dt_dev_slope_twi_w(self.ctx.h, C.byref(self.win), self.p("dem"), self.p("fac"), self.px,
                                             self.n_top, self.p("slope"), None, self.p("ti"), self.p("mti")))
-        t = self.t
+
+    def gfi(self):
+        """GFI + ln(hl/H) over the flat extended rasters (halo cells hold zeros and are never read back)."""
+        t, n = self.t, self.He * self.We
         self._chk(self.L.dt_dev_gfi_lnhlh(self.ctx.h, t["hand"].data_ptr(), t["a_river"].data_ptr(),
                                           t["fac"].data_ptr(), n, self.n_gfi, self.b, self.px,
                                           t["gfi"].data_ptr(), t["lnhlh"].data_ptr()))
+
+    def downslope(self):
+        """downslope on the core window (needs only dem + fdr: independent of the exchanges)."""
         self._chk(self.L.dt_dev_downslope_w(self.ctx.h, C.byref(self.win), self.p("dem"), self.p("fdr"), self.px,
                                             self.dz, 0, self.p("down"), self.n_unres.data_ptr()))
+
+    def pointwise(self):
+        self.slope_twi()
+        self.gfi()
+        self.downslope()
 
     def unresolved_downslope(self):
         self.ctx.sync()
@@ -428,19 +442,56 @@ def all_gather_summaries(arrs, layout, rank, group=None):
     return res
 
 
-def run_rank(tile, layout, gather):
-    """the chain of one rank; `gather(tuple_of_tensors) -> summaries of all ranks` is the only
-    communication (two calls)."""
+class Exchange:
+    """The two all-gathers of a step, issued on a SIDE stream behind an event, so that kernels queued
+    on the main stream after the summaries keep the GPU busy while the ring rows travel (RCCL) and
+    the rank-level graph is solved on the host."""
+
+    def __init__(self, tile, layout, world, group=None):
+        self.tile, self.layout, self.world, self.group = tile, layout, world, group
+        self.torch = tile.torch
+        self.side = self.torch.cuda.Stream(device=tile.dev)
+
+    def gather_after(self, event, arrs):
+        tc = self.torch
+        with tc.cuda.stream(self.side):
+            self.side.wait_event(event)
+            for a in arrs:
+                a.record_stream(self.side)
+            if self.world == 1:
+                host = [a.to("cpu", non_blocking=True) for a in arrs]
+                self.side.synchronize()
+                return [tuple(h.numpy() for h in host)]
+            out = all_gather_summaries(arrs, self.layout, self.tile.rank, self.group)
+            self.side.synchronize()
+        return out
+
+
+def run_rank(tile, layout, exchange):
+    """One step of one rank.  `exchange.gather(tensors)` is the only communication (two calls); the
+    independent kernels (downslope; slope+TI+MTI) are queued BEFORE each wait so they overlap it."""
     tile.d8()
-    fa = tile.fa_local()
-    ext = solve_flowacc(layout, gather(fa))
+    fa = tile.fa_local(sync=False)
+    codes = tile.ring_codes_dev()
+    ev_arrs = fa + (codes,)
+    # queue work that does not depend on the exchange, then wait for the ring rows
+    import torch
+    main = torch.cuda.current_stream(tile.dev)
+    ev = torch.cuda.Event()
+    ev.record(main)
+    tile.downslope()
+    allfa = exchange.gather_after(ev, ev_arrs)
+    ext = solve_flowacc(layout, [s[:3] for s in allfa])
+    ring_codes = [s[3] for s in allfa]
     tile.fa_finish(ext[tile.rank])
-    codes = tile.torch.as_tensor(tile.ring_codes(), device=tile.dev)
-    fh = tile.fh_local()
-    allfh = gather(fh + (codes,))
-    res = solve_flowhand(layout, [s[:6] for s in allfh], [s[6] for s in allfh])
+    fh = tile.fh_local(sync=False)
+    ev2 = torch.cuda.Event()
+    ev2.record(main)
+    tile.slope_twi()
+    allfh = exchange.gather_after(ev2, fh)
+    res = solve_flowhand(layout, allfh, ring_codes)
     tile.fh_finish(res[tile.rank])
-    tile.pointwise()
+    tile.gfi()
 
 
 def simulate(tiles, layout):
