@@ -6,6 +6,33 @@
 
 #include "dt_common.h"
 #include "dt_kernels.h"
+#include "dt_math.h"
+
+// ---- float64 math tables (dt_math.h) -------------------------------------------------------------
+void dt_math_host_table(DtLogEntry *tab) {
+  for (int i = 0; i < DT_LOGTAB_N; i++) {
+    double c = 1.0 + (i + 0.5) / DT_LOGTAB_N;
+    double rc = 1.0 / c;
+    tab[i].rc = rc;
+    tab[i].lnc = (double)(-logl((long double)rc));
+  }
+}
+__device__ DtLogEntry g_logtab[DT_LOGTAB_N];
+const DtLogEntry *dt_math_device_table(hipStream_t s) {
+  static thread_local int uploaded_dev = -1;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  DtLogEntry *p = nullptr;
+  (void)hipGetSymbolAddress((void **)&p, HIP_SYMBOL(g_logtab));
+  if (uploaded_dev != dev) {
+    static DtLogEntry host[DT_LOGTAB_N];
+    dt_math_host_table(host);
+    (void)hipMemcpyAsync(p, host, sizeof(host), hipMemcpyHostToDevice, s);
+    (void)hipStreamSynchronize(s);
+    uploaded_dev = dev;
+  }
+  return p;
+}
 
 // ===========================================================================================
 // Synthetic DEM ("tilted integer fBm") -- integer arithmetic identical to
@@ -155,14 +182,14 @@ __device__ __forceinline__ SlopeCell dt_slope_cell(float c, float nw, float n, f
 // rounding except at rounding ties; NaN / inf cases propagate identically: ln of a negative A or t
 // is NaN like pow / log of it).  lnpx2 = ln(px^2) is computed once on the host.
 __device__ __forceinline__ void dt_twi_cell(int64_t fac, float srad, double lnpx2, double n, float &ti,
-                                            float &mti) {
+                                            float &mti, const DtLogEntry *s_tab) {
   if (fac <= -100) {
     ti = DT_NODATA;
     mti = DT_NODATA;
     return;
   }
-  double la = (fac == 0 ? 0.0 : log((double)fac)) + lnpx2;
-  double lt = log(tan((double)srad + 0.01));
+  double la = (fac == 0 ? 0.0 : dt_fast_log((double)fac, s_tab)) + lnpx2;
+  double lt = dt_fast_lntan((double)srad + 0.01, s_tab);
   ti = (float)(la - lt);
   mti = (float)(n * la - lt);
 }
@@ -172,7 +199,7 @@ __device__ __forceinline__ void dt_twi_cell(int64_t fac, float srad, double lnpx
 __device__ __forceinline__ float dt_slope_rad(float slope_pct, float dem) {
   if (dem == DT_NODATA) return DT_NODATA;
   float q = slope_pct / 100.0f;
-  return (float)atan((double)q);
+  return (float)dt_fast_atan((double)q);
 }
 
 template <bool W_SLOPE, bool W_FDR, bool W_RAD, bool W_TWI>
@@ -183,8 +210,10 @@ __global__ __launch_bounds__(256) void k_stencil(const float *__restrict__ dem, 
                                                 const int32_t *__restrict__ acc32, double n_top,
                                                 double lnpx2, float *__restrict__ ti,
                                                 float *__restrict__ mti, int tiles_x, int tiles_y,
-                                                int vec_ok) {
+                                                int vec_ok, const DtLogEntry *__restrict__ g_tab) {
   __shared__ __attribute__((aligned(16))) float t[(SD_TY + 2) * SD_LDW];
+  __shared__ DtLogEntry s_tab[W_TWI ? DT_LOGTAB_N : 1];
+  if (W_TWI) dt_math_stage(g_tab, s_tab);
 
   // XCD-aware tile mapping: workgroup id b runs on XCD group (b % 8); give each group a band
   // of tile rows and walk it row-major.
@@ -280,7 +309,7 @@ __global__ __launch_bounds__(256) void k_stencil(const float *__restrict__ dem, 
         if (W_TWI) {
           int xx = gx + k;
           int64_t f = xx < W ? (int64_t)acc32[(long long)gy * w.ld + xx] : -100;
-          dt_twi_cell(f, ro[k], lnpx2, n_top, tio[k], mtio[k]);
+          dt_twi_cell(f, ro[k], lnpx2, n_top, tio[k], mtio[k], s_tab);
         }
       }
       long long o = (long long)gy * w.ld + gx;
@@ -330,9 +359,10 @@ int dt_launch_stencil(hipStream_t s, const DtWin &w, const float *dem, double px
                (!mti || ((uintptr_t)mti & 15) == 0) && (!fdr || ((uintptr_t)fdr & 3) == 0);
   dim3 g((unsigned)ntiles), b(256);
   bool ws = slope != nullptr, wf = fdr != nullptr, wr = slope_rad != nullptr, wt = ti != nullptr;
+  const DtLogEntry *g_tab = wt ? dt_math_device_table(s) : nullptr;
 #define DT_GO(S, F, R, T)                                                                          \
   hipLaunchKernelGGL((k_stencil<S, F, R, T>), g, b, 0, s, dem, w, px, slope, fdr,                  \
-                     slope_rad, acc32, n_top, log(px * px), ti, mti, tiles_x, tiles_y, vec_ok)
+                     slope_rad, acc32, n_top, log(px * px), ti, mti, tiles_x, tiles_y, vec_ok, g_tab)
   if (wt) {
     DT_REQUIRE(acc32 && mti, "fused TWI needs acc32, ti and mti");
     if (ws && wr) DT_GO(true, false, true, true);
@@ -566,11 +596,14 @@ template <typename IT>
 __global__ __launch_bounds__(256) void k_twi(const IT *__restrict__ acc32,
                                             const float *__restrict__ srad, int64_t n, double px2,
                                             double n_top, float *__restrict__ ti,
-                                            float *__restrict__ mti) {
+                                            float *__restrict__ mti, const DtLogEntry *__restrict__ g_tab) {
+  __shared__ DtLogEntry s_tab[DT_LOGTAB_N];
+  dt_math_stage(g_tab, s_tab);
+  __syncthreads();
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   float a, b;
-  dt_twi_cell((int64_t)acc32[i], srad[i], px2, n_top, a, b);
+  dt_twi_cell((int64_t)acc32[i], srad[i], px2, n_top, a, b, s_tab);
   ti[i] = a;
   mti[i] = b;
 }
@@ -578,14 +611,14 @@ int dt_launch_twi(hipStream_t s, const int32_t *acc32, const float *srad, int64_
                   double n_top, float *ti, float *mti) {
   if (n == 0) return DT_OK;
   hipLaunchKernelGGL(k_twi<int32_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, acc32, srad, n,
-                     log(px * px), n_top, ti, mti);
+                     log(px * px), n_top, ti, mti, dt_math_device_table(s));
   return DT_OK;
 }
 int dt_launch_twi_i64(hipStream_t s, const int64_t *fac, const float *srad, int64_t n, double px,
                       double n_top, float *ti, float *mti) {
   if (n == 0) return DT_OK;
   hipLaunchKernelGGL(k_twi<int64_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, fac, srad, n,
-                     log(px * px), n_top, ti, mti);
+                     log(px * px), n_top, ti, mti, dt_math_device_table(s));
   return DT_OK;
 }
 
@@ -596,7 +629,11 @@ int dt_launch_twi_i64(hipStream_t s, const int64_t *fac, const float *srad, int6
 template <bool OWN_CELL, typename IT>
 __global__ __launch_bounds__(256) void k_gfi(const float *__restrict__ hand,
                                             const IT *__restrict__ area, int64_t n, double expo,
-                                            double c0, float *__restrict__ out) {
+                                            double c0, float *__restrict__ out,
+                                            const DtLogEntry *__restrict__ g_tab) {
+  __shared__ DtLogEntry s_tab[DT_LOGTAB_N];
+  dt_math_stage(g_tab, s_tab);
+  __syncthreads();
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   float h = hand[i];
@@ -605,8 +642,8 @@ __global__ __launch_bounds__(256) void k_gfi(const float *__restrict__ hand,
     return;
   }
   IT ar = area[i];
-  double la = (OWN_CELL && ar == 0) ? 0.0 : log((double)ar);
-  out[i] = (float)(c0 + expo * la - log((double)h + 0.01));
+  double la = (OWN_CELL && ar == 0) ? 0.0 : dt_fast_log((double)ar, s_tab);
+  out[i] = (float)(c0 + expo * la - dt_fast_log((double)h + 0.01, s_tab));
 }
 // GFI and ln(hl/H) in one pass: hand is read once and ln(h + 0.01) evaluated once (3 logs / cell
 // instead of 4, 12 + 4 bytes / cell instead of 24)
@@ -614,7 +651,11 @@ __global__ __launch_bounds__(256) void k_gfi_both(const float *__restrict__ hand
                                                  const int32_t *__restrict__ a_river,
                                                  const int32_t *__restrict__ fac, int64_t n, double expo,
                                                  double c0, float *__restrict__ gfi,
-                                                 float *__restrict__ lnhlh) {
+                                                 float *__restrict__ lnhlh,
+                                                 const DtLogEntry *__restrict__ g_tab) {
+  __shared__ DtLogEntry s_tab[DT_LOGTAB_N];
+  dt_math_stage(g_tab, s_tab);
+  __syncthreads();
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   float h = hand[i];
@@ -623,16 +664,16 @@ __global__ __launch_bounds__(256) void k_gfi_both(const float *__restrict__ hand
     lnhlh[i] = DT_NODATA;
     return;
   }
-  double lh = c0 - log((double)h + 0.01);
+  double lh = c0 - dt_fast_log((double)h + 0.01, s_tab);
   int32_t f = fac[i];
-  gfi[i] = (float)(lh + expo * log((double)a_river[i]));
-  lnhlh[i] = (float)(lh + (f == 0 ? 0.0 : expo * log((double)f)));
+  gfi[i] = (float)(lh + expo * dt_fast_log((double)a_river[i], s_tab));
+  lnhlh[i] = (float)(lh + (f == 0 ? 0.0 : expo * dt_fast_log((double)f, s_tab)));
 }
 int dt_launch_gfi_both(hipStream_t s, const float *hand, const int32_t *a_river, const int32_t *fac,
                        int64_t n, double expo, double b, double size, float *gfi, float *lnhlh) {
   if (n == 0) return DT_OK;
   hipLaunchKernelGGL(k_gfi_both, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, hand, a_river, fac, n,
-                     expo, log(b) + expo * log(size * size), gfi, lnhlh);
+                     expo, log(b) + expo * log(size * size), gfi, lnhlh, dt_math_device_table(s));
   return DT_OK;
 }
 
@@ -640,16 +681,16 @@ int dt_launch_gfi(hipStream_t s, const float *hand, const int32_t *area, int64_t
                   double b, double size, float *out, int own_cell) {
   if (n == 0) return DT_OK;
   dim3 g((unsigned)((n + 255) / 256)), bl(256);
-  if (own_cell) hipLaunchKernelGGL((k_gfi<true, int32_t>), g, bl, 0, s, hand, area, n, expo, log(b) + expo * log(size * size), out);
-  else hipLaunchKernelGGL((k_gfi<false, int32_t>), g, bl, 0, s, hand, area, n, expo, log(b) + expo * log(size * size), out);
+  if (own_cell) hipLaunchKernelGGL((k_gfi<true, int32_t>), g, bl, 0, s, hand, area, n, expo, log(b) + expo * log(size * size), out, dt_math_device_table(s));
+  else hipLaunchKernelGGL((k_gfi<false, int32_t>), g, bl, 0, s, hand, area, n, expo, log(b) + expo * log(size * size), out, dt_math_device_table(s));
   return DT_OK;
 }
 int dt_launch_gfi_i64(hipStream_t s, const float *hand, const int64_t *area, int64_t n, double expo,
                       double b, double size, float *out, int own_cell) {
   if (n == 0) return DT_OK;
   dim3 g((unsigned)((n + 255) / 256)), bl(256);
-  if (own_cell) hipLaunchKernelGGL((k_gfi<true, int64_t>), g, bl, 0, s, hand, area, n, expo, log(b) + expo * log(size * size), out);
-  else hipLaunchKernelGGL((k_gfi<false, int64_t>), g, bl, 0, s, hand, area, n, expo, log(b) + expo * log(size * size), out);
+  if (own_cell) hipLaunchKernelGGL((k_gfi<true, int64_t>), g, bl, 0, s, hand, area, n, expo, log(b) + expo * log(size * size), out, dt_math_device_table(s));
+  else hipLaunchKernelGGL((k_gfi<false, int64_t>), g, bl, 0, s, hand, area, n, expo, log(b) + expo * log(size * size), out, dt_math_device_table(s));
   return DT_OK;
 }
 // gfi.river_accumulation (gfi.py:119-147): A_r = fac.flat[idx] where idx != -100 else fac.flat[0]
@@ -723,7 +764,7 @@ __global__ __launch_bounds__(256) void k_downslope(const float *__restrict__ dem
 #define MW_RING 0x1000u
 #define MW_STOP (MW_BADCODE | MW_EDGE | MW_RING)
 
-__global__ __launch_bounds__(1024) void k_downslope_win(const float *__restrict__ dem,
+__global__ __launch_bounds__(1024, 8) void k_downslope_win(const float *__restrict__ dem,
                                                        const uint8_t *__restrict__ fdr, DtWin w,
                                                        double px, double dz, float dzf, int raw,
                                                        float *__restrict__ out, int tiles_x, int ntiles,
@@ -739,15 +780,19 @@ __global__ __launch_bounds__(1024) void k_downslope_win(const float *__restrict_
   const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
   const int wy0 = tyi * DW_CORE - DW_M, wx0 = txi * DW_CORE - DW_M;
   const bool vec = (w.ld % 4 == 0) && (((uintptr_t)dem & 15) == 0) && (((uintptr_t)fdr & 3) == 0);
+  // readable cells (inside the global raster and in memory): rows [ya, yb), columns [xa, xb)
+  const int ya = max(-w.halo, -w.gy0), yb = min(w.H + w.halo, w.Hg - w.gy0);
+  const int xa = max(-w.halo, -w.gx0), xb = min(w.W + w.halo, w.Wg - w.gx0);
   // 112 rows x 28 groups of 4 cells (wx0 is a multiple of 8: float4 / uchar4 stay aligned)
   for (int i = threadIdx.x; i < DW_WIN * (DW_WIN / 4); i += 1024) {
     int r = i / (DW_WIN / 4), c4 = (i - r * (DW_WIN / 4)) * 4;
     int gy = wy0 + r, gx = wx0 + c4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     uint32_t codes = 0;
+    const bool row_ok = gy >= ya && gy < yb;
     bool rd[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) rd[k] = dt_readable(w, gy, gx + k);
+    for (int k = 0; k < 4; k++) rd[k] = row_ok && gx + k >= xa && gx + k < xb;
     if (vec && rd[0] && rd[3]) {
       v = *reinterpret_cast<const float4 *>(dem + (long long)gy * w.ld + gx);
       codes = *reinterpret_cast<const uint32_t *>(fdr + (long long)gy * w.ld + gx);
@@ -773,7 +818,8 @@ __global__ __launch_bounds__(1024) void k_downslope_win(const float *__restrict_
         dt_d8_delta(code, dy, dx);
         mw = (uint32_t)(dy * DW_WIN + dx + 256);
         if (dy != 0 && dx != 0) mw |= MW_DIAG;
-        if (!dt_in_global(w, gy + dy, gx + k + dx)) mw |= MW_EDGE;
+        int ny = w.gy0 + gy + dy, nx = w.gx0 + gx + k + dx;
+        if (ny < 0 || ny >= w.Hg || nx < 0 || nx >= w.Wg) mw |= MW_EDGE;
       }
       // ring of the window, or the edge of what is in memory: hand over to the global walk
       if (r == 0 || r == DW_WIN - 1 || rx == 0 || rx == DW_WIN - 1 || !rd[k]) mw |= MW_RING;

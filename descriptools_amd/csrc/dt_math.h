@@ -1,0 +1,93 @@
+// dt_math.h -- float64 ln / ln(tan) / atan for the descriptor kernels, ~3-4x fewer instructions than the
+// device library's log / tan / pow / atan while staying far inside what the float32 outputs can
+// resolve (the reference rounds ONE float64 expression to float32; a float64 error of 1e-13 moves
+// that rounding in ~1 cell per 10^6, and by one float32 ulp).
+//
+//   dt_fast_log(x)    x = m * 2^e;  128-entry table on the top 7 mantissa bits: ln m = ln c_i +
+//                     ln(1 + u), u = m / c_i - 1, |u| <= 2^-8, degree-5 series.  rel. error ~2e-16.
+//   dt_fast_lntan(y)  y in (0, pi/2): ln tan y = +-(ln z + g(z^2)), z = min(y, pi/2 - y),
+//                     g = degree-10 polynomial (dt_math_coeffs.h), abs error ~6e-14.
+//   dt_fast_atan(q)   q >= 0: one division into [0, tan(pi/8)], degree-7 polynomial, abs error ~1e-12.
+// Arguments outside those domains (negative / NaN / inf / subnormal) take the device library's
+// functions, so NaN and inf propagate exactly as before.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "dt_math_coeffs.h"
+
+#define DT_LOGTAB_N 128
+struct DtLogEntry {
+  double rc;   // ~ 1 / c_i,  c_i = 1 + (i + 0.5) / 128
+  double lnc;  // -ln(rc)
+};
+
+// fills `tab` (host) -- uploaded once per process by dt_capi.hip
+void dt_math_host_table(DtLogEntry *tab);
+// device copy of the table (global memory); kernels stage it into LDS with dt_math_stage()
+const DtLogEntry *dt_math_device_table(hipStream_t s);
+
+__device__ __forceinline__ void dt_math_stage(const DtLogEntry *__restrict__ g, DtLogEntry *s_tab) {
+  for (int i = threadIdx.x; i < DT_LOGTAB_N; i += blockDim.x) s_tab[i] = g[i];
+}
+
+__device__ __forceinline__ double dt_fast_log(double x, const DtLogEntry *s_tab) {
+  unsigned long long b = (unsigned long long)__double_as_longlong(x);
+  unsigned hi = (unsigned)(b >> 32);
+  unsigned ex = hi >> 20;  // sign + exponent
+  if (ex - 1u >= 0x7FEu) return log(x);  // zero, subnormal, negative, inf, NaN: library semantics
+  int e = (int)ex - 1023;
+  unsigned idx = (hi >> 13) & 127u;
+  double m = __longlong_as_double((long long)((b & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull));
+  DtLogEntry t = s_tab[idx];
+  double u = fma(m, t.rc, -1.0);
+  double p = fma(u, 0.2, -0.25);
+  p = fma(u, p, 1.0 / 3.0);
+  p = fma(u, p, -0.5);
+  p = fma(u, p, 1.0);
+  p = u * p;
+  return fma((double)e, 0.6931471805599453, t.lnc + p);
+}
+
+__device__ __forceinline__ double dt_fast_lntan(double y, const DtLogEntry *s_tab) {
+  const double HALF_PI = 1.5707963267948966, QUARTER_PI = 0.7853981633974483;
+  if (!(y > 0.0 && y < HALF_PI)) return log(tan(y));
+  bool lo = y <= QUARTER_PI;
+  double z = lo ? y : HALF_PI - y;
+  if (!(z > 1e-300)) return log(tan(y));
+  double t = fma(z * z, DT_LNTAN_SCALE, -1.0);
+  double g = dt_lntan_c[DT_LNTAN_DEG];
+#pragma unroll
+  for (int k = DT_LNTAN_DEG - 1; k >= 0; k--) g = fma(g, t, dt_lntan_c[k]);
+  double r = dt_fast_log(z, s_tab) + g;
+  return lo ? r : -r;
+}
+
+// fast reciprocal (rel. error ~1e-16): hardware estimate + two Newton steps
+__device__ __forceinline__ double dt_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+
+__device__ __forceinline__ double dt_fast_atan(double q) {
+  const double T8 = 0.41421356237309503, T38 = 2.414213562373095;  // tan(pi/8), tan(3 pi/8)
+  if (!(q >= 0.0 && q < 1e300)) return atan(q);
+  double x, base, sgn = 1.0;
+  if (q <= T8) {
+    x = q;
+    base = 0.0;
+  } else if (q < T38) {
+    x = (q - 1.0) * dt_rcp(q + 1.0);
+    base = 0.7853981633974483;
+  } else {
+    x = dt_rcp(q);
+    base = 1.5707963267948966;
+    sgn = -1.0;
+  }
+  double t = fma(x * x, DT_ATAN_SCALE, -1.0);
+  double h = dt_atan_c[DT_ATAN_DEG];
+#pragma unroll
+  for (int k = DT_ATAN_DEG - 1; k >= 0; k--) h = fma(h, t, dt_atan_c[k]);
+  return fma(sgn * x, h, base);
+}

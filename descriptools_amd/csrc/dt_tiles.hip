@@ -815,12 +815,56 @@ __global__ __launch_bounds__(256) void k_fh_tile3(const uint8_t *__restrict__ fd
     s_x[threadIdx.x] = o;
   }
   __syncthreads();
+  // every cell's resolved word into registers; s_st is then reused as a per-END-CELL payload table
+  // {river height, river accumulation}: the river cell's own values for in-tile river ends, the
+  // resolved (possibly remote) river's for exit ends -- 252 gathers per tile instead of 2 per cell
+  unsigned long long wd[CPT];
+#pragma unroll
+  for (int j = 0; j < CPT; j++) wd[j] = s_st[threadIdx.x + 256 * j];
+  __syncthreads();
+  float zc[CPT];  // own height (also needed for HAND)
+#pragma unroll
+  for (int j = 0; j < CPT; j++) {
+    int c = threadIdx.x + 256 * j;
+    int y = y0 + c / TW, x = x0 + c % TW;
+    zc[j] = DT_NODATA;
+    if (y >= w.H || x >= w.W) continue;
+    long long o = (long long)y * w.ld + x;
+    if (dem) zc[j] = dem[o];
+    uint32_t ptr = (uint32_t)(wd[j] >> 32), ncf = (uint32_t)(wd[j] & 0xFFFFu);
+    if (!(ncf & FHT_DONE) || (ptr & 0xFFFu) != (uint32_t)c) continue;  // not the end cell of a path
+    uint32_t kind = (ptr >> 12) & 7u;
+    float zr = DT_NODATA;
+    int32_t ar = -100;
+    if (kind == K_RIVER) {
+      zr = zc[j];
+      if (acc32) ar = acc32[o];
+    } else if (kind == K_EXIT || kind == K_REXIT) {
+      unsigned long long xs = s_x[dt_slot_of(c / TW, c % TW)];
+      uint32_t xptr = (uint32_t)(xs >> 32);
+      if (xptr != FHT_DEAD) {
+        if (xptr & FHT_REMOTE) {
+          zr = rem.zr[xptr & ~FHT_REMOTE];
+          ar = rem.ar[xptr & ~FHT_REMOTE];
+        } else {
+          long long ro = (long long)(xptr / (uint32_t)w.W) * w.ld + (xptr % (uint32_t)w.W);
+          if (dem) zr = dem[ro];
+          if (acc32) ar = acc32[ro];
+        }
+      }
+    } else {
+      continue;
+    }
+    s_st[c] = ((unsigned long long)(uint32_t)ar << 32) | (unsigned long long)__float_as_uint(zr);
+  }
+  __syncthreads();
   const double dcard = px, ddiag = px * sqrt(2.0);
+#pragma unroll
   for (int j = 0; j < CPT; j++) {
     int c = threadIdx.x + 256 * j;
     int y = y0 + c / TW, x = x0 + c % TW;
     if (y >= w.H || x >= w.W) continue;
-    unsigned long long s = s_st[c];
+    unsigned long long s = wd[j];
     uint32_t ptr = (uint32_t)(s >> 32), nd = (uint32_t)((s >> 16) & 0xFFFFu);
     uint32_t ncf = (uint32_t)(s & 0xFFFFu), nc = ncf & 0x7FFFu;
     uint32_t kind = (ptr >> 12) & 7u, f = ptr & 0xFFFu;
@@ -843,8 +887,7 @@ __global__ __launch_bounds__(256) void k_fh_tile3(const uint8_t *__restrict__ fd
     }
     const bool remote = ok && (ridx & FHT_REMOTE) != 0u;
     const uint32_t key = ridx & ~FHT_REMOTE;
-    long long ro = 0;  // raster offset of a local river cell
-    if (ok && !remote) ro = (long long)(ridx / (uint32_t)w.W) * w.ld + (ridx % (uint32_t)w.W);
+    unsigned long long pay = ok ? s_st[f] : 0ull;
     long long o = (long long)y * w.ld + x;
     if (fdist) fdist[o] = ok ? (float)(dcard * (double)nc + ddiag * (double)nd) : DT_NODATA;
     if (idx32) idx32[o] = (ok && !remote) ? (int32_t)ridx : -100;
@@ -855,16 +898,16 @@ __global__ __launch_bounds__(256) void k_fh_tile3(const uint8_t *__restrict__ fd
       idx64[o] = g;
     }
     if (hand) {
-      float h = DT_NODATA, z = dem[o];
+      float h = DT_NODATA, z = zc[j];
       if (z != DT_NODATA && ok) {  // flowhand.py:436
-        h = z - (remote ? rem.zr[key] : dem[ro]);
+        h = z - __uint_as_float((uint32_t)pay);
         if (h < 0.0f && h != DT_NODATA) h = 0.0f;  // flowhand.py:438
       }
       hand[o] = h;
     }
     // A_river = fac[idx] carried as payload; cells without a river cell get -100 (GFI is -100 there
     // anyway: their hand is -100, gfi.py:289)
-    if (a_river) a_river[o] = ok ? (remote ? rem.ar[key] : acc32[ro]) : -100;
+    if (a_river) a_river[o] = ok ? (int32_t)(uint32_t)(pay >> 32) : -100;
   }
 }
 
