@@ -769,8 +769,13 @@ __global__ __launch_bounds__(1024, 8) void k_downslope_win(const float *__restri
                                                        double px, double dz, float dzf, int raw,
                                                        float *__restrict__ out, int tiles_x, int ntiles,
                                                        int *__restrict__ n_unresolved) {
-  __shared__ __attribute__((aligned(16))) float s_z[DW_WIN * DW_WIN];
-  __shared__ uint16_t s_w[DW_WIN * DW_WIN];
+  // one LDS block: heights at byte 0, move words at byte DW_WIN*DW_WIN*4 (the walk reads both with one
+  // address register and an immediate offset)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[DW_WIN * DW_WIN * 6];
+  float *s_z = reinterpret_cast<float *>(smem);
+  uint16_t *s_w = reinterpret_cast<uint16_t *>(smem + DW_WIN * DW_WIN * 4);
+  // LDS byte address of smem (0 when it is the kernel's only LDS object, but do not rely on it)
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
   int b = blockIdx.x, tile;
   {
     int xcd = b & 7, j = b >> 3;
@@ -855,8 +860,17 @@ __global__ __launch_bounds__(1024, 8) void k_downslope_win(const float *__restri
     while (running) {
       bool stop = (mw & MW_STOP) != 0u;
       int np = stop ? pos : pos + (int)(mw & 0x1FFu) - 256;
-      float zt = s_z[np];
-      uint32_t mwn = s_w[np];
+      // the successor's height and move word in ONE round trip (hipcc otherwise sinks the second read
+      // behind the first one's wait)
+      float zt;
+      uint32_t mwn;
+      {
+        uint32_t a4 = lds0 + ((uint32_t)np << 2), a2 = lds0 + ((uint32_t)np << 1);
+        asm volatile("ds_read_b32 %0, %2\n\tds_read_u16 %1, %3 offset:%4\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(zt), "=&v"(mwn)
+                     : "v"(a4), "v"(a2), "n"(DW_WIN * DW_WIN * 4)
+                     : "memory");
+      }
       bool nod = !stop && zt == DT_NODATA;  // :231-281: stop without moving
       bool ok = !stop && !nod;
       nodata_ahead = nodata_ahead || nod;
