@@ -240,3 +240,110 @@ def test_flowacc_arbitrary_fields(dt, impl, H, W, mode):
         _lib.check(_lib.lib().dt_set_flow_impl(2))
     ref = oracle.flowacc(fdr)
     assert np.array_equal(acc, ref), "%d cells differ" % int((acc != ref).sum())
+
+
+def test_full_size_4096_vs_oracle(dt):
+    """BASELINE.json configs[1]: 4096 x 4096 synthetic DEM, every descriptor of the resident chain
+    against the oracle (O(N) oracle variants; ~20 s of CPU)."""
+    from descriptools_amd import chain
+    n, px = 4096, 10.0
+    dem = oracle.synth_dem(1, n, n)
+    thr = n * n // 512
+    out = chain.run_host(dem, px, river_threshold=thr)
+    sl_o, fdr_o = oracle.slope_d8(dem, px)
+    assert np.array_equal(out["fdr"], fdr_o) and np.array_equal(out["slope"], sl_o)
+    acc_o = oracle.flowacc(fdr_o, dem)
+    assert np.array_equal(out["fac"], acc_o)
+    river = (acc_o > thr).astype(np.int8)
+    assert np.array_equal(out["river"], river)
+    idx_o, nc, nd = oracle.flowhand_fast(fdr_o, river)
+    assert np.array_equal(out["idx"], idx_o), "river index: bit-exact at full size"
+    ok = idx_o != -100
+    d_o = np.where(ok, (px * nc + (px * np.sqrt(2.0)) * nd), -100.0).astype(np.float32)
+    assert np.array_equal(out["fdist"], d_o), "count-form distance: identical arithmetic"
+    flat = dem.reshape(-1)
+    hand_o = np.where(ok, np.maximum(dem - flat[np.where(ok, idx_o, 0)], 0), -100).astype(np.float32)
+    assert np.array_equal(out["hand"], hand_o)
+    assert np.array_equal(out["down"], oracle.downslope(dem, fdr_o, px, 5.0))
+    slr = np.where(dem == -100, -100, np.arctan(sl_o / 100)).astype(np.float32)
+    # the chain's radians come from its own float64 atan: <= 1 float32 ulp from numpy's float32 arctan
+    assert np.max(np.abs(out["slope_rad"].astype(np.float64) - slr)) <= 2.4e-7
+    ti_o, mti_o = oracle.twi(acc_o, out["slope_rad"], px, 0.1)
+    assert_float_close(out["ti"], ti_o, rtol=1e-5, what="ti")
+    assert_float_close(out["mti"], mti_o, rtol=1e-5, atol=1e-6, what="mti")
+    g_o = oracle.gfi(hand_o, acc_o, idx_o, 0.4, 0.1, px)
+    assert_float_close(out["gfi"], g_o, rtol=1e-5, atol=1e-6, what="gfi")
+    l_o = oracle.lnhlh(hand_o, acc_o, 0.4, 0.1, px)
+    assert_float_close(out["lnhlh"], l_o, rtol=1e-5, atol=1e-6, what="lnhlh")
+    # how far inside the tolerance the float descriptors are (reported, not asserted tightly)
+    v = ti_o != -100
+    print("max rel err  ti %.2e  mti-abs %.2e  gfi-abs %.2e" % (
+        np.max(np.abs(out["ti"][v] - ti_o[v]) / np.abs(ti_o[v])), np.max(np.abs(out["mti"][v] - mti_o[v])),
+        np.max(np.abs(out["gfi"][g_o != -100] - g_o[g_o != -100]))))
+
+
+def test_full_size_16384_properties(dt):
+    """BASELINE.json configs[2] size: size-independent properties of the 16384^2 chain on the GPU
+    (the oracle would need minutes): conservation of flow accumulation, river / HAND consistency, and
+    equality with a 2 x 2 tiling of the same DEM run as four logical ranks."""
+    import torch
+    from descriptools_amd import _lib, chain, tiling
+    from descriptools_amd.device import Context
+    n, px = 16384, 10.0
+    thr = n * n // 512
+    L = _lib.lib()
+    ctx = Context()
+    dem = torch.empty((n, n), dtype=torch.float32, device="cuda")
+    _lib.check(L.dt_dev_synth_dem(ctx.h, 1, n, n, 0, 0, n, n, 0, dem.data_ptr()))
+    keep = []
+
+    def alloc(shape, dtp):
+        t = torch.empty(shape, dtype={np.float32: torch.float32, np.uint8: torch.uint8, np.int8: torch.int8,
+                                      np.int32: torch.int32}[dtp], device="cuda")
+        keep.append(t)
+        return t.data_ptr()
+    ch = chain.Chain(n, n, ctx=ctx, px=px, river_threshold=thr, alloc=alloc)
+    ch.run(dem.data_ptr())
+    ctx.sync()
+    t = {name: keep[i] for i, (name, _) in enumerate(chain.OUTPUTS)}
+    fdr, fac, river, idx, hand, fdist = t["fdr"], t["fac"], t["river"], t["idx"], t["hand"], t["fdist"]
+    # (1) every cell drains to exactly one outlet: sum over outlets of (acc + 1) == number of cells
+    #     (synthetic DEM: no nodata, no cycles); outlets = cells whose D8 step leaves the raster
+    yy = torch.arange(n, device="cuda").view(-1, 1).expand(n, n)
+    xx = torch.arange(n, device="cuda").view(1, -1).expand(n, n)
+    dy = torch.zeros(256, dtype=torch.int64, device="cuda")
+    dx = torch.zeros(256, dtype=torch.int64, device="cuda")
+    for c, (a, b) in {1: (0, 1), 2: (1, 1), 4: (1, 0), 8: (1, -1), 16: (0, -1), 32: (-1, -1), 64: (-1, 0),
+                      128: (-1, 1)}.items():
+        dy[c], dx[c] = a, b
+    f = fdr.long()
+    ty, tx = yy + dy[f], xx + dx[f]
+    outlet = (ty < 0) | (ty >= n) | (tx < 0) | (tx >= n) | (f == 0)
+    assert int((fac[outlet].long() + 1).sum()) == n * n
+    assert int((fac < 0).sum()) == 0
+    # (2) river mask, and HAND consistency: river cells drain to themselves at distance 0
+    assert torch.equal(river, (fac > thr).to(torch.int8))
+    lin = (yy * n + xx).to(torch.int32)
+    rv = river == 1
+    assert torch.equal(idx[rv], lin[rv]) and float(fdist[rv].abs().max()) == 0.0
+    ok = idx >= 0
+    assert bool((river.view(-1)[idx[ok].long()] == 1).all()), "every river index points at a river cell"
+    assert bool((hand[ok] >= 0).all()) and bool((hand[~ok] == -100).all())
+    assert bool((fdist[ok & ~rv] >= px).all())
+    # (3) the same DEM as 2 x 2 logical ranks == untiled
+    layout = tiling.Layout([n // 2, n // 2], [n // 2, n // 2])
+    tiles = []
+    for r in range(4):
+        tl = tiling.RankTile(layout, r, device=0, px=px, river_threshold=thr)
+        tl.synth_dem(1)
+        tiles.append(tl)
+    tiling.simulate(tiles, layout)
+    for tl in tiles:
+        assert tl.unresolved_downslope() == 0
+        y0, x0 = layout.origin(tl.rank)
+        for name in ("fdr", "fac", "river", "fdist", "hand", "a_river", "slope", "ti", "mti", "gfi", "lnhlh",
+                     "down"):
+            assert torch.equal(tl.core(name), t[name][y0:y0 + tl.H, x0:x0 + tl.W]), (tl.rank, name)
+        gi = tl.core("idx")
+        li = t["idx"][y0:y0 + tl.H, x0:x0 + tl.W].long()
+        assert torch.equal(gi, li), (tl.rank, "idx")
