@@ -33,6 +33,35 @@ OPS = [("d8", 5), ("flowacc_river", 5 + 1), ("flowhand", 18 + 4), ("slope_twi", 
        ("gfi_lnhlh", 4 + 4 + 4 + 4 + 4), ("downslope", 9)]
 
 
+# kernels behind each op (names as rocprofv3 prints them) -- used to attach the PMC-measured HBM
+# traffic (profiles/r1/v2_pmc_traffic.json, collected in separate --pmc runs of this script) to an op
+OP_KERNELS = {
+    "d8": ["k_stencil<false, true, false, false>"],
+    "flowacc_river": ["k_fa_tile1", "k_fa_link", "k_fa_reduce", "k_fa_poison", "k_fa_tile3<true, true>",
+                      "__amd_rocclr_fillBufferAligned"],
+    "flowhand": ["k_fh_tile1", "k_fh_ghost_init", "k_fh_node_jump", "k_fh_tile3"],
+    "slope_twi": ["k_stencil<true, false, true, true>"],
+    "gfi_lnhlh": ["k_gfi_both"],
+    "downslope": ["k_downslope_win"],
+}
+PMC_FILE = os.path.join(ROOT, "profiles", "r1", "v2_pmc_traffic.json")
+
+
+def pmc_traffic(op, size):
+    """HBM bytes per op from the committed PMC run (None when not measured for this size)."""
+    try:
+        d = json.load(open(PMC_FILE))
+        if d["size"] != size:
+            return None
+        tot = 0.0
+        for k in OP_KERNELS[op]:
+            e = d["kernels"][k]
+            tot += max(e["launches_per_step"], 1) * (2.0 * e["fetch_kb"] + e["write_kb"]) * 1024.0
+        return tot
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -159,9 +188,14 @@ def main():
         per_op[name] = {"ms": round(ms, 4), "algo_bytes_per_cell": bpc, "achieved_GBs": round(gbs, 1),
                         "frac": round(gbs / HBM_PEAK_GBS, 4)}
     dom = max(per_op, key=lambda k: per_op[k]["ms"])
+    for name in per_op:
+        tr = pmc_traffic(name, S)
+        per_op[name]["traffic_bytes"] = None if tr is None else int(tr)
     roof = {"kernel": dom, "bound": "hbm", "achieved": per_op[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": per_op[dom]["frac"], "traffic": None,
-            "note": "algorithmic bytes/cell x cells / mean op time from HIP events in the timed region"}
+            "unit": "GB/s", "frac": per_op[dom]["frac"], "traffic": per_op[dom]["traffic_bytes"],
+            "note": "achieved = algorithmic bytes/cell x cells / mean op time (HIP events on the launch "
+                    "stream, timed region); traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 summed over the op's "
+                    "kernels, from separate rocprofv3 --pmc runs committed under profiles/"}
 
     cells = N * world
     value = cells * args.steps / dt / 1e6
