@@ -128,8 +128,8 @@ struct SlopeCell {
 // scan positions: NW0 N1 NE2 W3 E4 SW5 S6 SE7
 __device__ __forceinline__ SlopeCell dt_slope_cell(float c, float nw, float n, float ne, float w,
                                                   float e, float sw, float s, float se,
-                                                  double inv_unused, double dcard, double ddiag) {
-  (void)inv_unused;
+                                                  double inv_card, double inv_diag, double dcard,
+                                                  double ddiag) {
   SlopeCell r;
   if (c <= DT_NODATA) {  // slope.py:231
     r.slope = DT_NODATA;
@@ -158,8 +158,20 @@ __device__ __forceinline__ SlopeCell dt_slope_cell(float c, float nw, float n, f
   DT_CAND(sw, db, dcode, dpos, 8u, 5)
   DT_CAND(se, db, dcode, dpos, 2u, 7)
 #undef DT_CAND
-  double vc = cb > 0.0f ? (double)cb / dcard : 0.0;
-  double vd = db > 0.0f ? (double)db / ddiag : 0.0;
+  // Exact float64 divisions are ~15 instructions each.  Fast path: multiply by the (correctly rounded)
+  // reciprocals -- within 3 float64 ulp of the reference's quotient -- and accept the result only if
+  // neither the cardinal / diagonal comparison nor the final float32 rounding can be affected by
+  // those ulps (checked below); otherwise divide.  Results are bit-identical either way.
+  double vc = (double)cb * inv_card, vd = (double)db * inv_diag;
+  const double EPS = 8.9e-16;  // 4 ulp, relative
+  double vmax = vc > vd ? vc : vd;
+  bool ambiguous = (vc != vd) && fabs(vc - vd) <= EPS * vmax;
+  float f_lo = (float)(vmax * (100.0 * (1.0 - EPS))), f_hi = (float)(vmax * (100.0 * (1.0 + EPS)));
+  ambiguous = ambiguous || (f_lo != f_hi);
+  if (ambiguous) {
+    vc = cb > 0.0f ? (double)cb / dcard : 0.0;
+    vd = db > 0.0f ? (double)db / ddiag : 0.0;
+  }
   double v;
   uint32_t code;
   if (vc > vd || (vc == vd && cpos < dpos)) {
@@ -266,6 +278,7 @@ __global__ __launch_bounds__(256) void k_stencil(const float *__restrict__ dem, 
   const int gx = x0 + cx;
   if (gx >= W) return;
   const double dcard = px, ddiag = px * sqrt(2.0);
+  const double inv_card = 1.0 / dcard, inv_diag = 1.0 / ddiag;
 
   // rolling 3-row window of 6 values (cols cx-1 .. cx+4)
   float a[6], bb[6], cc[6];
@@ -291,7 +304,7 @@ __global__ __launch_bounds__(256) void k_stencil(const float *__restrict__ dem, 
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         SlopeCell sc = dt_slope_cell(bb[k + 1], a[k], a[k + 1], a[k + 2], bb[k], bb[k + 2], cc[k],
-                                     cc[k + 1], cc[k + 2], 0.0, dcard, ddiag);
+                                     cc[k + 1], cc[k + 2], inv_card, inv_diag, dcard, ddiag);
         so[k] = sc.slope;
         uint32_t code = sc.code;
         if (W_FDR) {
