@@ -359,6 +359,25 @@ extern "C" int dt_dev_confusion_multi(dt_ctx *c, const double *desc, const int8_
   return DT_OK;
 }
 
+extern "C" int dt_dev_unique_extremes_f32(dt_ctx *c, const float *x, int64_t N, float *out3_dev) {
+  DT_CTX(c);
+  DT_REQUIRE(x && out3_dev && N >= 0, "bad arguments");
+  DT_TRY(dt_scratch_reset(c, 256));
+  uint32_t *work = (uint32_t *)dt_scratch_take(c, 64);
+  DT_TRY(dt_launch_unique_extremes(c->stream, x, N, work, out3_dev));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+
+extern "C" int dt_dev_minmax_scale_f32(dt_ctx *c, const float *x, int64_t N, float mn, float mx, float nodata,
+                                       double *desc) {
+  DT_CTX(c);
+  DT_REQUIRE((x && desc) || N == 0, "NULL raster");
+  DT_TRY(dt_launch_minmax_scale(c->stream, x, N, mn, mx, nodata, desc));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+
 extern "C" int dt_dev_i32_to_i64(dt_ctx *c, const int32_t *src, int64_t N, int64_t *dst) {
   DT_CTX(c);
   DT_TRY(dt_launch_i32_to_i64(c->stream, src, N, dst));

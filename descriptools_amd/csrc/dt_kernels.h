@@ -56,3 +56,6 @@ int dt_launch_fh_finish(hipStream_t s, const DtWin &w, const float *dem, const u
                         int32_t *idx32, long long *idx64, float *hand, int32_t *a_river);
 int dt_launch_gfi_both(hipStream_t s, const float *hand, const int32_t *a_river, const int32_t *fac,
                        int64_t n, double expo, double b, double size, float *gfi, float *lnhlh);
+int dt_launch_unique_extremes(hipStream_t s, const float *x, int64_t n, uint32_t *work4, float *out3);
+int dt_launch_minmax_scale(hipStream_t s, const float *x, int64_t n, float mn, float mx, float nodata,
+                           double *out);

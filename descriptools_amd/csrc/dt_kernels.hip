@@ -1059,6 +1059,84 @@ int dt_launch_confusion(hipStream_t s, const double *desc, const int8_t *flood, 
   return DT_OK;
 }
 
+// ===========================================================================================
+// Device-resident evaluation helpers (E1)
+// ===========================================================================================
+// order-preserving map float -> uint32 for atomicMin / atomicMax on floats
+__device__ __forceinline__ uint32_t dt_f2ord(float f) {
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float dt_ord2f(uint32_t o) {
+  return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o);
+}
+// out[0] = min, out[1] = max over cells with x > lower (NaN skipped); ordered-uint encoding
+__global__ __launch_bounds__(256) void k_minmax_above(const float *__restrict__ x, int64_t n, float lower,
+                                                     int use_lower, uint32_t *__restrict__ out) {
+  uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+  int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    float v = x[i];
+    if (v != v) continue;
+    if (use_lower && !(v > lower)) continue;
+    uint32_t o = dt_f2ord(v);
+    mn = min(mn, o);
+    mx = max(mx, o);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    mn = min(mn, (uint32_t)__shfl_down((int)mn, off));
+    mx = max(mx, (uint32_t)__shfl_down((int)mx, off));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(&out[0], mn);
+    atomicMax(&out[1], mx);
+  }
+}
+__global__ void k_minmax_decode(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
+                                float *__restrict__ out3) {
+  // a = {min, max} over all cells, b = {min over cells > global min, -}: np.unique(x)[0], [1], [-1]
+  out3[0] = a[0] == 0xFFFFFFFFu ? NAN : dt_ord2f(a[0]);
+  out3[1] = b[0] == 0xFFFFFFFFu ? NAN : dt_ord2f(b[0]);
+  out3[2] = a[1] == 0u ? NAN : dt_ord2f(a[1]);
+}
+// smallest, second-smallest distinct and largest value of a float32 raster (what the example derives
+// from np.unique(hand): elements[0], elements[1], elements[-1]; Example/example.py:113-115)
+int dt_launch_unique_extremes(hipStream_t s, const float *x, int64_t n, uint32_t *work4, float *out3) {
+  uint32_t init[4] = {0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u};
+  DT_HIP(hipMemcpyAsync(work4, init, sizeof(init), hipMemcpyHostToDevice, s));
+  DT_HIP(hipStreamSynchronize(s));  // init[] is on the stack
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_minmax_above, dim3((unsigned)blocks), dim3(256), 0, s, x, n, 0.0f, 0, work4);
+  // second pass needs the global minimum: read it back (tiny)
+  uint32_t a0;
+  DT_HIP(hipMemcpyAsync(&a0, work4, 4, hipMemcpyDeviceToHost, s));
+  DT_HIP(hipStreamSynchronize(s));
+  float lower = a0 == 0xFFFFFFFFu ? 0.0f : __builtin_bit_cast(float, (a0 & 0x80000000u) ? (a0 & 0x7FFFFFFFu) : ~a0);
+  hipLaunchKernelGGL(k_minmax_above, dim3((unsigned)blocks), dim3(256), 0, s, x, n, lower, 1, work4 + 2);
+  hipLaunchKernelGGL(k_minmax_decode, dim3(1), dim3(1), 0, s, work4, work4 + 2, out3);
+  return DT_OK;
+}
+
+// evaluation.minMaxScale on a float32 raster (evaluation.py:5-9): numpy keeps float32 there, so the
+// arithmetic is float32; NaN where x == nodata (or x is NaN); widened to the float64 the confusion kernel
+// reads
+__global__ __launch_bounds__(256) void k_minmax_scale(const float *__restrict__ x, int64_t n, float mn,
+                                                     float mx, float nodata, double *__restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float v = x[i];
+  float d = (v == nodata) ? NAN : (v - mn) / (mx - mn);
+  out[i] = (double)d;
+}
+int dt_launch_minmax_scale(hipStream_t s, const float *x, int64_t n, float mn, float mx, float nodata,
+                           double *out) {
+  if (n) hipLaunchKernelGGL(k_minmax_scale, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n, mn, mx,
+                            nodata, out);
+  return DT_OK;
+}
+
 // ---- dtype helpers ----------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_i32_to_i64(const int32_t *__restrict__ a, int64_t n,
                                                    int64_t *__restrict__ b) {

@@ -205,6 +205,15 @@ int dt_dev_flowhand_finish_w(dt_ctx *ctx, const dt_window *win, const float *dem
                              const float *rem_zr, const int32_t *rem_ar, float *fdist, int32_t *idx32,
                              int64_t *idx64, float *hand, int32_t *a_river);
 
+/* evaluation on resident rasters.  out3_dev (device float[3]) = smallest,
+ * second-smallest distinct and largest value of x, i.e. np.unique(x)[0], [1], [-1] as
+ * Example/example.py:113-115 uses them (NaN when absent). */
+int dt_dev_unique_extremes_f32(dt_ctx *ctx, const float *x, int64_t N, float *out3_dev);
+/* evaluation.minMaxScale (evaluation.py:5-9) of a float32 raster: float32 arithmetic like numpy,
+ * NaN where x == nodata, written as the float64 raster dt_dev_confusion_multi reads. */
+int dt_dev_minmax_scale_f32(dt_ctx *ctx, const float *x, int64_t N, float mn, float mx, float nodata,
+                            double *desc);
+
 /* widen / narrow helpers for the int64 API dtypes */
 int dt_dev_i32_to_i64(dt_ctx *ctx, const int32_t *src, int64_t N, int64_t *dst);
 int dt_dev_i64_to_i32(dt_ctx *ctx, const int64_t *src, int64_t N, int32_t *dst);

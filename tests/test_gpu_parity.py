@@ -347,3 +347,29 @@ def test_full_size_16384_properties(dt):
         gi = tl.core("idx")
         li = t["idx"][y0:y0 + tl.H, x0:x0 + tl.W].long()
         assert torch.equal(gi, li), (tl.rank, "idx")
+
+
+def test_evaluate_resident_matches_host_api(dt):
+    """Device-resident evaluation (extremes -> minMaxScale -> calibration -> counts) == the drop-in host
+    functions on the same float32 HAND raster, on the Example data and on a synthetic chain."""
+    from descriptools_amd import chain, evaluation
+    from descriptools_amd.device import Context
+    dem, fdr, fac, river, flood, klass = load_example()
+    _, _, hand = dt.flowhand.flow_hand_index(dem, fdr, river, 12.5)
+    hand32 = hand.astype(np.float32)
+    ctx = Context()
+    d_hand, d_flood = ctx.to_device(hand32), ctx.to_device(flood.astype(np.int8))
+    res = evaluation.evaluate_resident(ctx, d_hand.ptr, d_flood.ptr, hand32.size, 'under')
+    d_hand.free(); d_flood.free(); ctx.close()
+    # host reference on the SAME float32 raster (numpy keeps float32 in minMaxScale / binary_map)
+    el = np.unique(hand32)
+    desc = evaluation.minMaxScale(hand32, el[1], el[-1], -100)
+    fl = flood.astype(np.int8).copy()
+    th = evaluation.calibration(desc, fl, 'under')
+    c, f, cm = evaluation.avaliacao(evaluation.binary_map(desc, th, 'under'), fl)
+    assert (res["mn"], res["mx"]) == (float(el[1]), float(el[-1])) == (0.0, 259.0)
+    assert res["threshold"] == th == 0.012
+    assert np.array_equal(res["counts"], np.bincount(cm.reshape(-1).astype(np.int64), minlength=4))
+    assert res["correctness"] == c and res["fit"] == f
+    # the int16 pipeline of the example gives the same class counts (exact small integers in float32)
+    assert np.array_equal(res["counts"], np.bincount(klass.reshape(-1).astype(np.int64), minlength=4))

@@ -82,3 +82,83 @@ def test_tiled_flowacc_cycles_across_ranks():
         got = t.host("fac")
         want = ref[y0:y0 + t.H, x0:x0 + t.W]
         assert np.array_equal(got, want), "rank %d: %d cells differ" % (t.rank, int((got != want).sum()))
+
+
+def test_tiled_evaluation_matches_untiled():
+    """config #5's classifier step on a tiled HAND: per-rank np.unique extremes combined as the
+    all-gather would (combine_extremes) and per-rank confusion counts summed as the all-reduce would equal
+    the untiled device evaluation."""
+    import ctypes as C
+    from descriptools_amd import _lib, chain, evaluation, tiling
+    from descriptools_amd.device import Context
+    L = _lib.lib()
+    layout = tiling.Layout([192, 192], [256, 256])
+    Hg, Wg = layout.Hg, layout.Wg
+    dem = _global_dem(7, Hg, Wg, 2)
+    ref = chain.run_host(dem, 10.0, river_threshold=(Hg * Wg) // 512)
+    hand = ref["hand"]
+    rng = np.random.default_rng(3)
+    flood = ((hand >= 0) & (hand < 2.0) & (rng.random(hand.shape) < 0.9)).astype(np.int8)
+    ctx = Context()
+    d_h, d_f = ctx.to_device(hand), ctx.to_device(flood)
+    want = evaluation.evaluate_resident(ctx, d_h.ptr, d_f.ptr, hand.size, 'under')
+    d_h.free()
+    d_f.free()
+    bufs = []
+    for r in range(layout.size):
+        y0, x0 = layout.origin(r)
+        H, W = layout.shape(r)
+        bufs.append((ctx.to_device(np.ascontiguousarray(hand[y0:y0 + H, x0:x0 + W])),
+                     ctx.to_device(np.ascontiguousarray(flood[y0:y0 + H, x0:x0 + W]))))
+    ext = []
+    for dh, _ in bufs:
+        e = ctx.empty(3, np.float32)
+        _lib.check(L.dt_dev_unique_extremes_f32(ctx.h, dh.ptr, dh.size, e.ptr))
+        ext.append(e.to_host())
+        e.free()
+    glob = evaluation.combine_extremes(ext)
+    assert float(glob[1]) == want["mn"] and float(glob[2]) == want["mx"]
+    # value of the scaled raster at global [0, 0] = binary_map's nodata (evaluation.py:111)
+    first = np.nan if hand[0, 0] == -100 else float((np.float32(hand[0, 0]) - glob[1]) / (glob[2] - glob[1]))
+    # every rank runs the same calibration with the counts summed over ranks at each stage
+    results = []
+    for i in range(layout.size):
+        def allreduce(c_local, i=i):
+            tot = c_local.copy()
+            for j, (dh, df) in enumerate(bufs):
+                if j == i:
+                    continue
+                dd = ctx.empty(dh.size, np.float64)
+                _lib.check(L.dt_dev_minmax_scale_f32(ctx.h, dh.ptr, dh.size, glob[1], glob[2], np.float32(-100), dd.ptr))
+                cc = ctx.empty(4 * len(c_local), np.int64)
+                th = np.ascontiguousarray(allreduce.th)
+                _lib.check(L.dt_dev_confusion_multi(ctx.h, dd.ptr, df.ptr, dh.size, first,
+                                                    th.ctypes.data_as(C.POINTER(C.c_double)), len(th), 1, cc.ptr))
+                tot += cc.to_host().reshape(len(th), 4)
+                dd.free()
+                cc.free()
+            return tot
+        # the thresholds of the current stage are needed by the emulated peers: wrap dt_dev_confusion_multi
+        orig = L.dt_dev_confusion_multi
+
+        def spy(ctxh, d, f, n, nod, thp, nth, under, cnt, _orig=orig, _ar=allreduce):
+            _ar.th = np.ctypeslib.as_array(thp, (nth,)).copy()
+            return _orig(ctxh, d, f, n, nod, thp, nth, under, cnt)
+        dh, df = bufs[i]
+        L_spy = type("LibSpy", (), {"__getattr__": lambda self, k: spy if k == "dt_dev_confusion_multi" else getattr(L, k)})()
+        old = _lib._lib
+        _lib._lib = L_spy
+        try:
+            results.append(evaluation.evaluate_resident(ctx, dh.ptr, df.ptr, dh.size, 'under',
+                                                        reduce_extremes=lambda e: glob, reduce_counts=allreduce,
+                                                        nodata_first=first))
+        finally:
+            _lib._lib = old
+    for res in results:
+        assert res["threshold"] == want["threshold"]
+        assert np.array_equal(res["counts"], want["counts"])
+        assert res["fit"] == want["fit"] and res["correctness"] == want["correctness"]
+    for dh, df in bufs:
+        dh.free()
+        df.free()
+    ctx.close()
