@@ -442,6 +442,56 @@ def all_gather_summaries(arrs, layout, rank, group=None):
     return res
 
 
+_DIRS = [(-1, -1), (-1, 0), (-1, 1), (0, -1), (0, 1), (1, -1), (1, 0), (1, 1)]
+
+
+def exchange_halo(ext, layout, rank, halo=HALO, group=None):
+    """Point-to-point halo exchange of an extended raster `ext` ((H + 2*halo) x (W + 2*halo) torch
+    tensor, CPU for gloo / GPU for RCCL) with the <= 8 neighbouring ranks: each rank sends the border
+    strips of its core and receives its halo.  xGMI is point-to-point, the strips are KBs: eight small
+    sends per rank, no collective.  Halo cells outside the global raster are left untouched."""
+    import torch
+    import torch.distributed as dist
+    H, W = layout.shape(rank)
+    ry, rx = rank // layout.tx, rank % layout.tx
+    h = halo
+    assert all(hh >= h for hh in layout.heights) and all(ww >= h for ww in layout.widths), \
+        "rank tiles must be at least `halo` cells in both directions"
+
+    def rows(d, send):  # slice of ext rows for direction component d
+        if d == 0:
+            return slice(h, h + H)
+        if send:
+            return slice(h, 2 * h) if d < 0 else slice(H, H + h)
+        return slice(0, h) if d < 0 else slice(h + H, 2 * h + H)
+
+    def cols(d, send):
+        if d == 0:
+            return slice(h, h + W)
+        if send:
+            return slice(h, 2 * h) if d < 0 else slice(W, W + h)
+        return slice(0, h) if d < 0 else slice(h + W, 2 * h + W)
+
+    ops, recvs = [], []
+    for k, (dy, dx) in enumerate(_DIRS):
+        py, px = ry + dy, rx + dx
+        if not (0 <= py < layout.ty and 0 <= px < layout.tx):
+            continue
+        peer = py * layout.tx + px
+        sbuf = ext[rows(dy, True), cols(dx, True)].contiguous()
+        rbuf = torch.empty_like(ext[rows(dy, False), cols(dx, False)]).contiguous()
+        # the peer sends towards us in the opposite direction: its tag is 7 - k
+        ops.append(dist.P2POp(dist.isend, sbuf, peer, group=group, tag=k))
+        ops.append(dist.P2POp(dist.irecv, rbuf, peer, group=group, tag=7 - k))
+        recvs.append((dy, dx, rbuf))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    for dy, dx, rbuf in recvs:
+        ext[rows(dy, False), cols(dx, False)] = rbuf
+    return ext
+
+
 class Exchange:
     """The two all-gathers of a step, issued on a SIDE stream behind an event, so that kernels queued
     on the main stream after the summaries keep the GPU busy while the ring rows travel (RCCL) and

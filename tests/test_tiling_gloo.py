@@ -176,6 +176,48 @@ def _worker(rank, port, q):
         dist.destroy_process_group()
 
 
+def _halo_worker(rank, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from descriptools_amd import tiling
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE="4")
+    dist.init_process_group("gloo", rank=rank, world_size=4)
+    try:
+        layout = tiling.Layout([64, 70], [128, 65])  # 2 x 2 ranks, ragged last row / column
+        h = 64
+        rng = np.random.default_rng(5)
+        glob = rng.random((layout.Hg, layout.Wg)).astype(np.float32)
+        y0, x0 = layout.origin(rank)
+        H, W = layout.shape(rank)
+        ext = torch.full((H + 2 * h, W + 2 * h), -7.0)
+        ext[h:h + H, h:h + W] = torch.as_tensor(glob[y0:y0 + H, x0:x0 + W])
+        tiling.exchange_halo(ext, layout, rank, h)
+        # every extended cell inside the global raster must now hold the global value; the rest is untouched
+        pad = np.full((layout.Hg + 2 * h, layout.Wg + 2 * h), -7.0, np.float32)
+        pad[h:h + layout.Hg, h:h + layout.Wg] = glob
+        want = pad[y0:y0 + H + 2 * h, x0:x0 + W + 2 * h]
+        q.put((rank, bool(np.array_equal(ext.numpy(), want))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_world4_gloo_halo_exchange():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_halo_worker, args=(r, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), sorted(res)
+
+
 @pytest.mark.timeout(300)
 def test_world2_gloo_rank_level_solves():
     import torch.multiprocessing as mp
