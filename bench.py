@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tiled", action="store_true", help="N = 1 through the multi-rank path (1 x 1 layout): "
                                                          "measures what the tiling machinery costs")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and use the "
+                    "collective path even with one rank (rehearsal of the RCCL calls on a 1-GPU box)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; default) or gloo (rehearsal of N > 1 "
                                                         "with several ranks sharing one GPU)")
     args = ap.parse_args()
@@ -82,8 +84,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or args.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "gloo":
             local_rank = local_rank % max(torch.cuda.device_count(), 1)
             dist.init_process_group("gloo")
@@ -97,7 +102,7 @@ def main():
     from descriptools_amd.device import Context
     L = _lib.lib()
 
-    if world > 1 or args.tiled:
+    if world > 1 or args.tiled or args.force_dist:
         return main_tiled(args, torch, dist, world, rank, local_rank, dev)
 
     S = args.size
@@ -236,14 +241,15 @@ def main_tiled(args, torch, dist, world, rank, local_rank, dev):
                            river_threshold=(layout.Hg * layout.Wg) // 512)
     tile.synth_dem(args.seed)
 
-    exchange = tiling.Exchange(tile, layout, world)
+    use_dist = world > 1 or args.force_dist
+    exchange = tiling.Exchange(tile, layout, world if not args.force_dist else max(world, 2))
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    cpu_red = world > 1 and dist.get_backend() == "gloo"
+    cpu_red = use_dist and dist.get_backend() == "gloo"
 
     for _ in range(args.warmup):
         tiling.run_rank(tile, layout, exchange)
@@ -254,7 +260,7 @@ def main_tiled(args, torch, dist, world, rank, local_rank, dev):
     barrier()
     dt = time.perf_counter() - t0
     unres = torch.tensor([tile.unresolved_downslope()], dtype=torch.int64, device="cpu" if cpu_red else dev)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if cpu_red else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -281,7 +287,7 @@ def main_tiled(args, torch, dist, world, rank, local_rank, dev):
     }
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
