@@ -651,9 +651,13 @@ __device__ __forceinline__ void fht_solve_tile(const FhTile &T, const uint8_t *_
 }
 
 // pass 1: perimeter node words
+// `cache` keeps every cell's resolved in-tile word (8 bytes, tile-major: cache[tile * NT + c]) so that
+// pass 3 does not have to solve the tile again: 16 bytes / cell of streaming HBM traffic instead of a
+// second LDS-bound pointer doubling.
 __global__ __launch_bounds__(256) void k_fh_tile1(const uint8_t *__restrict__ fdr,
                                                  const int8_t *__restrict__ river, DtWin w, int tiles_x,
-                                                 uint32_t nnodes, unsigned long long *__restrict__ nodes) {
+                                                 uint32_t nnodes, unsigned long long *__restrict__ nodes,
+                                                 unsigned long long *__restrict__ cache) {
   __shared__ __attribute__((aligned(16))) uint8_t s_fdr[NT];
   __shared__ uint8_t s_halo[2 * (TW + 2) + 2 * TH];
   __shared__ unsigned long long s_st[NT];
@@ -684,6 +688,10 @@ __global__ __launch_bounds__(256) void k_fh_tile1(const uint8_t *__restrict__ fd
       o = fht_pack(node, nd + (diag ? 1u : 0u), nc + (diag ? 0u : 1u));
     }
     nodes[(size_t)tile * PS + threadIdx.x] = o;
+  }
+  for (int j = 0; j < CPT; j++) {
+    int c = threadIdx.x + 256 * j;
+    cache[(size_t)tile * NT + c] = s_st[c];
   }
 }
 
@@ -774,34 +782,30 @@ struct FhRemote {  // payload of rank exits (multi-GPU), all indexed by core-rin
 };
 
 __global__ __launch_bounds__(256) void k_fh_tile3(const uint8_t *__restrict__ fdr,
-                                                 const int8_t *__restrict__ river,
                                                  const float *__restrict__ dem,
                                                  const int32_t *__restrict__ acc32, DtWin w, int tiles_x,
                                                  uint32_t nnodes, const unsigned long long *__restrict__ nodes,
+                                                 const unsigned long long *__restrict__ cache,
                                                  FhRemote rem, double px, float *__restrict__ fdist,
                                                  int32_t *__restrict__ idx32, long long *__restrict__ idx64,
                                                  float *__restrict__ hand, int32_t *__restrict__ a_river) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_fdr[NT];
-  __shared__ uint8_t s_halo[2 * (TW + 2) + 2 * TH];
-  __shared__ unsigned long long s_st[NT];
-  __shared__ unsigned long long s_x[PS];  // resolved word of the node each exit cell steps onto (+ the step)
+  __shared__ unsigned long long s_st[NT];  // per-END-CELL payload table {river height, accumulation}
+  __shared__ unsigned long long s_x[PS];   // resolved word of the node each exit cell steps onto (+ the step)
   const int tile = blockIdx.x;
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int y0 = ty * TH, x0 = tx * TW;
-  FhTile T{s_fdr, s_halo, s_st};
-  fht_solve_tile(T, fdr, river, w, y0, x0);
   if (threadIdx.x < PS) {
     int ly, lx;
     dt_cell_of_slot(threadIdx.x, ly, lx);
     int f = ly * TW + lx;
-    unsigned long long s = s_st[f];
+    unsigned long long s = cache[(size_t)tile * NT + f];
     uint32_t sp = (uint32_t)(s >> 32);
     unsigned long long o = fht_pack(FHT_DEAD, 0, FHT_DONE);
     // only exit cells (a finished word pointing at itself with kind EXIT / REXIT) are looked up
     bool ex = sp == ((uint32_t)f | (K_EXIT << 12)), rex = sp == ((uint32_t)f | (K_REXIT << 12));
     if (ex || rex) {
       int dy, dx;
-      dt_d8_delta(s_fdr[f], dy, dx);
+      dt_d8_delta(fdr[(long long)(y0 + ly) * w.ld + x0 + lx], dy, dx);
       size_t node = ex ? (size_t)dt_node_of(y0 + ly + dy, x0 + lx + dx, tiles_x)
                        : (size_t)nnodes + (size_t)dt_perim_index(w.H, w.W, y0 + ly, x0 + lx);
       unsigned long long ns = nodes[node];
@@ -814,14 +818,13 @@ __global__ __launch_bounds__(256) void k_fh_tile3(const uint8_t *__restrict__ fd
     }
     s_x[threadIdx.x] = o;
   }
-  __syncthreads();
-  // every cell's resolved word into registers; s_st is then reused as a per-END-CELL payload table
-  // {river height, river accumulation}: the river cell's own values for in-tile river ends, the
-  // resolved (possibly remote) river's for exit ends -- 252 gathers per tile instead of 2 per cell
   unsigned long long wd[CPT];
 #pragma unroll
-  for (int j = 0; j < CPT; j++) wd[j] = s_st[threadIdx.x + 256 * j];
+  for (int j = 0; j < CPT; j++) wd[j] = cache[(size_t)tile * NT + threadIdx.x + 256 * j];
   __syncthreads();
+  // payload table {river height, river accumulation} per END cell: the river cell's own values for
+  // in-tile river ends, the resolved (possibly remote) river's for exit ends -- 252 gathers per tile
+  // instead of 2 per cell
   float zc[CPT];  // own height (also needed for HAND)
 #pragma unroll
   for (int j = 0; j < CPT; j++) {
@@ -912,7 +915,7 @@ __global__ __launch_bounds__(256) void k_fh_tile3(const uint8_t *__restrict__ fd
 }
 
 struct FhScratch {
-  unsigned long long *nodes;
+  unsigned long long *nodes, *cache;
   int64_t nnodes, ntiles, P;
   int tiles_x;
 };
@@ -923,11 +926,13 @@ static FhScratch fh_layout(const DtWin &w, void *scratch) {
   f.nnodes = f.ntiles * PS;
   f.P = dt_perim_count(w.H, w.W);
   f.nodes = (unsigned long long *)scratch;
+  f.cache = (unsigned long long *)((char *)scratch + dt_align256(((size_t)f.nnodes + (size_t)f.P) * 8));
   return f;
 }
 size_t dt_flowhand_tiled_scratch(int64_t H, int64_t W) {
   int64_t ntiles = ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
-  return dt_align256(((size_t)ntiles * PS + (size_t)dt_perim_count((int)H, (int)W)) * 8) + 256;
+  return dt_align256(((size_t)ntiles * PS + (size_t)dt_perim_count((int)H, (int)W)) * 8) +
+         dt_align256((size_t)ntiles * NT * 8) + 256;
 }
 
 // phase 1: tile pass + perimeter node doubling (rank exits park on their ghosts)
@@ -938,7 +943,7 @@ int dt_launch_fh_local(hipStream_t s, const DtWin &w, const uint8_t *fdr, const 
   FhScratch f = fh_layout(w, scratch);
   DT_REQUIRE(f.nnodes + f.P < 0x7FFFFFF0ll, "raster too large for one device tile");
   dim3 gt((unsigned)f.ntiles), b(256), gn((unsigned)((f.nnodes + f.P + 255) / 256));
-  hipLaunchKernelGGL(k_fh_tile1, gt, b, 0, s, fdr, river, w, f.tiles_x, (uint32_t)f.nnodes, f.nodes);
+  hipLaunchKernelGGL(k_fh_tile1, gt, b, 0, s, fdr, river, w, f.tiles_x, (uint32_t)f.nnodes, f.nodes, f.cache);
   hipLaunchKernelGGL(k_fh_ghost_init, dim3((unsigned)((f.P + 255) / 256)), b, 0, s, f.nodes, (uint32_t)f.nnodes, f.P);
   // 15 rounds resolve every chain of <= 20000 moves (each node hop is >= 1 move; 2^15 > 20000)
   for (int r = 0; r < 15; r++) hipLaunchKernelGGL(k_fh_node_jump, gn, b, 0, s, f.nodes, f.nnodes + f.P);
@@ -970,7 +975,8 @@ int dt_launch_fh_finish(hipStream_t s, const DtWin &w, const float *dem, const u
     for (int r = 0; r < 2; r++) hipLaunchKernelGGL(k_fh_node_jump, gn, b, 0, s, f.nodes, f.nnodes + f.P);
   }
   FhRemote rem{rem_gidx, rem_zr, rem_ar};
-  hipLaunchKernelGGL(k_fh_tile3, gt, b, 0, s, fdr, river, dem, acc32, w, f.tiles_x, (uint32_t)f.nnodes, f.nodes,
+  (void)river;
+  hipLaunchKernelGGL(k_fh_tile3, gt, b, 0, s, fdr, dem, acc32, w, f.tiles_x, (uint32_t)f.nnodes, f.nodes, f.cache,
                      rem, px, fdist, idx32, idx64, hand, a_river);
   return DT_OK;
 }
