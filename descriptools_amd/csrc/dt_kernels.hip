@@ -775,7 +775,8 @@ __global__ __launch_bounds__(256) void k_downslope(const float *__restrict__ dem
 #define MW_BADCODE 0x400u
 #define MW_EDGE 0x800u
 #define MW_RING 0x1000u
-#define MW_STOP (MW_BADCODE | MW_EDGE | MW_RING)
+#define MW_NODATA 0x2000u /* the successor cell is nodata: the walk stops here without moving */
+#define MW_STOP (MW_BADCODE | MW_EDGE | MW_RING | MW_NODATA)
 
 __global__ __launch_bounds__(1024, 8) void k_downslope_win(const float *__restrict__ dem,
                                                        const uint8_t *__restrict__ fdr, DtWin w,
@@ -847,6 +848,13 @@ __global__ __launch_bounds__(1024, 8) void k_downslope_win(const float *__restri
         make_uint2(mwv[0] | (mwv[1] << 16), mwv[2] | (mwv[3] << 16));
   }
   __syncthreads();
+  // second staging pass: a move onto a nodata cell never happens (downslope.py:231-281) -- fold that
+  // test into the move word so the walk loop has a single stop condition
+  for (int i = threadIdx.x; i < DW_WIN * DW_WIN; i += 1024) {
+    uint32_t mw = s_w[i];
+    if (!(mw & MW_STOP) && s_z[i + (int)(mw & 0x1FFu) - 256] == DT_NODATA) s_w[i] = (uint16_t)(mw | MW_NODATA);
+  }
+  __syncthreads();
   const double dcard = px, ddiag = px * sqrt(2.0);
   for (int j = 0; j < (DW_CORE * DW_CORE) / 1024; j++) {
     int c = threadIdx.x + 1024 * j;
@@ -868,38 +876,39 @@ __global__ __launch_bounds__(1024, 8) void k_downslope_win(const float *__restri
     // of a wave iterate until the longest walk ends anyway).  (double)drop < dz  <=>  drop < dzf
     // (dzf = smallest float >= dz).  The next cell's height and move word are fetched together.
     uint32_t mw = s_w[pos];
-    bool nodata_ahead = false;
-    bool running = drop < dzf;
-    while (running) {
-      bool stop = (mw & MW_STOP) != 0u;
-      int np = stop ? pos : pos + (int)(mw & 0x1FFu) - 256;
-      // the successor's height and move word in ONE round trip (hipcc otherwise sinks the second read
-      // behind the first one's wait)
-      float zt;
-      uint32_t mwn;
-      {
-        uint32_t a4 = lds0 + ((uint32_t)np << 2), a2 = lds0 + ((uint32_t)np << 1);
-        asm volatile("ds_read_b32 %0, %2\n\tds_read_u16 %1, %3 offset:%4\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(zt), "=&v"(mwn)
-                     : "v"(a4), "v"(a2), "n"(DW_WIN * DW_WIN * 4)
-                     : "memory");
+    bool running = drop < dzf && !(mw & MW_STOP);
+    // every lane still running has made exactly `it` moves: the 5000-move cap is a scalar loop bound
+    for (int it = 0; it < 5000 && __any(running); it++) {
+      if (running) {
+        int np = pos + (int)(mw & 0x1FFu) - 256;
+        // the successor's height and move word in ONE round trip
+        float zt;
+        uint32_t mwn;
+        {
+          uint32_t a4 = lds0 + ((uint32_t)np << 2), a2 = lds0 + ((uint32_t)np << 1);
+          asm volatile("ds_read_b32 %0, %2\n\tds_read_u16 %1, %3 offset:%4\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(zt), "=&v"(mwn)
+                       : "v"(a4), "v"(a2), "n"(DW_WIN * DW_WIN * 4)
+                       : "memory");
+        }
+        dist += (mw & MW_DIAG) ? ddiag : dcard;
+        drop = z0 - zt;
+        pos = np;
+        mw = mwn;
+        loop++;
+        running = drop < dzf && !(mw & MW_STOP);
       }
-      bool nod = !stop && zt == DT_NODATA;  // :231-281: stop without moving
-      bool ok = !stop && !nod;
-      nodata_ahead = nodata_ahead || nod;
-      dist += ok ? ((mw & MW_DIAG) ? ddiag : dcard) : 0.0;
-      drop = ok ? z0 - zt : drop;
-      pos = ok ? np : pos;
-      mw = ok ? mwn : mw;
-      loop += ok ? 1 : 0;
-      running = ok && loop != 5000 && drop < dzf;
     }
-    if (loop == 5000 || nodata_ahead) failed = true;  // :303-304 / :518-521 (cap precedes the drop test)
-    else if (drop < dzf) {
-      // stopped on a move word: a non-D8 code never moves again (the reference spins to its cap),
-      // a move off the raster stops the walk (downslope.py:209-228); the ring continues below
-      if (mw & (MW_BADCODE | MW_EDGE)) failed = true;
+    if (drop < dzf) {
+      // :303-304 / :518-521: 5000 moves without reaching the drop (the cap precedes the drop test, but a
+      // lane that reached the drop on its 5000th move is also failed by the reference)
+      if (loop == 5000) failed = true;
+      // stopped on a move word: a non-D8 code never moves again (the reference spins to its cap), a move
+      // off the raster or onto nodata stops the walk (downslope.py:209-281); the ring continues below
+      else if (mw & (MW_BADCODE | MW_EDGE | MW_NODATA)) failed = true;
       else slow = true;
+    } else if (loop == 5000) {
+      failed = true;
     }
     if (slow) {  // on the window ring: finish on global memory
       int y = wy0 + pos / DW_WIN, x = wx0 + pos % DW_WIN;
