@@ -110,20 +110,21 @@ __device__ __forceinline__ uint32_t dt_tile_next(uint32_t code, int ly, int lx, 
 #define PT_EXIT 0x4000u
 #define PT_IDX 0x0FFFu
 
-__device__ __forceinline__ void dt_tile_sums(uint16_t *s_ptr, uint32_t *s_val, uint32_t *s_recv,
-                                             uint8_t *s_cyc) {
-  uint16_t np[CPT];
+// One LDS word per cell: val:16 (<= 4096 in pass 1) | ptr bits:16, so a round is 5-6 LDS instructions
+// per cell (own word, scatter atomic, gather, received sum, write back) instead of 8.
+__device__ __forceinline__ void dt_tile_sums(uint32_t *s_pv, uint32_t *s_recv, uint8_t *s_cyc) {
+  uint32_t pv[CPT], np[CPT];
   for (int round = 0; round < 12; round++) {
     int any = 0;
 #pragma unroll
     for (int j = 0; j < CPT; j++) {
       int c = threadIdx.x + 256 * j;
-      uint32_t p = s_ptr[c];
-      np[j] = (uint16_t)p;
-      if (p & PT_ALIVE) {
-        uint32_t t = p & PT_IDX;
-        atomicAdd(&s_recv[t], s_val[c]);
-        np[j] = s_ptr[t];
+      pv[j] = s_pv[c];
+      np[j] = pv[j] & 0xFFFFu;
+      if (pv[j] & PT_ALIVE) {
+        uint32_t t = pv[j] & PT_IDX;
+        atomicAdd(&s_recv[t], pv[j] >> 16);
+        np[j] = s_pv[t] & 0xFFFFu;
         any = 1;
       }
     }
@@ -132,11 +133,8 @@ __device__ __forceinline__ void dt_tile_sums(uint16_t *s_ptr, uint32_t *s_val, u
     for (int j = 0; j < CPT; j++) {
       int c = threadIdx.x + 256 * j;
       uint32_t r = s_recv[c];
-      if (r) {
-        s_val[c] += r;
-        s_recv[c] = 0;
-      }
-      s_ptr[c] = np[j];
+      if (r) s_recv[c] = 0;
+      s_pv[c] = (((pv[j] >> 16) + r) << 16) | np[j];
     }
     if (!__syncthreads_or(any)) return;
   }
@@ -144,7 +142,7 @@ __device__ __forceinline__ void dt_tile_sums(uint16_t *s_ptr, uint32_t *s_val, u
 #pragma unroll
   for (int j = 0; j < CPT; j++) {
     int c = threadIdx.x + 256 * j;
-    uint32_t p = s_ptr[c];
+    uint32_t p = s_pv[c];
     if (p & PT_ALIVE) s_cyc[p & PT_IDX] = 1;
   }
   __syncthreads();
@@ -170,8 +168,7 @@ __global__ __launch_bounds__(256) void k_fa_tile1(const uint8_t *__restrict__ fd
                                                  unsigned long long *__restrict__ rec,
                                                  int32_t *__restrict__ acc32) {
   __shared__ __attribute__((aligned(16))) uint8_t s_fdr[NT];  // reused as the in-tile cycle mask
-  __shared__ uint16_t s_ptr[NT];                               // idx:12 | PT_EXIT | PT_ALIVE
-  __shared__ uint32_t s_val[NT];
+  __shared__ uint32_t s_pv[NT];  // val:16 | idx:12 | PT_EXIT | PT_ALIVE
   __shared__ uint32_t s_recv[NT];
   const int tile = blockIdx.x;
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
@@ -200,30 +197,29 @@ __global__ __launch_bounds__(256) void k_fa_tile1(const uint8_t *__restrict__ fd
     // terminals point at themselves; an exit terminal carries PT_EXIT, which every cell whose
     // in-tile path ends there inherits through the jumps
     bool ex = (n == NX_EXIT || n == NX_REXIT);
-    s_ptr[c] = (uint16_t)(n < NT ? (n | PT_ALIVE) : ((uint32_t)c | (ex ? PT_EXIT : 0u)));
-    s_val[c] = 1u;
+    s_pv[c] = (1u << 16) | (n < NT ? (n | PT_ALIVE) : ((uint32_t)c | (ex ? PT_EXIT : 0u)));
     s_recv[c] = 0u;
     s_cyc[c] = 0;
   }
   __syncthreads();
-  dt_tile_sums(s_ptr, s_val, s_recv, s_cyc);
+  dt_tile_sums(s_pv, s_recv, s_cyc);
   if (threadIdx.x < PS) {
     int ly, lx;
     dt_cell_of_slot(threadIdx.x, ly, lx);
     int c = ly * TW + lx;
-    uint32_t p = s_ptr[c];
+    uint32_t p = s_pv[c];
     uint32_t xs = X_NONE;
     if (!(p & PT_ALIVE) && (p & PT_EXIT)) {
       uint32_t f = p & PT_IDX;
       xs = (uint32_t)dt_slot_of((int)f / TW, (int)f % TW);
     }
-    rec[(size_t)tile * PS + threadIdx.x] = fa_rec(my_code ? s_val[c] : 0u, xs, my_code, my_flags);
+    rec[(size_t)tile * PS + threadIdx.x] = fa_rec(my_code ? (p >> 16) : 0u, xs, my_code, my_flags);
   }
   // in-tile accumulation (upstream cells of this tile only); pass 3 adds what enters from outside
   for (int j = 0; j < CPT; j++) {
     int c = threadIdx.x + 256 * j;
     int y = y0 + c / TW, x = x0 + c % TW;
-    if (y < w.H && x < w.W) acc32[(long long)y * w.ld + x] = s_cyc[c] ? -100 : (int32_t)(s_val[c] - 1u);
+    if (y < w.H && x < w.W) acc32[(long long)y * w.ld + x] = s_cyc[c] ? -100 : (int32_t)((s_pv[c] >> 16) - 1u);
   }
 }
 
