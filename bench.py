@@ -44,7 +44,7 @@ OP_KERNELS = {
     "gfi_lnhlh": ["k_gfi_both"],
     "downslope": ["k_downslope_win"],
 }
-PMC_FILE = os.path.join(ROOT, "profiles", "r1", "v2_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r1", "v3_pmc_traffic.json")
 
 
 def pmc_traffic(op, size):
