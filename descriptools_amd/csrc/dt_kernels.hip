@@ -200,6 +200,17 @@ __device__ __forceinline__ void dt_twi_cell(int64_t fac, float srad, double lnpx
     mti = DT_NODATA;
     return;
   }
+  // float32 fast path (dt_math.h): valid arguments and results away from zero
+  if (fac >= 0 && fac < (1ll << 40) && srad >= 0.0f && srad <= 1.2f) {
+    double la = (fac == 0 ? 0.0 : dt_lnf((float)fac)) + lnpx2;
+    double lt = dt_lntanf((double)srad + 0.01);
+    double a = la - lt, b = n * la - lt;
+    if (fabs(a) >= DT_FAST_MIN && fabs(b) >= DT_FAST_MIN) {
+      ti = (float)a;
+      mti = (float)b;
+      return;
+    }
+  }
   double la = (fac == 0 ? 0.0 : dt_fast_log((double)fac, s_tab)) + lnpx2;
   double lt = dt_fast_lntan((double)srad + 0.01, s_tab);
   ti = (float)(la - lt);
@@ -211,6 +222,7 @@ __device__ __forceinline__ void dt_twi_cell(int64_t fac, float srad, double lnpx
 __device__ __forceinline__ float dt_slope_rad(float slope_pct, float dem) {
   if (dem == DT_NODATA) return DT_NODATA;
   float q = slope_pct / 100.0f;
+  if (q >= 0.0f && q < 1e30f) return (float)dt_atanf_pos(q);
   return (float)dt_fast_atan((double)q);
 }
 
@@ -655,38 +667,82 @@ __global__ __launch_bounds__(256) void k_gfi(const float *__restrict__ hand,
     return;
   }
   IT ar = area[i];
+  if (h > -0.005f && ar >= 0 && (ar > 0 || OWN_CELL)) {  // float32 fast path (dt_math.h)
+    double la = ar == 0 ? 0.0 : dt_lnf((float)ar);
+    double r = c0 + expo * la - dt_lnf((float)((double)h + 0.01));
+    if (fabs(r) >= DT_FAST_MIN) {
+      out[i] = (float)r;
+      return;
+    }
+  }
   double la = (OWN_CELL && ar == 0) ? 0.0 : dt_fast_log((double)ar, s_tab);
   out[i] = (float)(c0 + expo * la - dt_fast_log((double)h + 0.01, s_tab));
 }
 // GFI and ln(hl/H) in one pass: hand is read once and ln(h + 0.01) evaluated once (3 logs / cell
 // instead of 4, 12 + 4 bytes / cell instead of 24)
+__device__ __forceinline__ void dt_gfi_both_cell(float h, int32_t ar, int32_t f, double expo, double c0,
+                                                 const DtLogEntry *s_tab, float &g_out, float &l_out) {
+  if (h <= DT_NODATA) {
+    g_out = DT_NODATA;
+    l_out = DT_NODATA;
+    return;
+  }
+  if (h > -0.005f && ar > 0 && f >= 0) {  // float32 fast path (dt_math.h)
+    double lh = c0 - dt_lnf((float)((double)h + 0.01));
+    double g = lh + expo * dt_lnf((float)ar);
+    double l = lh + (f == 0 ? 0.0 : expo * dt_lnf((float)f));
+    if (fabs(g) >= DT_FAST_MIN && fabs(l) >= DT_FAST_MIN) {
+      g_out = (float)g;
+      l_out = (float)l;
+      return;
+    }
+  }
+  double lh = c0 - dt_fast_log((double)h + 0.01, s_tab);
+  g_out = (float)(lh + expo * dt_fast_log((double)ar, s_tab));
+  l_out = (float)(lh + (f == 0 ? 0.0 : expo * dt_fast_log((double)f, s_tab)));
+}
+
+// 4 cells per thread with 16-byte loads / stores, grid-stride (the table is staged once per workgroup)
 __global__ __launch_bounds__(256) void k_gfi_both(const float *__restrict__ hand,
                                                  const int32_t *__restrict__ a_river,
                                                  const int32_t *__restrict__ fac, int64_t n, double expo,
                                                  double c0, float *__restrict__ gfi,
                                                  float *__restrict__ lnhlh,
-                                                 const DtLogEntry *__restrict__ g_tab) {
+                                                 const DtLogEntry *__restrict__ g_tab, int vec_ok) {
   __shared__ DtLogEntry s_tab[DT_LOGTAB_N];
   dt_math_stage(g_tab, s_tab);
   __syncthreads();
-  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  float h = hand[i];
-  if (h <= DT_NODATA) {
-    gfi[i] = DT_NODATA;
-    lnhlh[i] = DT_NODATA;
-    return;
+  const int64_t stride = (int64_t)gridDim.x * 1024;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+    if (vec_ok && i + 3 < n) {
+      float4 h = *reinterpret_cast<const float4 *>(hand + i);
+      int4 ar = *reinterpret_cast<const int4 *>(a_river + i);
+      int4 f = *reinterpret_cast<const int4 *>(fac + i);
+      float4 g, l;
+      dt_gfi_both_cell(h.x, ar.x, f.x, expo, c0, s_tab, g.x, l.x);
+      dt_gfi_both_cell(h.y, ar.y, f.y, expo, c0, s_tab, g.y, l.y);
+      dt_gfi_both_cell(h.z, ar.z, f.z, expo, c0, s_tab, g.z, l.z);
+      dt_gfi_both_cell(h.w, ar.w, f.w, expo, c0, s_tab, g.w, l.w);
+      *reinterpret_cast<float4 *>(gfi + i) = g;
+      *reinterpret_cast<float4 *>(lnhlh + i) = l;
+    } else {
+      for (int k = 0; k < 4 && i + k < n; k++) {
+        float g, l;
+        dt_gfi_both_cell(hand[i + k], a_river[i + k], fac[i + k], expo, c0, s_tab, g, l);
+        gfi[i + k] = g;
+        lnhlh[i + k] = l;
+      }
+    }
   }
-  double lh = c0 - dt_fast_log((double)h + 0.01, s_tab);
-  int32_t f = fac[i];
-  gfi[i] = (float)(lh + expo * dt_fast_log((double)a_river[i], s_tab));
-  lnhlh[i] = (float)(lh + (f == 0 ? 0.0 : expo * dt_fast_log((double)f, s_tab)));
 }
 int dt_launch_gfi_both(hipStream_t s, const float *hand, const int32_t *a_river, const int32_t *fac,
                        int64_t n, double expo, double b, double size, float *gfi, float *lnhlh) {
   if (n == 0) return DT_OK;
-  hipLaunchKernelGGL(k_gfi_both, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, hand, a_river, fac, n,
-                     expo, log(b) + expo * log(size * size), gfi, lnhlh, dt_math_device_table(s));
+  int vec_ok = (((uintptr_t)hand | (uintptr_t)a_river | (uintptr_t)fac | (uintptr_t)gfi | (uintptr_t)lnhlh) & 15) == 0;
+  int64_t blocks = (n + 1023) / 1024;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(k_gfi_both, dim3((unsigned)blocks), dim3(256), 0, s, hand, a_river, fac, n, expo,
+                     log(b) + expo * log(size * size), gfi, lnhlh, dt_math_device_table(s), vec_ok);
   return DT_OK;
 }
 

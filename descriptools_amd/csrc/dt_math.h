@@ -91,3 +91,59 @@ __device__ __forceinline__ double dt_fast_atan(double q) {
   for (int k = DT_ATAN_DEG - 1; k >= 0; k--) h = fma(h, t, dt_atan_c[k]);
   return fma(sgn * x, h, base);
 }
+
+// ---------------------------------------------------------------------------------------------------
+// float32 fast path.  The descriptors are rounded to float32 and must stay within 1e-5 relative of the
+// reference: each logarithm below is  e * ln2  (exact exponent, float64)  +  log2(mantissa) * ln2
+// (hardware v_log_f32 on [0.5, 1): absolute error <= 6e-8), so a sum of three of them is good to
+// ~2e-7 ABSOLUTE whatever the magnitude of the arguments.  Callers use the result only when
+// |result| >= DT_FAST_MIN (relative error <= 1e-6) and recompute with the float64 routines above
+// otherwise (results near a zero crossing, out-of-domain arguments).  ~8 instructions per logarithm
+// instead of ~20 float64 ones: this is what lets the fused slope+TI+MTI and GFI kernels run at the
+// HBM rate instead of the float64 ALU rate.
+// ---------------------------------------------------------------------------------------------------
+#define DT_FAST_MIN 0.25
+
+// ln(x) for a positive, finite, normal float x
+__device__ __forceinline__ double dt_lnf(float x) {
+  float m = __builtin_amdgcn_frexp_mantf(x);  // [0.5, 1)
+  int e = __builtin_amdgcn_frexp_expf(x);
+  return fma((double)e, 0.6931471805599453, (double)__log2f(m) * 0.6931471805599453);
+}
+
+// ln(tan(y)) for y in [0.005, 1.25] (y given in float64: theta + 0.01)
+__device__ __forceinline__ double dt_lntanf(double y) {
+  const double HALF_PI = 1.5707963267948966;
+  bool lo = y <= 0.7853981633974483;
+  float z = (float)(lo ? y : HALF_PI - y);
+  float t = fmaf(z * z, (float)DT_LNTAN_SCALE, -1.0f);
+  float g = dt_lntan_c32[6];
+#pragma unroll
+  for (int k = 5; k >= 0; k--) g = fmaf(g, t, dt_lntan_c32[k]);
+  double r = dt_lnf(z) + (double)g;
+  return lo ? r : -r;
+}
+
+// atan(q), q >= 0 float32: reduction as dt_fast_atan with float32 division, degree-5 polynomial; the
+// last multiply-add is float64 so that the result rounds to float32 within ~1 ulp
+__device__ __forceinline__ double dt_atanf_pos(float q) {
+  const float T8 = 0.41421356f, T38 = 2.41421356f;
+  float x;
+  double base, sgn = 1.0;
+  if (q <= T8) {
+    x = q;
+    base = 0.0;
+  } else if (q < T38) {
+    x = (q - 1.0f) / (q + 1.0f);
+    base = 0.7853981633974483;
+  } else {
+    x = 1.0f / q;
+    base = 1.5707963267948966;
+    sgn = -1.0;
+  }
+  float t = fmaf(x * x, (float)DT_ATAN_SCALE, -1.0f);
+  float h = dt_atan_c32[5];
+#pragma unroll
+  for (int k = 4; k >= 0; k--) h = fmaf(h, t, dt_atan_c32[k]);
+  return fma(sgn * (double)x, (double)h, base);
+}
