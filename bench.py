@@ -27,9 +27,9 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 
 # op -> (algorithmic bytes per cell).  "d8" writes fdr only (slope comes out of the
-# fused slope+TWI stencil: dem 4 + fac 4 read, slope 4 + slope_rad 4 + TI 4 + MTI 4 written; the
-# north_star's 20 B/cell figure counts slope+TI+MTI, slope_rad is an extra 4 B we also write).
-OPS = [("d8", 5), ("flowacc_river", 5 + 1), ("flowhand", 18 + 4), ("slope_twi", 20 + 4),
+# fused slope+TWI stencil: dem 4 + fac 4 read, slope 4 + TI 4 + MTI 4 written = the north_star's
+# 20 B/cell; the slope-in-radians raster is an optional extra output that the chain does not need).
+OPS = [("d8", 5), ("flowacc_river", 5 + 1), ("flowhand", 18 + 4), ("slope_twi", 20),
        ("gfi_lnhlh", 4 + 4 + 4 + 4 + 4), ("downslope", 9)]
 
 
@@ -40,7 +40,7 @@ OP_KERNELS = {
     "flowacc_river": ["k_fa_tile1", "k_fa_link", "k_fa_reduce", "k_fa_poison", "k_fa_tile3<true, true>",
                       "__amd_rocclr_fillBufferAligned"],
     "flowhand": ["k_fh_tile1", "k_fh_ghost_init", "k_fh_node_jump", "k_fh_tile3"],
-    "slope_twi": ["k_stencil<true, false, true, true>"],
+    "slope_twi": ["k_stencil<true, false, false, true>"],
     "gfi_lnhlh": ["k_gfi_both"],
     "downslope": ["k_downslope_win"],
 }
@@ -148,7 +148,7 @@ def main():
             ("flowhand", lambda: L.dt_dev_flowhand(c, dem.data_ptr(), p("fdr"), p("river"), p("fac"), H, W,
                                                    ch.px, p("fdist"), p("idx"), p("hand"), p("a_river"))),
             ("slope_twi", lambda: L.dt_dev_slope_twi(c, dem.data_ptr(), p("fac"), H, W, ch.px, ch.n_top,
-                                                     p("slope"), p("slope_rad"), p("ti"), p("mti"))),
+                                                     p("slope"), None, p("ti"), p("mti"))),
             ("gfi_lnhlh", lambda: L.dt_dev_gfi_lnhlh(c, p("hand"), p("a_river"), p("fac"), N, ch.n_gfi, ch.b,
                                                      ch.px, p("gfi"), p("lnhlh"))),
             ("downslope", lambda: L.dt_dev_downslope(c, dem.data_ptr(), p("fdr"), H, W, ch.px, ch.dz, 0,

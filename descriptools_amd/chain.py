@@ -23,7 +23,8 @@ class Chain:
     """Owns the output rasters of one H x W tile on one device."""
 
     def __init__(self, H, W, ctx=None, px=10.0, n_top=0.1, n_gfi=0.4, b=0.1, dz=5.0,
-                 river_threshold=None, alloc=None):
+                 river_threshold=None, alloc=None, want_slope_rad=True):
+        self.want_slope_rad = want_slope_rad
         self.H, self.W, self.N = int(H), int(W), int(H) * int(W)
         self.ctx = ctx or Context()
         self.px, self.n_top, self.n_gfi, self.b, self.dz = px, n_top, n_gfi, b, dz
@@ -45,7 +46,7 @@ class Chain:
         check(L.dt_dev_flowhand(c, dem_ptr, p("fdr"), p("river"), p("fac"), H, W, self.px, p("fdist"),
                                 p("idx"), p("hand"), p("a_river")))
         check(L.dt_dev_slope_twi(c, dem_ptr, p("fac"), H, W, self.px, self.n_top, p("slope"),
-                                 p("slope_rad"), p("ti"), p("mti")))
+                                 p("slope_rad") if self.want_slope_rad else None, p("ti"), p("mti")))
         check(L.dt_dev_gfi_lnhlh(c, p("hand"), p("a_river"), p("fac"), N, self.n_gfi, self.b, self.px,
                                  p("gfi"), p("lnhlh")))
         check(L.dt_dev_downslope(c, dem_ptr, p("fdr"), H, W, self.px, self.dz, 0, p("down")))

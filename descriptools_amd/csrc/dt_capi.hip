@@ -378,6 +378,14 @@ extern "C" int dt_dev_minmax_scale_f32(dt_ctx *c, const float *x, int64_t N, flo
   return DT_OK;
 }
 
+extern "C" int dt_dev_membench_copy(dt_ctx *c, const float *a, float *b, int64_t N, int blocks) {
+  DT_CTX(c);
+  DT_REQUIRE(a && b && N >= 0 && blocks > 0, "bad arguments");
+  DT_TRY(dt_launch_membench_copy(c->stream, a, b, N, blocks));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+
 extern "C" int dt_dev_i32_to_i64(dt_ctx *c, const int32_t *src, int64_t N, int64_t *dst) {
   DT_CTX(c);
   DT_TRY(dt_launch_i32_to_i64(c->stream, src, N, dst));

@@ -59,3 +59,4 @@ int dt_launch_gfi_both(hipStream_t s, const float *hand, const int32_t *a_river,
 int dt_launch_unique_extremes(hipStream_t s, const float *x, int64_t n, uint32_t *work4, float *out3);
 int dt_launch_minmax_scale(hipStream_t s, const float *x, int64_t n, float mn, float mx, float nodata,
                            double *out);
+int dt_launch_membench_copy(hipStream_t s, const float *a, float *b, int64_t n, int blocks);

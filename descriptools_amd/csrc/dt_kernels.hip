@@ -125,7 +125,9 @@ struct SlopeCell {
   uint8_t code;
 };
 
-// scan positions: NW0 N1 NE2 W3 E4 SW5 S6 SE7
+// scan positions: NW0 N1 NE2 W3 E4 SW5 S6 SE7.  NEED_CODE = false (slope only): the D8 bookkeeping
+// (which neighbour, scan position for ties) is skipped -- the slope value does not depend on it.
+template <bool NEED_CODE>
 __device__ __forceinline__ SlopeCell dt_slope_cell(float c, float nw, float n, float ne, float w,
                                                   float e, float sw, float s, float se,
                                                   double inv_card, double inv_diag, double dcard,
@@ -140,6 +142,7 @@ __device__ __forceinline__ SlopeCell dt_slope_cell(float c, float nw, float n, f
   float cb = 0.0f, db = 0.0f;
   int cpos = 8, dpos = 8;
   uint32_t ccode = 0, dcode = 0;
+  if (NEED_CODE) {
 #define DT_CAND(nb, best, bcode, bpos, code_, pos_) \
   {                                                 \
     float d_ = c - (nb);                            \
@@ -149,15 +152,21 @@ __device__ __forceinline__ SlopeCell dt_slope_cell(float c, float nw, float n, f
       bpos = pos_;                                  \
     }                                               \
   }
-  DT_CAND(n, cb, ccode, cpos, 64u, 1)
-  DT_CAND(w, cb, ccode, cpos, 16u, 3)
-  DT_CAND(e, cb, ccode, cpos, 1u, 4)
-  DT_CAND(s, cb, ccode, cpos, 4u, 6)
-  DT_CAND(nw, db, dcode, dpos, 32u, 0)
-  DT_CAND(ne, db, dcode, dpos, 128u, 2)
-  DT_CAND(sw, db, dcode, dpos, 8u, 5)
-  DT_CAND(se, db, dcode, dpos, 2u, 7)
+    DT_CAND(n, cb, ccode, cpos, 64u, 1)
+    DT_CAND(w, cb, ccode, cpos, 16u, 3)
+    DT_CAND(e, cb, ccode, cpos, 1u, 4)
+    DT_CAND(s, cb, ccode, cpos, 4u, 6)
+    DT_CAND(nw, db, dcode, dpos, 32u, 0)
+    DT_CAND(ne, db, dcode, dpos, 128u, 2)
+    DT_CAND(sw, db, dcode, dpos, 8u, 5)
+    DT_CAND(se, db, dcode, dpos, 2u, 7)
 #undef DT_CAND
+  } else {
+#define DT_DIFF(nb) ((nb) != DT_NODATA ? c - (nb) : 0.0f)
+    cb = fmaxf(fmaxf(fmaxf(DT_DIFF(n), DT_DIFF(w)), fmaxf(DT_DIFF(e), DT_DIFF(s))), 0.0f);
+    db = fmaxf(fmaxf(fmaxf(DT_DIFF(nw), DT_DIFF(ne)), fmaxf(DT_DIFF(sw), DT_DIFF(se))), 0.0f);
+#undef DT_DIFF
+  }
   // Exact float64 divisions are ~15 instructions each.  Fast path: multiply by the (correctly rounded)
   // reciprocals -- within 3 float64 ulp of the reference's quotient -- and accept the result only if
   // neither the cardinal / diagonal comparison nor the final float32 rounding can be affected by
@@ -304,6 +313,27 @@ __global__ __launch_bounds__(256) void k_stencil(const float *__restrict__ dem, 
     dst[4] = m.w;
     dst[5] = p[4];
   };
+  // flow accumulation of my 4 x 4 patch: four 16-byte loads issued up front (latency hidden behind the
+  // stencil arithmetic) instead of sixteen 4-byte loads inside the loop
+  int4 facv[4];
+  if (W_TWI) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      int gy = y0 + ry + j;
+      facv[j] = make_int4(-100, -100, -100, -100);
+      if (gy < H) {
+        const int32_t *pf = acc32 + (long long)gy * w.ld + gx;
+        if (vec_ok && gx + 3 < W) {
+          facv[j] = *reinterpret_cast<const int4 *>(pf);
+        } else {
+          if (gx < W) facv[j].x = pf[0];
+          if (gx + 1 < W) facv[j].y = pf[1];
+          if (gx + 2 < W) facv[j].z = pf[2];
+          if (gx + 3 < W) facv[j].w = pf[3];
+        }
+      }
+    }
+  }
   load_row(ry, a);       // row above the first output row (tile row ry == raster row y0-1+ry)
   load_row(ry + 1, bb);  // first output row
 #pragma unroll
@@ -315,7 +345,7 @@ __global__ __launch_bounds__(256) void k_stencil(const float *__restrict__ dem, 
       uint32_t codes = 0;
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        SlopeCell sc = dt_slope_cell(bb[k + 1], a[k], a[k + 1], a[k + 2], bb[k], bb[k + 2], cc[k],
+        SlopeCell sc = dt_slope_cell<W_FDR>(bb[k + 1], a[k], a[k + 1], a[k + 2], bb[k], bb[k + 2], cc[k],
                                      cc[k + 1], cc[k + 2], inv_card, inv_diag, dcard, ddiag);
         so[k] = sc.slope;
         uint32_t code = sc.code;
@@ -332,9 +362,8 @@ __global__ __launch_bounds__(256) void k_stencil(const float *__restrict__ dem, 
         }
         if (W_RAD || W_TWI) ro[k] = dt_slope_rad(sc.slope, bb[k + 1]);
         if (W_TWI) {
-          int xx = gx + k;
-          int64_t f = xx < W ? (int64_t)acc32[(long long)gy * w.ld + xx] : -100;
-          dt_twi_cell(f, ro[k], lnpx2, n_top, tio[k], mtio[k], s_tab);
+          int32_t f32v = k == 0 ? facv[j].x : (k == 1 ? facv[j].y : (k == 2 ? facv[j].z : facv[j].w));
+          dt_twi_cell((int64_t)f32v, ro[k], lnpx2, n_top, tio[k], mtio[k], s_tab);
         }
       }
       long long o = (long long)gy * w.ld + gx;
@@ -1199,6 +1228,28 @@ int dt_launch_minmax_scale(hipStream_t s, const float *x, int64_t n, float mn, f
                            double *out) {
   if (n) hipLaunchKernelGGL(k_minmax_scale, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n, mn, mx,
                             nodata, out);
+  return DT_OK;
+}
+
+// ---- HBM copy micro-benchmark (the practical bandwidth ceiling the roofline fractions compare with) ----
+template <int UNROLL>
+__global__ __launch_bounds__(256) void k_membench_copy(const float4 *__restrict__ a, float4 *__restrict__ b,
+                                                      int64_t n4) {
+  int64_t stride = (int64_t)gridDim.x * 256 * UNROLL;
+  for (int64_t i = (int64_t)blockIdx.x * 256 * UNROLL + threadIdx.x; i < n4; i += stride) {
+    float4 v[UNROLL];
+#pragma unroll
+    for (int k = 0; k < UNROLL; k++)
+      if (i + k * 256 < n4) v[k] = a[i + k * 256];
+#pragma unroll
+    for (int k = 0; k < UNROLL; k++)
+      if (i + k * 256 < n4) b[i + k * 256] = v[k];
+  }
+}
+int dt_launch_membench_copy(hipStream_t s, const float *a, float *b, int64_t n, int blocks) {
+  int64_t n4 = n / 4;
+  if (n4 == 0) return DT_OK;
+  hipLaunchKernelGGL(k_membench_copy<4>, dim3((unsigned)blocks), dim3(256), 0, s, (const float4 *)a, (float4 *)b, n4);
   return DT_OK;
 }
 

@@ -214,6 +214,10 @@ int dt_dev_unique_extremes_f32(dt_ctx *ctx, const float *x, int64_t N, float *ou
 int dt_dev_minmax_scale_f32(dt_ctx *ctx, const float *x, int64_t N, float mn, float mx, float nodata,
                             double *desc);
 
+/* float4 grid-stride copy of N floats with `blocks` workgroups: the practical HBM ceiling on this device,
+ * reported by tools/stencil_bench.py next to the kernels' rates */
+int dt_dev_membench_copy(dt_ctx *ctx, const float *a, float *b, int64_t N, int blocks);
+
 /* widen / narrow helpers for the int64 API dtypes */
 int dt_dev_i32_to_i64(dt_ctx *ctx, const int32_t *src, int64_t N, int64_t *dst);
 int dt_dev_i64_to_i32(dt_ctx *ctx, const int64_t *src, int64_t N, int32_t *dst);
