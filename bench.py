@@ -202,6 +202,19 @@ def main():
                     "stream, timed region); traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 summed over the op's "
                     "kernels, from separate rocprofv3 --pmc runs committed under profiles/"}
 
+    # practical HBM ceiling of this device: a float4 grid-stride copy through the same library
+    src, dst = alloc((H, W), np.float32), alloc((H, W), np.float32)
+    for _ in range(2):
+        _lib.check(L.dt_dev_membench_copy(c, src.data_ptr(), dst.data_ptr(), N, 65536))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(5):
+        _lib.check(L.dt_dev_membench_copy(c, src.data_ptr(), dst.data_ptr(), N, 65536))
+    e1.record(stream)
+    torch.cuda.synchronize()
+    copy_gbs = N * 8 * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del src, dst
+
     cells = N * world
     value = cells * args.steps / dt / 1e6
     out = {
@@ -216,6 +229,7 @@ def main():
                    "parallelism": "1 tile per GPU" if world > 1 else "single GPU"},
         "roofline": roof,
         "per_op": per_op,
+        "hbm_copy_ceiling_GBs": round(copy_gbs, 1),
         "chain_algo_bytes_per_cell": chain.ALGO_BYTES_PER_CELL,
         "chain_frac_of_hbm_peak": round(cells * args.steps * chain.ALGO_BYTES_PER_CELL / dt / 1e9 / world
                                         / HBM_PEAK_GBS, 4),

@@ -623,25 +623,28 @@ __device__ __forceinline__ void fht_solve_tile(const FhTile &T, const uint8_t *_
     T.s_st[c] = s;
   }
   __syncthreads();
-  // pointer doubling in place; an in-tile cycle doubles its counts until they exceed the cap
-  for (int round = 0; round < 16; round++) {
+  // Pointer doubling in place.  The low 32 bits hold n_diag:16 | done:1 | n_card:15, so ONE integer add
+  // of the two low words adds both move counts and inherits the target's done bit (in-tile counts stay
+  // below 2^13: no carry into the done bit or between the fields).  An acyclic in-tile path has < 4096
+  // moves and is finished after 12 rounds; whatever is still unfinished after 13 runs into an in-tile D8
+  // cycle and is dead (the reference's revisit test / move cap, flowhand.py:830-837).
+  for (int round = 0; round < 13; round++) {
     int changed = 0;
+#pragma unroll
     for (int j = 0; j < CPT; j++) {
       int c = threadIdx.x + 256 * j;
       unsigned long long s = T.s_st[c];
-      uint32_t ncf = (uint32_t)(s & 0xFFFFu);
-      if (ncf & FHT_DONE) continue;
-      uint32_t ptr = (uint32_t)(s >> 32), nd = (uint32_t)((s >> 16) & 0xFFFFu);
-      unsigned long long t = T.s_st[ptr & 0xFFFu];
-      uint32_t tncf = (uint32_t)(t & 0xFFFFu);
-      uint32_t nnc = ncf + (tncf & 0x7FFFu), nnd = nd + (uint32_t)((t >> 16) & 0xFFFFu);
-      unsigned long long o;
-      if (nnc + nnd > FHT_CAP) o = fht_pack((uint32_t)c | (K_DEAD << 12), 0, FHT_DONE);
-      else o = fht_pack((uint32_t)(t >> 32), nnd, nnc | (tncf & FHT_DONE));
-      T.s_st[c] = o;
+      if ((uint32_t)s & FHT_DONE) continue;
+      unsigned long long t = T.s_st[(uint32_t)(s >> 32) & 0xFFFu];
+      T.s_st[c] = (t & 0xFFFFFFFF00000000ull) | (unsigned long long)((uint32_t)s + (uint32_t)t);
       changed = 1;
     }
     if (!__syncthreads_or(changed)) break;
+  }
+#pragma unroll
+  for (int j = 0; j < CPT; j++) {
+    int c = threadIdx.x + 256 * j;
+    if (!((uint32_t)T.s_st[c] & FHT_DONE)) T.s_st[c] = fht_pack((uint32_t)c | (K_DEAD << 12), 0, FHT_DONE);
   }
   __syncthreads();
 }
