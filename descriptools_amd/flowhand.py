@@ -36,6 +36,15 @@ def hand_calculator(dem, indices):
     return hand.astype(_hand_dtype(dem))
 
 
+def index_calculator(river_indices, row_start, column_start, column_size):
+    """flowhand.py:445-472 (unused by the reference itself): tile-local flat river indices ->
+    indices of the whole raster; -100 stays -100.  Pure index arithmetic (host)."""
+    river_indices = np.asarray(river_indices)
+    col = river_indices.shape[1]
+    return np.where(river_indices == -100, -100,
+                    (np.floor(river_indices / col) + row_start) * column_size + river_indices % col + column_start)
+
+
 def flow_distance_index_cpu(dem, flow_direction, river_matrix, px, boundary_distance, boundary_index,
                             out, row_start, col_start, matrix_columns, blocks=0, threads=0):
     """flowhand.py:476-562 for a tile without neighbouring tiles (out == 0 on all four sides, the

@@ -60,3 +60,7 @@ def geomorphic_flood_index_sequential_jit(hand, river_flow_accumulation, expoent
 def ln_hl_H_sequential_jit(hand, flow_accumulation, expoent, scale_factor, size):
     """Name of gfi.py:65; HIP path, kernel semantics."""
     return ln_hl_H_cpu(hand, flow_accumulation, expoent, scale_factor, size)
+
+
+geomorphic_flood_index_sequential = geomorphic_flood_index_sequential_jit
+ln_hl_H_sequential = ln_hl_H_sequential_jit

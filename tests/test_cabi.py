@@ -89,3 +89,58 @@ def test_evaluation_host_functions_match_golden():
         assert c == float(g["e%d_c" % k]) and f == float(g["e%d_f" % k])
         assert np.array_equal(cm, g["e%d_class" % k])
         assert np.array_equal(flood, g["e%d_flood_after" % k])
+
+
+def test_python_api_mirrors_reference_names():
+    """every public (non-kernel) function name of the reference's modules exists with the
+    same positional parameters in descriptools_amd."""
+    import inspect
+    import importlib
+    expected = {
+        "slope": {"sloper": ["dem", "px", "division_column", "division_row"],
+                  "slope_cpu": ["dem", "px", "extra", "blocks", "threads"],
+                  "slope_sequential_jit": None, "slope_sequential": None},
+        "flowhand": {"flow_hand_index": ["dem_raster", "flow_direction_matrix", "river_matrix", "px",
+                                         "division_column", "division_row"],
+                     "hand_calculator": ["dem", "indices"],
+                     "index_calculator": ["river_indices", "row_start", "column_start", "column_size"],
+                     "flow_distance_index_cpu": ["dem", "flow_direction", "river_matrix", "px",
+                                                 "boundary_distance", "boundary_index", "out", "row_start",
+                                                 "col_start", "matrix_columns", "blocks", "threads"],
+                     "flow_distance_indexes_sequential": None, "fdist_indexes_sequential_jit": None},
+        "topoindexes": {"topographic_index": ["flow_accumulation", "slope", "px", "n_top", "div_col", "div_row"],
+                        "topographic_index_cpu": ["flow_accumulation", "slope", "px", "expoent", "blocks",
+                                                  "threads"],
+                        "topographic_index_sequential": None, "topographic_index_sequential_jit": None,
+                        "modified_topographic_index_sequential": None,
+                        "modified_topographic_index_sequential_jit": None},
+        "gfi": {"gfi_calculator": ["hand", "flow_accumulation", "indices", "n_gfi", "scale_factor", "size",
+                                   "division_column", "division_row"],
+                "river_accumulation": ["flow_accumulation", "indices"],
+                "geomorphic_flood_index_cpu": ["hand", "river_flow_accumulation", "expoent", "scale_factor",
+                                               "size", "blocks", "threads"],
+                "ln_hl_H_calculator": ["hand", "flow_accumulation", "n_gfi", "scale_factor", "size",
+                                       "division_column", "division_row"],
+                "ln_hl_H_cpu": ["hand", "flow_accumulation", "expoent", "scale_factor", "size", "blocks",
+                                "threads"],
+                "geomorphic_flood_index_sequential": None, "geomorphic_flood_index_sequential_jit": None,
+                "ln_hl_H_sequential": None, "ln_hl_H_sequential_jit": None},
+        "downslope": {"downsloper": ["dem", "flow_direction", "px", "elevation_difference", "column_division",
+                                     "row_division"],
+                      "downslope_cpu": ["dem", "flow_direction", "px", "elevation_difference", "blocks",
+                                        "threads"],
+                      "downslope_sequential_jit": None, "downslope_sequential": None},
+        "evaluation": {"minMaxScale": ["mat", "mn", "mx", "nodata"],
+                       "calibration": ["descriptor_matrix", "comparison_matrix", "under"],
+                       "binary_map": ["descriptor_matrix", "threshold", "under"],
+                       "avaliacao": ["descriptor_flood_map", "comparison_flood_map"],
+                       "correctness": ["count"], "fit": ["count"]},
+        "helpers": {"divisor": ["row_length", "column_length", "row_division", "column_division"]},
+    }
+    for mod, funcs in expected.items():
+        m = importlib.import_module("descriptools_amd." + mod)
+        for name, params in funcs.items():
+            assert hasattr(m, name), "%s.%s missing" % (mod, name)
+            if params is not None:
+                got = list(inspect.signature(getattr(m, name)).parameters)
+                assert got == params, "%s.%s%s != %s" % (mod, name, got, params)
