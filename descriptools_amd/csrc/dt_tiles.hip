@@ -112,29 +112,40 @@ __device__ __forceinline__ uint32_t dt_tile_next(uint32_t code, int ly, int lx, 
 
 // One LDS word per cell: val:16 (<= 4096 in pass 1) | ptr bits:16, so a round is 5-6 LDS instructions
 // per cell (own word, scatter atomic, gather, received sum, write back) instead of 8.
+// Each lane owns PAIRS of adjacent cells (2 * (t + 256 j), +1) so that its own words and received sums
+// move with 64-bit LDS instructions; only the scatter atomic and the gather are per cell.
 __device__ __forceinline__ void dt_tile_sums(uint32_t *s_pv, uint32_t *s_recv, uint8_t *s_cyc) {
-  uint32_t pv[CPT], np[CPT];
+  uint2 pv[CPT / 2], np[CPT / 2];
+  uint2 *s_pv2 = reinterpret_cast<uint2 *>(s_pv);
+  uint2 *s_recv2 = reinterpret_cast<uint2 *>(s_recv);
   for (int round = 0; round < 12; round++) {
     int any = 0;
 #pragma unroll
-    for (int j = 0; j < CPT; j++) {
-      int c = threadIdx.x + 256 * j;
-      pv[j] = s_pv[c];
-      np[j] = pv[j] & 0xFFFFu;
-      if (pv[j] & PT_ALIVE) {
-        uint32_t t = pv[j] & PT_IDX;
-        atomicAdd(&s_recv[t], pv[j] >> 16);
-        np[j] = s_pv[t] & 0xFFFFu;
+    for (int j = 0; j < CPT / 2; j++) {
+      int c2 = threadIdx.x + 256 * j;
+      pv[j] = s_pv2[c2];
+      np[j].x = pv[j].x & 0xFFFFu;
+      np[j].y = pv[j].y & 0xFFFFu;
+      if (pv[j].x & PT_ALIVE) {
+        uint32_t t = pv[j].x & PT_IDX;
+        atomicAdd(&s_recv[t], pv[j].x >> 16);
+        np[j].x = s_pv[t] & 0xFFFFu;
+        any = 1;
+      }
+      if (pv[j].y & PT_ALIVE) {
+        uint32_t t = pv[j].y & PT_IDX;
+        atomicAdd(&s_recv[t], pv[j].y >> 16);
+        np[j].y = s_pv[t] & 0xFFFFu;
         any = 1;
       }
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < CPT; j++) {
-      int c = threadIdx.x + 256 * j;
-      uint32_t r = s_recv[c];
-      if (r) s_recv[c] = 0;
-      s_pv[c] = (((pv[j] >> 16) + r) << 16) | np[j];
+    for (int j = 0; j < CPT / 2; j++) {
+      int c2 = threadIdx.x + 256 * j;
+      uint2 r = s_recv2[c2];
+      if (r.x | r.y) s_recv2[c2] = make_uint2(0u, 0u);
+      s_pv2[c2] = make_uint2((((pv[j].x >> 16) + r.x) << 16) | np[j].x, (((pv[j].y >> 16) + r.y) << 16) | np[j].y);
     }
     if (!__syncthreads_or(any)) return;
   }
@@ -168,8 +179,8 @@ __global__ __launch_bounds__(256) void k_fa_tile1(const uint8_t *__restrict__ fd
                                                  unsigned long long *__restrict__ rec,
                                                  int32_t *__restrict__ acc32) {
   __shared__ __attribute__((aligned(16))) uint8_t s_fdr[NT];  // reused as the in-tile cycle mask
-  __shared__ uint32_t s_pv[NT];  // val:16 | idx:12 | PT_EXIT | PT_ALIVE
-  __shared__ uint32_t s_recv[NT];
+  __shared__ __attribute__((aligned(16))) uint32_t s_pv[NT];  // val:16 | idx:12 | PT_EXIT | PT_ALIVE
+  __shared__ __attribute__((aligned(16))) uint32_t s_recv[NT];
   const int tile = blockIdx.x;
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int y0 = ty * TH, x0 = tx * TW;
@@ -586,11 +597,15 @@ __device__ __forceinline__ void fht_solve_tile(const FhTile &T, const uint8_t *_
     if (dt_readable(w, y, x)) v = fdr[(long long)y * w.ld + x];
     T.s_halo[i] = v;
   }
-  uint32_t riv = 0;  // river mask of my 16 cells (row-contiguous per wave)
+  // river mask: staged through the word array with 16-byte row loads (it is free until the words are
+  // built), then picked up as one bit per owned cell
+  uint8_t *s_riv = reinterpret_cast<uint8_t *>(T.s_st);
+  dt_tile_load_fdr(reinterpret_cast<const uint8_t *>(river), w, y0, x0, s_riv);
+  __syncthreads();
+  uint32_t riv = 0;
   for (int j = 0; j < CPT; j++) {
     int c = threadIdx.x + 256 * j;
-    int y = y0 + c / TW, x = x0 + c % TW;
-    if (y < w.H && x < w.W && river[(long long)y * w.ld + x] == 1) riv |= 1u << j;
+    if (s_riv[c] == 1) riv |= 1u << j;
   }
   __syncthreads();
   for (int j = 0; j < CPT; j++) {
@@ -628,15 +643,24 @@ __device__ __forceinline__ void fht_solve_tile(const FhTile &T, const uint8_t *_
   // below 2^13: no carry into the done bit or between the fields).  An acyclic in-tile path has < 4096
   // moves and is finished after 12 rounds; whatever is still unfinished after 13 runs into an in-tile D8
   // cycle and is dead (the reference's revisit test / move cap, flowhand.py:830-837).
+  ulonglong2 *s_st2 = reinterpret_cast<ulonglong2 *>(T.s_st);  // lane owns adjacent cell pairs
   for (int round = 0; round < 13; round++) {
     int changed = 0;
 #pragma unroll
-    for (int j = 0; j < CPT; j++) {
-      int c = threadIdx.x + 256 * j;
-      unsigned long long s = T.s_st[c];
-      if ((uint32_t)s & FHT_DONE) continue;
-      unsigned long long t = T.s_st[(uint32_t)(s >> 32) & 0xFFFu];
-      T.s_st[c] = (t & 0xFFFFFFFF00000000ull) | (unsigned long long)((uint32_t)s + (uint32_t)t);
+    for (int j = 0; j < CPT / 2; j++) {
+      int c2 = threadIdx.x + 256 * j;
+      ulonglong2 s = s_st2[c2];
+      bool dx = ((uint32_t)s.x & FHT_DONE) != 0u, dy = ((uint32_t)s.y & FHT_DONE) != 0u;
+      if (dx && dy) continue;
+      if (!dx) {
+        unsigned long long t = T.s_st[(uint32_t)(s.x >> 32) & 0xFFFu];
+        s.x = (t & 0xFFFFFFFF00000000ull) | (unsigned long long)((uint32_t)s.x + (uint32_t)t);
+      }
+      if (!dy) {
+        unsigned long long t = T.s_st[(uint32_t)(s.y >> 32) & 0xFFFu];
+        s.y = (t & 0xFFFFFFFF00000000ull) | (unsigned long long)((uint32_t)s.y + (uint32_t)t);
+      }
+      s_st2[c2] = s;
       changed = 1;
     }
     if (!__syncthreads_or(changed)) break;
@@ -659,7 +683,7 @@ __global__ __launch_bounds__(256) void k_fh_tile1(const uint8_t *__restrict__ fd
                                                  unsigned long long *__restrict__ cache) {
   __shared__ __attribute__((aligned(16))) uint8_t s_fdr[NT];
   __shared__ uint8_t s_halo[2 * (TW + 2) + 2 * TH];
-  __shared__ unsigned long long s_st[NT];
+  __shared__ __attribute__((aligned(16))) unsigned long long s_st[NT];
   const int tile = blockIdx.x;
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int y0 = ty * TH, x0 = tx * TW;
