@@ -39,6 +39,8 @@ extern "C" int dt_ctx_create(int device, void *stream, dt_ctx **out) {
   c->scratch = nullptr;
   c->scratch_bytes = 0;
   c->scratch_used = 0;
+  c->scratch2 = nullptr;
+  c->scratch2_bytes = 0;
   if (stream) {
     c->stream = (hipStream_t)stream;
     c->own_stream = false;
@@ -60,6 +62,7 @@ extern "C" int dt_ctx_destroy(dt_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   if (c->scratch) (void)hipFree(c->scratch);
+  if (c->scratch2) (void)hipFree(c->scratch2);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return DT_OK;
@@ -501,6 +504,49 @@ extern "C" int dt_dev_flowhand_finish_w(dt_ctx *c, const dt_window *win, const f
   DT_TRY(dt_launch_fh_finish(c->stream, w, dem, fdr, river, acc32, px, c->scratch, res_ok, res_nc, res_nd,
                              (const long long *)rem_gidx, rem_zr, rem_ar, fdist, idx32, (long long *)idx64, hand,
                              a_river));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+
+static int dt_scratch2_reserve(dt_ctx *c, size_t bytes) {
+  if (bytes > c->scratch2_bytes) {
+    DT_HIP(hipStreamSynchronize(c->stream));
+    if (c->scratch2) DT_HIP(hipFree(c->scratch2));
+    c->scratch2 = nullptr;
+    c->scratch2_bytes = 0;
+    DT_HIP(hipMalloc((void **)&c->scratch2, bytes));
+    c->scratch2_bytes = bytes;
+  }
+  return DT_OK;
+}
+
+extern "C" int dt_dev_rank_solve_flowacc(dt_ctx *c, int ty, int tx, const int64_t *heights, const int64_t *widths,
+                                         int64_t Pmax, const void *rows_dev, int64_t rowbytes,
+                                         const int64_t *field_offsets3, int rank, int64_t P_rank,
+                                         uint64_t *ext_out_dev) {
+  DT_CTX(c);
+  DT_REQUIRE(heights && widths && rows_dev && field_offsets3 && ext_out_dev, "NULL pointer");
+  DT_REQUIRE(rank >= 0 && rank < ty * tx && P_rank >= 0 && P_rank <= Pmax, "bad rank / ring size");
+  DT_TRY(dt_scratch2_reserve(c, dt_rank_solve_scratch(ty * tx, Pmax)));
+  DT_TRY(dt_launch_rank_solve_flowacc(c->stream, ty, tx, heights, widths, Pmax, rows_dev, rowbytes, field_offsets3,
+                                      rank, P_rank, c->scratch2, (unsigned long long *)ext_out_dev));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+
+extern "C" int dt_dev_rank_solve_flowhand(dt_ctx *c, int ty, int tx, const int64_t *heights, const int64_t *widths,
+                                          int64_t Pmax, const void *rows_dev, int64_t rowbytes,
+                                          const int64_t *field_offsets7, int rank, int64_t P_rank,
+                                          uint8_t *res_ok, int32_t *res_nc, int32_t *res_nd, int64_t *rem_gidx,
+                                          float *rem_zr, int32_t *rem_ar) {
+  DT_CTX(c);
+  DT_REQUIRE(heights && widths && rows_dev && field_offsets7 && res_ok && res_nc && res_nd && rem_gidx && rem_zr &&
+                 rem_ar, "NULL pointer");
+  DT_REQUIRE(rank >= 0 && rank < ty * tx && P_rank >= 0 && P_rank <= Pmax, "bad rank / ring size");
+  DT_TRY(dt_scratch2_reserve(c, dt_rank_solve_scratch(ty * tx, Pmax)));
+  DT_TRY(dt_launch_rank_solve_flowhand(c->stream, ty, tx, heights, widths, Pmax, rows_dev, rowbytes,
+                                       field_offsets7, rank, P_rank, c->scratch2, res_ok, res_nc, res_nd,
+                                       (long long *)rem_gidx, rem_zr, rem_ar));
   DT_HIP(hipGetLastError());
   return DT_OK;
 }

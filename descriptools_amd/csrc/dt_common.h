@@ -44,6 +44,8 @@ struct dt_ctx {
   char *scratch;
   size_t scratch_bytes;
   size_t scratch_used;  // bump pointer, reset at the start of every entry point
+  char *scratch2;       // rank-level solves (must not disturb the two-phase tile scratch)
+  size_t scratch2_bytes;
 };
 
 // grow-only scratch, bump-allocated per entry point (256-B aligned)

@@ -60,3 +60,12 @@ int dt_launch_unique_extremes(hipStream_t s, const float *x, int64_t n, uint32_t
 int dt_launch_minmax_scale(hipStream_t s, const float *x, int64_t n, float mn, float mx, float nodata,
                            double *out);
 int dt_launch_membench_copy(hipStream_t s, const float *a, float *b, int64_t n, int blocks);
+// rank-level solves on all-gathered summary rows (multi-GPU)
+size_t dt_rank_solve_scratch(int nranks, int64_t Pmax);
+int dt_launch_rank_solve_flowacc(hipStream_t s, int ty, int tx, const int64_t *heights, const int64_t *widths,
+                                 int64_t Pmax, const void *rows, int64_t rowbytes, const int64_t *offs, int rank,
+                                 int64_t P_rank, void *scratch, unsigned long long *ext_out);
+int dt_launch_rank_solve_flowhand(hipStream_t s, int ty, int tx, const int64_t *heights, const int64_t *widths,
+                                  int64_t Pmax, const void *rows, int64_t rowbytes, const int64_t *offs, int rank,
+                                  int64_t P_rank, void *scratch, uint8_t *res_ok, int32_t *res_nc,
+                                  int32_t *res_nd, long long *gidx, float *zr, int32_t *ar);

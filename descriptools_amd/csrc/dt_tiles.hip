@@ -1003,3 +1003,231 @@ int dt_launch_fh_finish(hipStream_t s, const DtWin &w, const float *dem, const u
                      rem, px, fdist, idx32, idx64, hand, a_river);
   return DT_OK;
 }
+
+// ===========================================================================================
+// Rank level (multi-GPU): the small graph over the core-ring cells of ALL ranks, solved redundantly
+// on every GPU from the all-gathered summary rows.  Same algorithms as the tile level: in-degree
+// countdown with packed 64-bit atomics for the flow-accumulation inflow, pointer doubling for HAND.
+// Node id = rank * Pmax + ring index.
+// ===========================================================================================
+#define RK_MAX 64
+struct RkLayout {
+  int ty, tx, nranks;
+  long long Pmax;
+  int ys[RK_MAX + 1], xs[RK_MAX + 1];  // cumulative row / column origins of the rank grid
+  int Hg, Wg;
+};
+__device__ __forceinline__ void rk_rank_geom(const RkLayout &L, int r, int &y0, int &x0, int &H, int &W) {
+  int ry = r / L.tx, rx = r - ry * L.tx;
+  y0 = L.ys[ry];
+  x0 = L.xs[rx];
+  H = L.ys[ry + 1] - y0;
+  W = L.xs[rx + 1] - x0;
+}
+// node of the ring cell that the D8 step `code` from ring cell i of rank r lands on, or -1 when the step
+// stays inside the rank / leaves the global raster / the code is not a D8 code
+__device__ __forceinline__ long long rk_step_target(const RkLayout &L, int r, long long i, uint32_t code) {
+  if (!dt_d8_valid(code)) return -1;
+  int y0, x0, H, W;
+  rk_rank_geom(L, r, y0, x0, H, W);
+  if (i >= dt_perim_count(H, W)) return -1;
+  int y, x, dy, dx;
+  dt_perim_cell(H, W, i, y, x);
+  dt_d8_delta(code, dy, dx);
+  int ty = y + dy, tx = x + dx;
+  if (ty >= 0 && ty < H && tx >= 0 && tx < W) return -1;
+  int gy = y0 + ty, gx = x0 + tx;
+  if (gy < 0 || gy >= L.Hg || gx < 0 || gx >= L.Wg) return -1;
+  int ry = 0, rx = 0;
+  while (gy >= L.ys[ry + 1]) ry++;
+  while (gx >= L.xs[rx + 1]) rx++;
+  int r2 = ry * L.tx + rx, y2, x2, H2, W2;
+  rk_rank_geom(L, r2, y2, x2, H2, W2);
+  return (long long)r2 * L.Pmax + dt_perim_index(H2, W2, gy - y2, gx - x2);
+}
+
+struct RkRows {  // one all-gathered byte row per rank: field k of rank r at buf + r * rowbytes + off[k]
+  const unsigned char *buf;
+  long long rowbytes;
+  long long off[8];
+};
+template <typename T>
+__device__ __forceinline__ T rk_get(const RkRows &R, int field, int r, long long i) {
+  return reinterpret_cast<const T *>(R.buf + (long long)r * R.rowbytes + R.off[field])[i];
+}
+
+// ---- flow accumulation: rows = {A int64, xr int32, code uint8} --------------------------------------
+__global__ __launch_bounds__(256) void k_rk_fa_link(RkLayout L, RkRows R, int32_t *__restrict__ entry_of,
+                                                   int32_t *__restrict__ parent,
+                                                   unsigned long long *__restrict__ state) {
+  long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (n >= (long long)L.nranks * L.Pmax) return;
+  int r = (int)(n / L.Pmax);
+  long long i = n - (long long)r * L.Pmax;
+  long long e = rk_step_target(L, r, i, rk_get<uint8_t>(R, 2, r, i));
+  int32_t par = -1;
+  if (e >= 0) {
+    int r2 = (int)(e / L.Pmax);
+    int32_t xr = rk_get<int32_t>(R, 1, r2, e - (long long)r2 * L.Pmax);
+    if (xr >= 0) {
+      par = (int32_t)((long long)r2 * L.Pmax + xr);
+      atomicAdd(&state[par], 1ull << FA2_SH);
+    }
+  }
+  entry_of[n] = (int32_t)e;
+  parent[n] = par;
+}
+__global__ __launch_bounds__(256) void k_rk_fa_reduce(RkLayout L, RkRows R, const int32_t *__restrict__ entry_of,
+                                                     const int32_t *__restrict__ parent,
+                                                     unsigned long long *__restrict__ state,
+                                                     unsigned long long *__restrict__ ext) {
+  long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+  long long nn = (long long)L.nranks * L.Pmax;
+  if (n >= nn) return;
+  if (entry_of[n] < 0) return;   // not a rank exit
+  if (state[n] != 0ull) return;  // not a source
+  long long q = n;
+  int rq = (int)(q / L.Pmax);
+  unsigned long long A = (unsigned long long)rk_get<long long>(R, 0, rq, q - (long long)rq * L.Pmax);
+  for (long long it = 0; it < nn; it++) {
+    atomicAdd(&ext[entry_of[q]], A);
+    int32_t p = parent[q];
+    if (p < 0) break;
+    unsigned long long old = atomicAdd(&state[p], A - (1ull << FA2_SH));
+    if ((old >> FA2_SH) != 1ull) break;
+    int rp = (int)(p / L.Pmax);
+    A = (unsigned long long)rk_get<long long>(R, 0, rp, p - (long long)rp * L.Pmax) + (old & FA2_MASK) + A;
+    q = p;
+  }
+}
+__global__ __launch_bounds__(256) void k_rk_fa_poison(RkLayout L, const int32_t *__restrict__ entry_of,
+                                                     const unsigned long long *__restrict__ state,
+                                                     unsigned long long *__restrict__ ext) {
+  long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (n >= (long long)L.nranks * L.Pmax) return;
+  if (entry_of[n] >= 0 && (state[n] >> FA2_SH) != 0ull) atomicOr(&ext[entry_of[n]], FA_CYCLE);
+}
+
+static int rk_make_layout(int ty, int tx, const int64_t *heights, const int64_t *widths, int64_t Pmax,
+                          RkLayout *L) {
+  DT_REQUIRE(ty >= 1 && tx >= 1 && ty <= RK_MAX && tx <= RK_MAX, "rank grid too large");
+  L->ty = ty;
+  L->tx = tx;
+  L->nranks = ty * tx;
+  L->Pmax = Pmax;
+  L->ys[0] = L->xs[0] = 0;
+  for (int i = 0; i < ty; i++) L->ys[i + 1] = L->ys[i] + (int)heights[i];
+  for (int i = 0; i < tx; i++) L->xs[i + 1] = L->xs[i] + (int)widths[i];
+  L->Hg = L->ys[ty];
+  L->Wg = L->xs[tx];
+  return DT_OK;
+}
+
+size_t dt_rank_solve_scratch(int nranks, int64_t Pmax) {
+  size_t nn = (size_t)nranks * (size_t)Pmax;
+  return dt_align256(nn * 8) * 3 + dt_align256(nn * 4) * 2 + 256;
+}
+
+// ext_out[i] (device, P_rank entries) = inflow arriving at ring cell i of `rank` (bit 63 = cycle)
+int dt_launch_rank_solve_flowacc(hipStream_t s, int ty, int tx, const int64_t *heights, const int64_t *widths,
+                                 int64_t Pmax, const void *rows, int64_t rowbytes, const int64_t *offs, int rank,
+                                 int64_t P_rank, void *scratch, unsigned long long *ext_out) {
+  RkLayout L;
+  DT_TRY(rk_make_layout(ty, tx, heights, widths, Pmax, &L));
+  RkRows R;
+  R.buf = (const unsigned char *)rows;
+  R.rowbytes = rowbytes;
+  for (int k = 0; k < 8; k++) R.off[k] = k < 3 ? offs[k] : 0;
+  size_t nn = (size_t)L.nranks * (size_t)Pmax;
+  if (nn == 0) return DT_OK;
+  char *p = (char *)scratch;
+  unsigned long long *state = (unsigned long long *)p;  p += dt_align256(nn * 8);
+  unsigned long long *ext = (unsigned long long *)p;  p += dt_align256(nn * 8);
+  p += dt_align256(nn * 8);
+  int32_t *entry_of = (int32_t *)p;  p += dt_align256(nn * 4);
+  int32_t *parent = (int32_t *)p;
+  DT_HIP(hipMemsetAsync(state, 0, dt_align256(nn * 8) * 2, s));
+  dim3 g((unsigned)((nn + 255) / 256)), b(256);
+  hipLaunchKernelGGL(k_rk_fa_link, g, b, 0, s, L, R, entry_of, parent, state);
+  hipLaunchKernelGGL(k_rk_fa_reduce, g, b, 0, s, L, R, entry_of, parent, state, ext);
+  hipLaunchKernelGGL(k_rk_fa_poison, g, b, 0, s, L, entry_of, state, ext);
+  DT_HIP(hipMemcpyAsync(ext_out, ext + (size_t)rank * Pmax, (size_t)P_rank * 8, hipMemcpyDeviceToDevice, s));
+  return DT_OK;
+}
+
+// ---- HAND: rows = {ref int32, nc int32, nd int32, zr float, ar int32, kind uint8, ringcode uint8} ----
+__global__ __launch_bounds__(256) void k_rk_fh_build(RkLayout L, RkRows R, unsigned long long *__restrict__ nodes) {
+  long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (n >= (long long)L.nranks * L.Pmax) return;
+  int r = (int)(n / L.Pmax);
+  long long i = n - (long long)r * L.Pmax;
+  uint32_t kind = rk_get<uint8_t>(R, 5, r, i);
+  unsigned long long o = fht_pack(FHT_DEAD, 0, FHT_DONE);
+  if (kind == K_RIVER) {
+    o = fht_pack((uint32_t)n, (uint32_t)rk_get<int32_t>(R, 2, r, i), (uint32_t)rk_get<int32_t>(R, 1, r, i) | FHT_DONE);
+  } else if (kind == K_REXIT) {
+    long long ex = rk_get<int32_t>(R, 0, r, i);  // ring index of the exit cell in the same rank
+    long long e = rk_step_target(L, r, ex, rk_get<uint8_t>(R, 6, r, ex));
+    if (e >= 0) o = fht_pack((uint32_t)e, (uint32_t)rk_get<int32_t>(R, 2, r, i), (uint32_t)rk_get<int32_t>(R, 1, r, i));
+  }
+  nodes[n] = o;
+}
+__global__ __launch_bounds__(256) void k_rk_fh_result(RkLayout L, RkRows R, const unsigned long long *__restrict__ nodes,
+                                                     int rank, long long P_rank, uint8_t *__restrict__ res_ok,
+                                                     int32_t *__restrict__ res_nc, int32_t *__restrict__ res_nd,
+                                                     long long *__restrict__ gidx, float *__restrict__ zr,
+                                                     int32_t *__restrict__ ar) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= P_rank) return;
+  uint8_t ok = 0;
+  int32_t c = 0, d = 0, a = 0;
+  long long g = -100;
+  float z = DT_NODATA;
+  long long e = rk_step_target(L, rank, i, rk_get<uint8_t>(R, 6, rank, i));
+  if (e >= 0) {
+    unsigned long long wd = nodes[e];
+    uint32_t ptr = (uint32_t)(wd >> 32), ncf = (uint32_t)(wd & 0xFFFFu);
+    if ((ncf & FHT_DONE) && ptr != FHT_DEAD) {
+      ok = 1;
+      c = (int32_t)(ncf & 0x7FFFu);
+      d = (int32_t)((wd >> 16) & 0xFFFFu);
+      int rt = (int)(ptr / (uint32_t)L.Pmax);
+      long long it = (long long)ptr - (long long)rt * L.Pmax;
+      int y0, x0, H, W;
+      rk_rank_geom(L, rt, y0, x0, H, W);
+      int ref = rk_get<int32_t>(R, 0, rt, it);  // core-local flat index of the river cell
+      g = (long long)(y0 + ref / W) * L.Wg + x0 + ref % W;
+      z = rk_get<float>(R, 3, rt, it);
+      a = rk_get<int32_t>(R, 4, rt, it);
+    }
+  }
+  res_ok[i] = ok;
+  res_nc[i] = c;
+  res_nd[i] = d;
+  gidx[i] = g;
+  zr[i] = z;
+  ar[i] = a;
+}
+
+int dt_launch_rank_solve_flowhand(hipStream_t s, int ty, int tx, const int64_t *heights, const int64_t *widths,
+                                  int64_t Pmax, const void *rows, int64_t rowbytes, const int64_t *offs, int rank,
+                                  int64_t P_rank, void *scratch, uint8_t *res_ok, int32_t *res_nc,
+                                  int32_t *res_nd, long long *gidx, float *zr, int32_t *ar) {
+  RkLayout L;
+  DT_TRY(rk_make_layout(ty, tx, heights, widths, Pmax, &L));
+  RkRows R;
+  R.buf = (const unsigned char *)rows;
+  R.rowbytes = rowbytes;
+  for (int k = 0; k < 8; k++) R.off[k] = k < 7 ? offs[k] : 0;
+  size_t nn = (size_t)L.nranks * (size_t)Pmax;
+  if (nn == 0 || P_rank == 0) return DT_OK;
+  DT_REQUIRE(nn < 0x7FFFFFF0ull, "too many ring cells");
+  unsigned long long *nodes = (unsigned long long *)scratch;
+  dim3 g((unsigned)((nn + 255) / 256)), b(256);
+  hipLaunchKernelGGL(k_rk_fh_build, g, b, 0, s, L, R, nodes);
+  // every hop between ranks is >= 1 move: 15 doublings cover the 20000-move cap
+  for (int r = 0; r < 15; r++) hipLaunchKernelGGL(k_fh_node_jump, g, b, 0, s, nodes, (int64_t)nn);
+  hipLaunchKernelGGL(k_rk_fh_result, dim3((unsigned)((P_rank + 255) / 256)), b, 0, s, L, R, nodes, rank,
+                     (long long)P_rank, res_ok, res_nc, res_nd, gidx, zr, ar);
+  return DT_OK;
+}

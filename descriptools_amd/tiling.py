@@ -247,6 +247,14 @@ def solve_flowhand(layout, summaries, ring_codes):
 # ---------------------------------------------------------------------------------------------------
 # one rank's tile on its GPU
 # ---------------------------------------------------------------------------------------------------
+# summary-row fields: (name, dtype, byte offset in units of pmax)
+FA_FIELDS = (("A", "int64", 0), ("xr", "int32", 8), ("code", "uint8", 12), ("ring", "uint8", 13))
+FA_ROW_BYTES = 16
+FH_FIELDS = (("ref", "int32", 0), ("nc", "int32", 4), ("nd", "int32", 8), ("zr", "float32", 12),
+             ("ar", "int32", 16), ("kind", "uint8", 20), ("ring", "uint8", 21))
+FH_ROW_BYTES = 24
+
+
 class RankTile:
     """Extended rasters ((H + 2*HALO) x (W + 2*HALO)) of one rank and the windowed library calls."""
 
@@ -277,6 +285,34 @@ class RankTile:
         self.win = _lib.Window(self.H, self.W, self.We, self.gy0, self.gx0, layout.Hg, layout.Wg, halo)
         ys, xs = ring_coords(self.H, self.W)
         self._ring_lin = torch.as_tensor((ys + halo) * self.We + xs + halo, device=self.dev)
+        # summary rows, laid out for the all-gather and for the rank-level solves on the GPU: every field
+        # has pmax entries (pmax = the largest ring of any rank, rounded up to 8 so fields stay aligned)
+        pm = max(perim_count(*layout.shape(r)) for r in range(layout.size))
+        self.pmax = pm = (pm + 7) // 8 * 8
+        self.fa_row = torch.zeros(FA_ROW_BYTES * pm, dtype=torch.uint8, device=self.dev)
+        self.fh_row = torch.zeros(FH_ROW_BYTES * pm, dtype=torch.uint8, device=self.dev)
+        self._fa_v = self._row_views(self.fa_row, FA_FIELDS)
+        self._fh_v = self._row_views(self.fh_row, FH_FIELDS)
+        self._fa_offs = (C.c_int64 * 3)(*[o * pm for _, _, o in FA_FIELDS[:3]])
+        self._fh_offs = (C.c_int64 * 7)(*[o * pm for _, _, o in FH_FIELDS])
+        self._heights = (C.c_int64 * layout.ty)(*layout.heights)
+        self._widths = (C.c_int64 * layout.tx)(*layout.widths)
+        self._ext = torch.zeros(max(self.P, 1), dtype=torch.int64, device=self.dev)
+        self._res = (torch.zeros(max(self.P, 1), dtype=torch.uint8, device=self.dev),
+                     torch.zeros(max(self.P, 1), dtype=torch.int32, device=self.dev),
+                     torch.zeros(max(self.P, 1), dtype=torch.int32, device=self.dev),
+                     torch.zeros(max(self.P, 1), dtype=torch.int64, device=self.dev),
+                     torch.zeros(max(self.P, 1), dtype=torch.float32, device=self.dev),
+                     torch.zeros(max(self.P, 1), dtype=torch.int32, device=self.dev))
+
+    def _row_views(self, row, fields):
+        tc, pm = self.torch, self.pmax
+        v = {}
+        for name, dt, off in fields:
+            tdt = getattr(tc, dt)
+            es = tc.empty(0, dtype=tdt).element_size()
+            v[name] = row[off * pm:(off + es) * pm].view(tdt)[:self.P]
+        return v
 
     # pointer of raster `name` at the core origin
     def p(self, name):
@@ -330,10 +366,8 @@ class RankTile:
         return self.ring_codes_dev().cpu().numpy()
 
     def fa_local(self, sync=True):
-        tc = self.torch
-        A = tc.empty(self.P, dtype=tc.int64, device=self.dev)
-        xr = tc.empty(self.P, dtype=tc.int32, device=self.dev)
-        code = tc.empty(self.P, dtype=tc.uint8, device=self.dev)
+        v = self._fa_v
+        A, xr, code = v["A"], v["xr"], v["code"]
         self._chk(self.L.dt_dev_flowacc_local_w(self.ctx.h, C.byref(self.win), self.p("fdr"), self.p("fac"),
                                                 A.data_ptr(), xr.data_ptr(), code.data_ptr()))
         if sync:
@@ -348,11 +382,39 @@ class RankTile:
                                                  e.data_ptr() if e is not None else None,
                                                  self.river_threshold, self.p("fac"), self.p("river")))
 
+    def fill_ring_codes(self):
+        """D8 codes of the ring cells into both summary rows (the rank-level solves step across ranks with them)."""
+        rc = self.ring_codes_dev()
+        self._fa_v["ring"].copy_(rc)
+        self._fh_v["ring"].copy_(rc)
+
+    def fa_solve_finish(self, rows):
+        """rank-level inflow solve on the GPU from the all-gathered rows (size x FA_ROW_BYTES*pmax bytes,
+        device), then pass 3.  No host synchronisation."""
+        self._keep_rows = rows
+        self._chk(self.L.dt_dev_rank_solve_flowacc(self.ctx.h, self.layout.ty, self.layout.tx, self._heights,
+                                                   self._widths, self.pmax, rows.data_ptr(),
+                                                   FA_ROW_BYTES * self.pmax, self._fa_offs, self.rank, self.P,
+                                                   self._ext.data_ptr()))
+        self._chk(self.L.dt_dev_flowacc_finish_w(self.ctx.h, C.byref(self.win), self.p("fdr"), self.p("dem"),
+                                                 self._ext.data_ptr(), self.river_threshold, self.p("fac"),
+                                                 self.p("river")))
+
+    def fh_solve_finish(self, rows):
+        self._keep_rows2 = rows
+        r = self._res
+        self._chk(self.L.dt_dev_rank_solve_flowhand(self.ctx.h, self.layout.ty, self.layout.tx, self._heights,
+                                                    self._widths, self.pmax, rows.data_ptr(),
+                                                    FH_ROW_BYTES * self.pmax, self._fh_offs, self.rank, self.P,
+                                                    *[a.data_ptr() for a in r]))
+        self._chk(self.L.dt_dev_flowhand_finish_w(self.ctx.h, C.byref(self.win), self.p("dem"), self.p("fdr"),
+                                                  self.p("river"), self.p("fac"), self.px,
+                                                  *[a.data_ptr() for a in r], self.p("fdist"), None,
+                                                  self.p("idx"), self.p("hand"), self.p("a_river")))
+
     def fh_local(self, sync=True):
-        tc = self.torch
-        kind = tc.empty(self.P, dtype=tc.uint8, device=self.dev)
-        ref, nc, nd, ar = (tc.empty(self.P, dtype=tc.int32, device=self.dev) for _ in range(4))
-        zr = tc.empty(self.P, dtype=tc.float32, device=self.dev)
+        v = self._fh_v
+        kind, ref, nc, nd, zr, ar = v["kind"], v["ref"], v["nc"], v["nd"], v["zr"], v["ar"]
         self._chk(self.L.dt_dev_flowhand_local_w(self.ctx.h, C.byref(self.win), self.p("dem"), self.p("fdr"),
                                                  self.p("river"), self.p("fac"), kind.data_ptr(),
                                                  ref.data_ptr(), nc.data_ptr(), nd.data_ptr(), zr.data_ptr(),
@@ -494,59 +556,72 @@ def exchange_halo(ext, layout, rank, halo=HALO, group=None):
 
 class Exchange:
     """The two all-gathers of a step, issued on a SIDE stream behind an event, so that kernels queued
-    on the main stream after the summaries keep the GPU busy while the ring rows travel (RCCL) and
-    the rank-level graph is solved on the host."""
+    on the main stream after the summaries keep the GPU busy while the ring rows travel (RCCL).  The
+    gathered rows stay on the device: the rank-level graphs are solved there (dt_dev_rank_solve_*), the
+    main stream only waits on an event, the host never blocks."""
 
     def __init__(self, tile, layout, world, group=None):
         self.tile, self.layout, self.world, self.group = tile, layout, world, group
-        self.torch = tile.torch
-        self.side = self.torch.cuda.Stream(device=tile.dev)
+        tc = self.torch = tile.torch
+        self.side = tc.cuda.Stream(device=tile.dev)
+        n = layout.size
+        self.fa_all = tc.zeros(n * tile.fa_row.numel(), dtype=tc.uint8, device=tile.dev)
+        self.fh_all = tc.zeros(n * tile.fh_row.numel(), dtype=tc.uint8, device=tile.dev)
 
-    def gather_after(self, event, arrs):
+    def gather(self, row, out):
+        """all-gather `row` into `out` behind the main stream's current work; the main stream resumes
+        after the gather.  Work queued on the main stream BEFORE the returned wait overlaps it."""
         tc = self.torch
+        main = tc.cuda.current_stream(self.tile.dev)
+        if self.world == 1:
+            return row
+        import torch.distributed as dist
+        ev = tc.cuda.Event()
+        ev.record(main)
+        if dist.get_backend(self.group) == "gloo":  # CPU rehearsal of the RCCL path
+            ev.synchronize()
+            h = tc.empty(out.numel(), dtype=tc.uint8)
+            dist.all_gather_into_tensor(h, row.cpu(), group=self.group)
+            out.copy_(h)
+            return out
         with tc.cuda.stream(self.side):
-            self.side.wait_event(event)
-            for a in arrs:
-                a.record_stream(self.side)
-            if self.world == 1:
-                host = [a.to("cpu", non_blocking=True) for a in arrs]
-                self.side.synchronize()
-                return [tuple(h.numpy() for h in host)]
-            out = all_gather_summaries(arrs, self.layout, self.tile.rank, self.group)
-            self.side.synchronize()
+            self.side.wait_event(ev)
+            dist.all_gather_into_tensor(out, row, group=self.group)
+            done = tc.cuda.Event()
+            done.record(self.side)
+        self._done = done
         return out
+
+    def wait(self):
+        d = getattr(self, "_done", None)
+        if d is not None:
+            self.torch.cuda.current_stream(self.tile.dev).wait_event(d)
+            self._done = None
 
 
 def run_rank(tile, layout, exchange):
-    """One step of one rank.  `exchange.gather(tensors)` is the only communication (two calls); the
-    independent kernels (downslope; slope+TI+MTI) are queued BEFORE each wait so they overlap it."""
+    """One step of one rank.  The two all-gathers are the only communication; the independent kernels
+    (downslope; slope+TI+MTI) are queued between each gather's launch and the wait on it, so they
+    overlap it.  Nothing in the step synchronises with the host."""
     tile.d8()
-    fa = tile.fa_local(sync=False)
-    codes = tile.ring_codes_dev()
-    ev_arrs = fa + (codes,)
-    # queue work that does not depend on the exchange, then wait for the ring rows
-    import torch
-    main = torch.cuda.current_stream(tile.dev)
-    ev = torch.cuda.Event()
-    ev.record(main)
+    tile.fa_local(sync=False)
+    tile.fill_ring_codes()
+    rows = exchange.gather(tile.fa_row, exchange.fa_all)
     tile.downslope()
-    allfa = exchange.gather_after(ev, ev_arrs)
-    ext = solve_flowacc(layout, [s[:3] for s in allfa])
-    ring_codes = [s[3] for s in allfa]
-    tile.fa_finish(ext[tile.rank])
-    fh = tile.fh_local(sync=False)
-    ev2 = torch.cuda.Event()
-    ev2.record(main)
+    exchange.wait()
+    tile.fa_solve_finish(rows)
+    tile.fh_local(sync=False)
+    rows = exchange.gather(tile.fh_row, exchange.fh_all)
     tile.slope_twi()
-    allfh = exchange.gather_after(ev2, fh)
-    res = solve_flowhand(layout, allfh, ring_codes)
-    tile.fh_finish(res[tile.rank])
+    exchange.wait()
+    tile.fh_solve_finish(rows)
     tile.gfi()
 
 
 def simulate(tiles, layout):
-    """N logical ranks on ONE device, lock-step, with the all-gathers replaced by list collection:
-    what proves tiled == untiled without a multi-GPU node."""
+    """N logical ranks on ONE device, lock-step, with the all-gathers replaced by list collection and the
+    rank-level solves done by the numpy restatement (solve_flowacc / solve_flowhand): what proves
+    tiled == untiled without a multi-GPU node."""
     for t in tiles:
         t.d8()
     fa = [tuple(a.cpu().numpy() for a in t.fa_local()) for t in tiles]
@@ -558,4 +633,23 @@ def simulate(tiles, layout):
     res = solve_flowhand(layout, fh, codes)
     for t in tiles:
         t.fh_finish(res[t.rank])
+        t.pointwise()
+
+
+def simulate_dev(tiles, layout):
+    """Same as simulate(), but with the product's rank-level solves on the GPU: the gathered buffer is
+    the concatenation of the logical ranks' summary rows, exactly what the RCCL all-gather delivers."""
+    import torch
+    for t in tiles:
+        t.d8()
+        t.fa_local(sync=False)
+        t.fill_ring_codes()
+    rows = torch.cat([t.fa_row for t in tiles])
+    for t in tiles:
+        t.fa_solve_finish(rows)
+    for t in tiles:
+        t.fh_local(sync=False)
+    rows = torch.cat([t.fh_row for t in tiles])
+    for t in tiles:
+        t.fh_solve_finish(rows)
         t.pointwise()

@@ -218,6 +218,22 @@ int dt_dev_minmax_scale_f32(dt_ctx *ctx, const float *x, int64_t N, float mn, fl
  * reported by tools/stencil_bench.py next to the kernels' rates */
 int dt_dev_membench_copy(dt_ctx *ctx, const float *a, float *b, int64_t N, int blocks);
 
+/* Rank-level solves on the GPU (multi-GPU): `rows_dev` holds one all-gathered byte row per rank
+ * (rowbytes apart); field k of rank r starts at rows_dev + r * rowbytes + field_offsets[k] and has Pmax
+ * entries.  heights / widths (host) describe the ty x tx rank grid.
+ *   flow accumulation fields: {A int64, xr int32, code uint8} (the outputs of dt_dev_flowacc_local_w)
+ *     -> ext_out_dev[P_rank] for dt_dev_flowacc_finish_w
+ *   HAND fields: {ref int32, nc int32, nd int32, zr float, ar int32, kind uint8, ring D8 code uint8}
+ *     -> the res_* / rem_* arrays [P_rank] for dt_dev_flowhand_finish_w */
+int dt_dev_rank_solve_flowacc(dt_ctx *ctx, int ty, int tx, const int64_t *heights, const int64_t *widths,
+                              int64_t Pmax, const void *rows_dev, int64_t rowbytes,
+                              const int64_t *field_offsets3, int rank, int64_t P_rank, uint64_t *ext_out_dev);
+int dt_dev_rank_solve_flowhand(dt_ctx *ctx, int ty, int tx, const int64_t *heights, const int64_t *widths,
+                               int64_t Pmax, const void *rows_dev, int64_t rowbytes,
+                               const int64_t *field_offsets7, int rank, int64_t P_rank, uint8_t *res_ok,
+                               int32_t *res_nc, int32_t *res_nd, int64_t *rem_gidx, float *rem_zr,
+                               int32_t *rem_ar);
+
 /* widen / narrow helpers for the int64 API dtypes */
 int dt_dev_i32_to_i64(dt_ctx *ctx, const int32_t *src, int64_t N, int64_t *dst);
 int dt_dev_i64_to_i32(dt_ctx *ctx, const int64_t *src, int64_t N, int32_t *dst);

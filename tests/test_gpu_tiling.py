@@ -15,6 +15,7 @@ def _global_dem(seed, Hg, Wg, nod):
     return oracle.synth_dem(seed, 2048, 2048, 300, 200, Hg, Wg, nod)
 
 
+@pytest.mark.parametrize("solver", ["device", "numpy"])
 @pytest.mark.parametrize("heights,widths,nod,seed", [
     ([192, 192], [256, 256], 0, 1),        # 2 x 2
     ([384], [192, 320], 3, 2),             # 1 x 2, uneven, nodata blobs
@@ -23,7 +24,9 @@ def _global_dem(seed, Hg, Wg, nod):
     ([128, 128, 128], [128, 256, 128], 2, 4),  # 3 x 3
     ([384], [512], 0, 5),                  # 1 x 1 through the windowed entry points
 ])
-def test_tiled_equals_untiled(heights, widths, nod, seed):
+def test_tiled_equals_untiled(heights, widths, nod, seed, solver):
+    """solver "device" = the product's rank-level solves (dt_dev_rank_solve_*), "numpy" = their host
+    restatement in tiling.py (test infrastructure for the gloo rehearsals)."""
     from descriptools_amd import chain, tiling
     layout = tiling.Layout(heights, widths)
     Hg, Wg = layout.Hg, layout.Wg
@@ -39,7 +42,7 @@ def test_tiled_equals_untiled(heights, widths, nod, seed):
         y0, x0 = layout.origin(r)
         t.set_dem_ext(pad[y0:y0 + t.He, x0:x0 + t.We])
         tiles.append(t)
-    tiling.simulate(tiles, layout)
+    (tiling.simulate_dev if solver == "device" else tiling.simulate)(tiles, layout)
     for t in tiles:
         assert t.unresolved_downslope() == 0
         y0, x0 = layout.origin(t.rank)
@@ -77,11 +80,20 @@ def test_tiled_flowacc_cycles_across_ranks():
     fa = [tuple(a.cpu().numpy() for a in t.fa_local()) for t in tiles]
     ext = tiling.solve_flowacc(layout, fa)
     for t in tiles:
-        t.fa_finish(ext[t.rank])
+        t.fill_ring_codes()
+    rows = torch.cat([t.fa_row for t in tiles])
+    for t in tiles:
         y0, x0 = layout.origin(t.rank)
-        got = t.host("fac")
         want = ref[y0:y0 + t.H, x0:x0 + t.W]
+        t.fa_finish(ext[t.rank])
+        got = t.host("fac")
         assert np.array_equal(got, want), "rank %d: %d cells differ" % (t.rank, int((got != want).sum()))
+        t.t["fac"].zero_()
+        t.fa_local()             # pass 3 consumes the tile scratch: redo passes 1-2
+        t.fa_solve_finish(rows)  # the rank-level solve on the GPU
+        got = t.host("fac")
+        assert np.array_equal(got, want), "rank %d (device solve): %d cells differ" % (
+            t.rank, int((got != want).sum()))
 
 
 def test_tiled_evaluation_matches_untiled():
