@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void k_fa_tile1(const uint8_t *__restrict__ fd
 // feeds (the neighbouring tile's perimeter cell its D8 step lands on) and the exit node that entry's
 // in-tile path leads to (its parent in the reduced forest).  Rank exits have neither.
 #define FA_NONE 0xFFFFFFFFu
-#define FA2_SH 56
+#define FA2_SH 54 /* pending count in bits 54-63: a tile exit has at most 260 feeders (the cells around the tile) */
 #define FA2_MASK ((1ull << FA2_SH) - 1ull)
 #define FA_CYCLE (1ull << 63) /* ext flag: this entry cell is fed by a cross-tile D8 cycle */
 #define FA_VALUE(e) ((e) & ~FA_CYCLE)
@@ -270,14 +270,12 @@ __global__ __launch_bounds__(256) void k_fa_link(const unsigned long long *__res
   parent[n] = par;
 }
 
-// countdown over the reduced forest; A(q) = W(q) + winj(q) + sum of A over the exit nodes feeding
+// countdown over the reduced forest; A(q) = W(q) + sum of A over the exit nodes feeding
 // q's tile through entry cells whose in-tile path leads to q.  ext[entry] accumulates the inflow
-// arriving at an entry cell from other tiles.  winj (may be NULL) = inflow injected from other
-// ranks that reaches q inside its tile.
+// arriving at an entry cell from other tiles.
 __global__ __launch_bounds__(256) void k_fa_reduce(const unsigned long long *__restrict__ rec, int64_t nnodes,
                                                   const uint32_t *__restrict__ entry_of,
                                                   const uint32_t *__restrict__ parent,
-                                                  const unsigned long long *__restrict__ winj,
                                                   unsigned long long *__restrict__ state,
                                                   unsigned long long *__restrict__ ext) {
   int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -286,16 +284,16 @@ __global__ __launch_bounds__(256) void k_fa_reduce(const unsigned long long *__r
   if (REC_CODE(r) == 0) return;  // not an exit node
   if (state[n] != 0ull) return;  // not a source of the reduced forest (a source's word stays 0)
   uint32_t q = (uint32_t)n;
-  unsigned long long A = REC_W(r) + (winj ? winj[q] : 0ull);
+  unsigned long long A = REC_W(r);
   for (int64_t it = 0; it < nnodes; it++) {
     uint32_t e = entry_of[q];
-    if (e == FA_NONE) break;  // rank exit: its total stays in (rec, winj, state)
+    if (e == FA_NONE) break;  // rank exit: its total stays in (rec, state)
     atomicAdd(&ext[e], A);
     uint32_t p = parent[q];
     if (p == FA_NONE) break;
     unsigned long long old = atomicAdd(&state[p], A - (1ull << FA2_SH));
     if ((old >> FA2_SH) != 1ull) break;
-    A = REC_W(rec[p]) + (winj ? winj[p] : 0ull) + (old & FA2_MASK) + A;
+    A = REC_W(rec[p]) + (old & FA2_MASK) + A;
     q = p;
   }
 }
@@ -378,16 +376,21 @@ __global__ __launch_bounds__(256) void k_fa_tile3(const uint8_t *__restrict__ fd
 #define J_TERM 0x80000000u
 __global__ __launch_bounds__(256) void k_fa_jump_init(const unsigned long long *__restrict__ rec,
                                                      int64_t nnodes, const uint32_t *__restrict__ entry_of,
-                                                     uint32_t *__restrict__ jump) {
+                                                     const unsigned long long *__restrict__ state,
+                                                     uint32_t *__restrict__ jump, uint32_t *__restrict__ nxt) {
   int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (n >= nnodes) return;
   uint32_t xs = REC_XSLOT(rec[n]);
   uint32_t j = FA_NONE;
   if (xs != X_NONE) {
     uint32_t q = (uint32_t)(n / PS) * PS + xs;
-    j = (rec[q] & REC_RANK_EXIT) ? (q | J_TERM) : entry_of[q];
+    // an exit the local countdown never resolved sits on a D8 cycle spanning tiles of this rank: whatever
+    // enters it dies there (its cells are -100, k_fa_poison)
+    if (rec[q] & REC_RANK_EXIT) j = q | J_TERM;
+    else if ((state[q] >> FA2_SH) == 0ull) j = entry_of[q];
   }
   jump[n] = j;
+  nxt[n] = j;  // the un-doubled successor: k_fa_propagate walks it
 }
 __global__ __launch_bounds__(256) void k_fa_jump(uint32_t *__restrict__ jump, int64_t nnodes) {
   int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -432,13 +435,14 @@ __global__ __launch_bounds__(256) void k_fa_rank_summary(DtWin w, int tiles_x,
   xr[i] = out;
 }
 
-// inject the inflow other ranks deliver at ring cell i: it enters tile entry node n (ext) and reaches
-// that tile's exit X(n) (winj) -- from there the normal countdown carries it on.
-__global__ __launch_bounds__(256) void k_fa_inject(DtWin w, int tiles_x,
-                                                  const unsigned long long *__restrict__ rec,
-                                                  const unsigned long long *__restrict__ ext_perim, int64_t P,
-                                                  unsigned long long *__restrict__ ext,
-                                                  unsigned long long *__restrict__ winj) {
+// the inflow other ranks deliver at ring cell i drains through every tile entry on its way to the rank
+// exit (or to where the path ends): one lane per ring cell walks the entry -> entry successor list adding
+// it to ext[].  The local countdown's results stay valid (accumulation is linear in the inflow), so the
+// perimeter graph is not solved a second time.
+__global__ __launch_bounds__(256) void k_fa_propagate(DtWin w, int tiles_x, int64_t nnodes,
+                                                     const uint32_t *__restrict__ nxt,
+                                                     const unsigned long long *__restrict__ ext_perim, int64_t P,
+                                                     unsigned long long *__restrict__ ext) {
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= P) return;
   unsigned long long v = ext_perim[i];
@@ -446,18 +450,18 @@ __global__ __launch_bounds__(256) void k_fa_inject(DtWin w, int tiles_x,
   int y, x;
   dt_perim_cell(w.H, w.W, i, y, x);
   uint32_t n = dt_node_of(y, x, tiles_x);
-  if (v & FA_CYCLE) atomicOr(&ext[n], FA_CYCLE);
-  unsigned long long val = FA_VALUE(v);
-  if (val) {
-    atomicAdd(&ext[n], val);
-    uint32_t xs = REC_XSLOT(rec[n]);
-    if (xs != X_NONE) atomicAdd(&winj[(n / PS) * PS + xs], val);
+  const unsigned long long val = FA_VALUE(v), cyc = v & FA_CYCLE;
+  for (int64_t it = 0; it < nnodes; it++) {
+    if (val) atomicAdd(&ext[n], val);
+    if (cyc) atomicOr(&ext[n], FA_CYCLE);
+    n = nxt[n];
+    if (n == FA_NONE || (n & J_TERM)) break;
   }
 }
 
 struct FaScratch {
-  unsigned long long *rec, *state, *ext, *winj;
-  uint32_t *entry_of, *parent, *jump;
+  unsigned long long *rec, *state, *ext;
+  uint32_t *entry_of, *parent, *jump, *nxt;
   int64_t nnodes, ntiles;
   int tiles_x;
 };
@@ -469,18 +473,18 @@ static FaScratch fa_layout(const DtWin &w, void *scratch) {
   char *p = (char *)scratch;
   size_t n8 = dt_align256((size_t)f.nnodes * 8), n4 = dt_align256((size_t)f.nnodes * 4);
   f.rec = (unsigned long long *)p;  p += n8;
-  f.state = (unsigned long long *)p;  p += n8;  // state, ext, winj contiguous: one memset
+  f.state = (unsigned long long *)p;  p += n8;  // state, ext contiguous: one memset
   f.ext = (unsigned long long *)p;  p += n8;
-  f.winj = (unsigned long long *)p;  p += n8;
   f.entry_of = (uint32_t *)p;  p += n4;
   f.parent = (uint32_t *)p;  p += n4;
-  f.jump = (uint32_t *)p;
+  f.jump = (uint32_t *)p;  p += n4;
+  f.nxt = (uint32_t *)p;
   return f;
 }
 size_t dt_flowacc_tiled_scratch(int64_t H, int64_t W) {
   int64_t ntiles = ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
   size_t nn = (size_t)ntiles * PS;
-  return dt_align256(nn * 8) * 4 + dt_align256(nn * 4) * 3 + 256;
+  return dt_align256(nn * 8) * 3 + dt_align256(nn * 4) * 4 + 256;
 }
 
 // phase 1: tile pass + local perimeter graph.  With `rank_level` the rank-exit jumps are resolved too
@@ -491,14 +495,13 @@ int dt_launch_fa_local(hipStream_t s, const DtWin &w, const uint8_t *fdr, void *
   DT_REQUIRE(scratch_bytes >= dt_flowacc_tiled_scratch(w.H, w.W), "scratch too small");
   FaScratch f = fa_layout(w, scratch);
   DT_REQUIRE(f.nnodes < 0x7FFFFFF0ll, "raster too large for one device tile");
-  DT_HIP(hipMemsetAsync(f.state, 0, dt_align256((size_t)f.nnodes * 8) * 3, s));
+  DT_HIP(hipMemsetAsync(f.state, 0, dt_align256((size_t)f.nnodes * 8) * 2, s));
   dim3 gt((unsigned)f.ntiles), b(256), gn((unsigned)((f.nnodes + 255) / 256));
   hipLaunchKernelGGL(k_fa_tile1, gt, b, 0, s, fdr, w, f.tiles_x, f.rec, acc32);
   hipLaunchKernelGGL(k_fa_link, gn, b, 0, s, f.rec, f.nnodes, f.tiles_x, f.entry_of, f.parent, f.state);
-  hipLaunchKernelGGL(k_fa_reduce, gn, b, 0, s, f.rec, f.nnodes, f.entry_of, f.parent,
-                     (const unsigned long long *)nullptr, f.state, f.ext);
+  hipLaunchKernelGGL(k_fa_reduce, gn, b, 0, s, f.rec, f.nnodes, f.entry_of, f.parent, f.state, f.ext);
   if (rank_level) {
-    hipLaunchKernelGGL(k_fa_jump_init, gn, b, 0, s, f.rec, f.nnodes, f.entry_of, f.jump);
+    hipLaunchKernelGGL(k_fa_jump_init, gn, b, 0, s, f.rec, f.nnodes, f.entry_of, f.state, f.jump, f.nxt);
     // a path crosses each tile perimeter node at most once; 2^24 tile crossings inside one rank
     // would need a path longer than any raster this library accepts per device
     for (int r = 0; r < 24; r++) hipLaunchKernelGGL(k_fa_jump, gn, b, 0, s, f.jump, f.nnodes);
@@ -516,8 +519,8 @@ int dt_launch_fa_summary(hipStream_t s, const DtWin &w, void *scratch, int64_t *
   return DT_OK;
 }
 
-// phase 2: optional injection of the inflow from other ranks (re-runs the perimeter countdown with
-// it), then the final tile pass.
+// phase 2: optional inflow from other ranks, carried along the entry successor lists of phase 1
+// (dt_launch_fa_local with rank_level), then the final tile pass.
 int dt_launch_fa_finish(hipStream_t s, const DtWin &w, const uint8_t *fdr, const float *dem, void *scratch,
                         const unsigned long long *ext_perim, int64_t river_thr, int32_t *acc32,
                         int8_t *river) {
@@ -526,12 +529,8 @@ int dt_launch_fa_finish(hipStream_t s, const DtWin &w, const uint8_t *fdr, const
   dim3 gt((unsigned)f.ntiles), b(256), gn((unsigned)((f.nnodes + 255) / 256));
   if (ext_perim) {
     int64_t P = dt_perim_count(w.H, w.W);
-    DT_HIP(hipMemsetAsync(f.state, 0, dt_align256((size_t)f.nnodes * 8) * 3, s));
-    hipLaunchKernelGGL(k_fa_link, gn, b, 0, s, f.rec, f.nnodes, f.tiles_x, f.entry_of, f.parent, f.state);
-    hipLaunchKernelGGL(k_fa_inject, dim3((unsigned)((P + 255) / 256)), b, 0, s, w, f.tiles_x, f.rec, ext_perim,
-                       P, f.ext, f.winj);
-    hipLaunchKernelGGL(k_fa_reduce, gn, b, 0, s, f.rec, f.nnodes, f.entry_of, f.parent,
-                       (const unsigned long long *)f.winj, f.state, f.ext);
+    hipLaunchKernelGGL(k_fa_propagate, dim3((unsigned)((P + 255) / 256)), b, 0, s, w, f.tiles_x, f.nnodes, f.nxt,
+                       ext_perim, P, f.ext);
   }
   hipLaunchKernelGGL(k_fa_poison, gn, b, 0, s, f.rec, f.nnodes, f.entry_of, f.state, f.ext);
   int32_t thr = river_thr > 2147483647ll ? 2147483647 : (river_thr < -2147483647ll ? -2147483647 : (int32_t)river_thr);
@@ -1057,9 +1056,10 @@ __device__ __forceinline__ T rk_get(const RkRows &R, int field, int r, long long
 }
 
 // ---- flow accumulation: rows = {A int64, xr int32, code uint8} --------------------------------------
+// A rank exit can be fed by thousands of exits of the neighbouring ranks, so the pending count gets a
+// 32-bit word of its own (the tile level packs count and sum into one 64-bit word: <= 260 feeders there).
 __global__ __launch_bounds__(256) void k_rk_fa_link(RkLayout L, RkRows R, int32_t *__restrict__ entry_of,
-                                                   int32_t *__restrict__ parent,
-                                                   unsigned long long *__restrict__ state) {
+                                                   int32_t *__restrict__ parent, uint32_t *__restrict__ pending) {
   long long n = (long long)blockIdx.x * 256 + threadIdx.x;
   if (n >= (long long)L.nranks * L.Pmax) return;
   int r = (int)(n / L.Pmax);
@@ -1071,21 +1071,30 @@ __global__ __launch_bounds__(256) void k_rk_fa_link(RkLayout L, RkRows R, int32_
     int32_t xr = rk_get<int32_t>(R, 1, r2, e - (long long)r2 * L.Pmax);
     if (xr >= 0) {
       par = (int32_t)((long long)r2 * L.Pmax + xr);
-      atomicAdd(&state[par], 1ull << FA2_SH);
+      atomicAdd(&pending[par], 1u);
     }
   }
   entry_of[n] = (int32_t)e;
   parent[n] = par;
 }
+// sources of the forest of rank exits: exits nothing feeds (decided before the countdown starts changing `pending`)
+__global__ __launch_bounds__(256) void k_rk_fa_sources(long long nn, const int32_t *__restrict__ entry_of,
+                                                      const uint32_t *__restrict__ pending,
+                                                      uint8_t *__restrict__ is_src) {
+  long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (n >= nn) return;
+  is_src[n] = (entry_of[n] >= 0 && pending[n] == 0u) ? 1 : 0;
+}
 __global__ __launch_bounds__(256) void k_rk_fa_reduce(RkLayout L, RkRows R, const int32_t *__restrict__ entry_of,
                                                      const int32_t *__restrict__ parent,
-                                                     unsigned long long *__restrict__ state,
+                                                     const uint8_t *__restrict__ is_src,
+                                                     uint32_t *__restrict__ pending,
+                                                     unsigned long long *__restrict__ sum,
                                                      unsigned long long *__restrict__ ext) {
   long long n = (long long)blockIdx.x * 256 + threadIdx.x;
   long long nn = (long long)L.nranks * L.Pmax;
   if (n >= nn) return;
-  if (entry_of[n] < 0) return;   // not a rank exit
-  if (state[n] != 0ull) return;  // not a source
+  if (!is_src[n]) return;
   long long q = n;
   int rq = (int)(q / L.Pmax);
   unsigned long long A = (unsigned long long)rk_get<long long>(R, 0, rq, q - (long long)rq * L.Pmax);
@@ -1093,19 +1102,23 @@ __global__ __launch_bounds__(256) void k_rk_fa_reduce(RkLayout L, RkRows R, cons
     atomicAdd(&ext[entry_of[q]], A);
     int32_t p = parent[q];
     if (p < 0) break;
-    unsigned long long old = atomicAdd(&state[p], A - (1ull << FA2_SH));
-    if ((old >> FA2_SH) != 1ull) break;
+    atomicAdd(&sum[p], A);
+    __threadfence();  // the sum lands before the count drops: whoever takes the count to 0 sees every addend
+    if (atomicSub(&pending[p], 1u) != 1u) break;
+    __threadfence();
     int rp = (int)(p / L.Pmax);
-    A = (unsigned long long)rk_get<long long>(R, 0, rp, p - (long long)rp * L.Pmax) + (old & FA2_MASK) + A;
+    A = (unsigned long long)rk_get<long long>(R, 0, rp, p - (long long)rp * L.Pmax) +
+        __hip_atomic_load(&sum[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     q = p;
   }
 }
+// exits whose count never reached 0 sit on a D8 cycle spanning ranks
 __global__ __launch_bounds__(256) void k_rk_fa_poison(RkLayout L, const int32_t *__restrict__ entry_of,
-                                                     const unsigned long long *__restrict__ state,
+                                                     const uint32_t *__restrict__ pending,
                                                      unsigned long long *__restrict__ ext) {
   long long n = (long long)blockIdx.x * 256 + threadIdx.x;
   if (n >= (long long)L.nranks * L.Pmax) return;
-  if (entry_of[n] >= 0 && (state[n] >> FA2_SH) != 0ull) atomicOr(&ext[entry_of[n]], FA_CYCLE);
+  if (entry_of[n] >= 0 && pending[n] != 0u) atomicOr(&ext[entry_of[n]], FA_CYCLE);
 }
 
 static int rk_make_layout(int ty, int tx, const int64_t *heights, const int64_t *widths, int64_t Pmax,
@@ -1125,7 +1138,7 @@ static int rk_make_layout(int ty, int tx, const int64_t *heights, const int64_t 
 
 size_t dt_rank_solve_scratch(int nranks, int64_t Pmax) {
   size_t nn = (size_t)nranks * (size_t)Pmax;
-  return dt_align256(nn * 8) * 3 + dt_align256(nn * 4) * 2 + 256;
+  return dt_align256(nn * 8) * 2 + dt_align256(nn * 4) * 3 + dt_align256(nn) + 256;
 }
 
 // ext_out[i] (device, P_rank entries) = inflow arriving at ring cell i of `rank` (bit 63 = cycle)
@@ -1141,16 +1154,18 @@ int dt_launch_rank_solve_flowacc(hipStream_t s, int ty, int tx, const int64_t *h
   size_t nn = (size_t)L.nranks * (size_t)Pmax;
   if (nn == 0) return DT_OK;
   char *p = (char *)scratch;
-  unsigned long long *state = (unsigned long long *)p;  p += dt_align256(nn * 8);
+  unsigned long long *sum = (unsigned long long *)p;  p += dt_align256(nn * 8);  // sum, ext, pending: one memset
   unsigned long long *ext = (unsigned long long *)p;  p += dt_align256(nn * 8);
-  p += dt_align256(nn * 8);
+  uint32_t *pending = (uint32_t *)p;  p += dt_align256(nn * 4);
   int32_t *entry_of = (int32_t *)p;  p += dt_align256(nn * 4);
-  int32_t *parent = (int32_t *)p;
-  DT_HIP(hipMemsetAsync(state, 0, dt_align256(nn * 8) * 2, s));
+  int32_t *parent = (int32_t *)p;  p += dt_align256(nn * 4);
+  uint8_t *is_src = (uint8_t *)p;
+  DT_HIP(hipMemsetAsync(sum, 0, dt_align256(nn * 8) * 2 + dt_align256(nn * 4), s));
   dim3 g((unsigned)((nn + 255) / 256)), b(256);
-  hipLaunchKernelGGL(k_rk_fa_link, g, b, 0, s, L, R, entry_of, parent, state);
-  hipLaunchKernelGGL(k_rk_fa_reduce, g, b, 0, s, L, R, entry_of, parent, state, ext);
-  hipLaunchKernelGGL(k_rk_fa_poison, g, b, 0, s, L, entry_of, state, ext);
+  hipLaunchKernelGGL(k_rk_fa_link, g, b, 0, s, L, R, entry_of, parent, pending);
+  hipLaunchKernelGGL(k_rk_fa_sources, g, b, 0, s, (long long)nn, entry_of, pending, is_src);
+  hipLaunchKernelGGL(k_rk_fa_reduce, g, b, 0, s, L, R, entry_of, parent, is_src, pending, sum, ext);
+  hipLaunchKernelGGL(k_rk_fa_poison, g, b, 0, s, L, entry_of, pending, ext);
   DT_HIP(hipMemcpyAsync(ext_out, ext + (size_t)rank * Pmax, (size_t)P_rank * 8, hipMemcpyDeviceToDevice, s));
   return DT_OK;
 }

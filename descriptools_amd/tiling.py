@@ -270,6 +270,9 @@ class RankTile:
         self.He, self.We = self.H + 2 * halo, self.W + 2 * halo
         self.dev = torch.device("cuda", device)
         self.ctx = Context(device=device, stream=stream)
+        # torch ops below (fills, copies, the ring gather) run on torch's current stream: when that is not
+        # the context's stream the two are ordered by hand (_torch_begin / _torch_end)
+        self._foreign = stream is None or int(stream) != int(torch.cuda.current_stream(self.dev).cuda_stream)
         self.px, self.n_top, self.n_gfi, self.b, self.dz = px, n_top, n_gfi, b, dz
         self.river_threshold = (layout.Hg * layout.Wg) // 512 if river_threshold is None else int(river_threshold)
         self.P = perim_count(self.H, self.W)
@@ -305,6 +308,16 @@ class RankTile:
                      torch.zeros(max(self.P, 1), dtype=torch.float32, device=self.dev),
                      torch.zeros(max(self.P, 1), dtype=torch.int32, device=self.dev))
 
+        self._torch_end()
+
+    def _torch_begin(self):
+        if self._foreign:
+            self.ctx.sync()
+
+    def _torch_end(self):
+        if self._foreign:
+            self.torch.cuda.current_stream(self.dev).synchronize()
+
     def _row_views(self, row, fields):
         tc, pm = self.torch, self.pmax
         v = {}
@@ -338,10 +351,13 @@ class RankTile:
         self.ctx.sync()
         oy, ox = y0 - (self.gy0 - h), x0 - (self.gx0 - h)
         self.t["dem"][oy:oy + (y1 - y0), ox:ox + (x1 - x0)] = tmp
+        self._torch_end()
 
     def set_dem_ext(self, dem_ext):
         """host array of the extended window (He x We); cells outside the global raster are ignored."""
+        self._torch_begin()
         self.t["dem"].copy_(self.torch.as_tensor(np.ascontiguousarray(dem_ext, np.float32)))
+        self._torch_end()
 
     # ---- local stages ------------------------------------------------------------------------------
     def d8(self):
@@ -384,9 +400,11 @@ class RankTile:
 
     def fill_ring_codes(self):
         """D8 codes of the ring cells into both summary rows (the rank-level solves step across ranks with them)."""
+        self._torch_begin()
         rc = self.ring_codes_dev()
         self._fa_v["ring"].copy_(rc)
         self._fh_v["ring"].copy_(rc)
+        self._torch_end()
 
     def fa_solve_finish(self, rows):
         """rank-level inflow solve on the GPU from the all-gathered rows (size x FA_ROW_BYTES*pmax bytes,
@@ -640,16 +658,23 @@ def simulate_dev(tiles, layout):
     """Same as simulate(), but with the product's rank-level solves on the GPU: the gathered buffer is
     the concatenation of the logical ranks' summary rows, exactly what the RCCL all-gather delivers."""
     import torch
+
+    def gather(rows):  # the logical ranks own one stream each: order them around the copy by hand
+        for t in tiles:
+            t.ctx.sync()
+        out = torch.cat(rows)
+        torch.cuda.synchronize()
+        return out
     for t in tiles:
         t.d8()
         t.fa_local(sync=False)
         t.fill_ring_codes()
-    rows = torch.cat([t.fa_row for t in tiles])
+    rows = gather([t.fa_row for t in tiles])
     for t in tiles:
         t.fa_solve_finish(rows)
     for t in tiles:
         t.fh_local(sync=False)
-    rows = torch.cat([t.fh_row for t in tiles])
+    rows = gather([t.fh_row for t in tiles])
     for t in tiles:
         t.fh_solve_finish(rows)
         t.pointwise()

@@ -343,7 +343,8 @@ def test_full_size_16384_properties(dt):
         y0, x0 = layout.origin(tl.rank)
         for name in ("fdr", "fac", "river", "fdist", "hand", "a_river", "slope", "ti", "mti", "gfi", "lnhlh",
                      "down"):
-            assert torch.equal(tl.core(name), t[name][y0:y0 + tl.H, x0:x0 + tl.W]), (tl.rank, name)
+            a, b = tl.core(name), t[name][y0:y0 + tl.H, x0:x0 + tl.W]
+            assert torch.equal(a, b), (tl.rank, name, int((a != b).sum()), torch.nonzero(a != b)[:4].tolist())
         gi = tl.core("idx")
         li = t["idx"][y0:y0 + tl.H, x0:x0 + tl.W].long()
         assert torch.equal(gi, li), (tl.rank, "idx")

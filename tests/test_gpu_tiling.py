@@ -77,11 +77,13 @@ def test_tiled_flowacc_cycles_across_ranks():
         t.t["fdr"].copy_(torch.as_tensor(pad[y0:y0 + t.He, x0:x0 + t.We]))
         t.t["dem"].fill_(1.0)
         tiles.append(t)
+    torch.cuda.synchronize()
     fa = [tuple(a.cpu().numpy() for a in t.fa_local()) for t in tiles]
     ext = tiling.solve_flowacc(layout, fa)
     for t in tiles:
         t.fill_ring_codes()
     rows = torch.cat([t.fa_row for t in tiles])
+    torch.cuda.synchronize()
     for t in tiles:
         y0, x0 = layout.origin(t.rank)
         want = ref[y0:y0 + t.H, x0:x0 + t.W]
@@ -89,7 +91,8 @@ def test_tiled_flowacc_cycles_across_ranks():
         got = t.host("fac")
         assert np.array_equal(got, want), "rank %d: %d cells differ" % (t.rank, int((got != want).sum()))
         t.t["fac"].zero_()
-        t.fa_local()             # pass 3 consumes the tile scratch: redo passes 1-2
+        torch.cuda.synchronize()
+        t.fa_local()             # the inflow is added on top of passes 1-2: redo them
         t.fa_solve_finish(rows)  # the rank-level solve on the GPU
         got = t.host("fac")
         assert np.array_equal(got, want), "rank %d (device solve): %d cells differ" % (
