@@ -844,33 +844,39 @@ __global__ __launch_bounds__(256) void k_downslope(const float *__restrict__ dem
 }
 // Windowed version: a 1024-thread workgroup stages a 112 x 112 window (64 x 64 core + 24-cell
 // margin) in LDS as float32 heights plus one pre-decoded 16-bit "move word" per cell
-//   bits 0-8  window-index offset of the D8 successor, biased by 256
-//   bit  9    the move is diagonal
-//   bits 10.. why the fast walk must stop here: non-D8 code / the move leaves the raster / the
-//             cell is on the window's outer ring (successor may be outside the window)
-// so the inner loop is ~20 VALU instructions per move instead of ~60 (the global walk is
-// VALU-bound on D8 decoding and bounds tests, not latency-bound).  A walk that reaches the ring
-// continues on global memory with the generic step.  Same arithmetic as k_downslope: the path
-// length is the reference's sequential float64 sum (bit-identical results).  75 KiB of LDS: two
-// workgroups per CU; workgroups are banded per XCD so overlapping margins come from L2.
+//   bits 0-9  BYTE offset of the D8 successor's move word from this cell's, biased by 512
+//   bit  10   the move is diagonal
+//   bits 11-13 why the fast walk must stop here: non-D8 code / the move leaves the raster / the cell is
+//             on the window's outer ring (successor may be outside the window)
+//   bit  15   any of those
+// so a move is 9 VALU instructions and one LDS round trip (the global walk is VALU-bound on D8 decoding
+// and bounds tests, not latency-bound).  The fast walk only COUNTS cardinal and diagonal moves; the
+// reference's path length is a sequential float64 sum, whose rounding depends on the order of the moves,
+// so the count form px*nc + px*sqrt(2)*nd is accepted only when the float32 result provably does not
+// depend on that (the whole error interval rounds to one float); the rare other cells, and walks that
+// reach the window ring, are redone by the generic sequential walk on global memory.  Results are
+// bit-identical to k_downslope.  75 KiB of LDS: two workgroups per CU; workgroups are banded per XCD so
+// overlapping margins come from L2.
 #define DW_CORE 64
 #define DW_M 24
 #define DW_WIN (DW_CORE + 2 * DW_M) /* 112 */
-#define MW_DIAG 0x200u
-#define MW_BADCODE 0x400u
-#define MW_EDGE 0x800u
-#define MW_RING 0x1000u
-#define MW_NODATA 0x2000u /* the successor cell is nodata: the walk stops here without moving */
-#define MW_STOP (MW_BADCODE | MW_EDGE | MW_RING | MW_NODATA)
+#define MW_OFF 0x3FFu
+#define MW_BIAS 512
+#define MW_DIAG 0x400u
+#define MW_BADCODE 0x800u
+#define MW_EDGE 0x1000u
+#define MW_RING 0x2000u
+#define MW_STOP 0x8000u
 
 __global__ __launch_bounds__(1024, 8) void k_downslope_win(const float *__restrict__ dem,
                                                        const uint8_t *__restrict__ fdr, DtWin w,
                                                        double px, double dz, float dzf, int raw,
                                                        float *__restrict__ out, int tiles_x, int ntiles,
                                                        int *__restrict__ n_unresolved) {
-  // one LDS block: heights at byte 0, move words at byte DW_WIN*DW_WIN*4 (the walk reads both with one
-  // address register and an immediate offset)
+  // one LDS block: heights at byte 0, move words at byte DW_WIN*DW_WIN*4 (the walk reads both from one
+  // address register)
   __shared__ __attribute__((aligned(16))) unsigned char smem[DW_WIN * DW_WIN * 6];
+  __shared__ uint16_t s_lut[256];
   float *s_z = reinterpret_cast<float *>(smem);
   uint16_t *s_w = reinterpret_cast<uint16_t *>(smem + DW_WIN * DW_WIN * 4);
   // LDS byte address of smem (0 when it is the kernel's only LDS object, but do not rely on it)
@@ -887,116 +893,154 @@ __global__ __launch_bounds__(1024, 8) void k_downslope_win(const float *__restri
   // readable cells (inside the global raster and in memory): rows [ya, yb), columns [xa, xb)
   const int ya = max(-w.halo, -w.gy0), yb = min(w.H + w.halo, w.Hg - w.gy0);
   const int xa = max(-w.halo, -w.gx0), xb = min(w.W + w.halo, w.Wg - w.gx0);
-  // 112 rows x 28 groups of 4 cells (wx0 is a multiple of 8: float4 / uchar4 stay aligned)
+  // D8 code -> move word (256 entries: one LDS read per cell instead of ~15 VALU instructions)
+  if (threadIdx.x < 256) {
+    uint32_t code = threadIdx.x, mw = MW_BADCODE | MW_STOP | MW_BIAS;
+    if (dt_d8_valid(code)) {
+      int dy, dx;
+      dt_d8_delta(code, dy, dx);
+      mw = (uint32_t)(2 * (dy * DW_WIN + dx) + MW_BIAS);
+      if (dy != 0 && dx != 0) mw |= MW_DIAG;
+    }
+    s_lut[code] = (uint16_t)mw;
+  }
+  __syncthreads();
+  // block-uniform: every window cell is in memory and no move from it can leave the global raster
+  const bool interior = vec && wy0 >= ya && wy0 + DW_WIN <= yb && wx0 >= xa && wx0 + DW_WIN <= xb &&
+                        w.gy0 + wy0 >= 1 && w.gy0 + wy0 + DW_WIN <= w.Hg - 1 && w.gx0 + wx0 >= 1 &&
+                        w.gx0 + wx0 + DW_WIN <= w.Wg - 1;
+  const float ninf = -__builtin_inff();
+  // 112 rows x 28 groups of 4 cells (wx0 is a multiple of 8: float4 / uchar4 stay aligned).  A nodata
+  // height is staged as -inf: the walk never moves onto nodata (downslope.py:231-281); a lane that does
+  // sees an infinite drop, stops, and is redone by the generic walk.
   for (int i = threadIdx.x; i < DW_WIN * (DW_WIN / 4); i += 1024) {
     int r = i / (DW_WIN / 4), c4 = (i - r * (DW_WIN / 4)) * 4;
     int gy = wy0 + r, gx = wx0 + c4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    uint32_t codes = 0;
-    const bool row_ok = gy >= ya && gy < yb;
-    bool rd[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) rd[k] = row_ok && gx + k >= xa && gx + k < xb;
-    if (vec && rd[0] && rd[3]) {
-      v = *reinterpret_cast<const float4 *>(dem + (long long)gy * w.ld + gx);
-      codes = *reinterpret_cast<const uint32_t *>(fdr + (long long)gy * w.ld + gx);
-    } else {
-      const float *p = dem + (long long)gy * w.ld;
-      const uint8_t *f = fdr + (long long)gy * w.ld;
-      if (rd[0]) { v.x = p[gx]; codes |= (uint32_t)f[gx]; }
-      if (rd[1]) { v.y = p[gx + 1]; codes |= (uint32_t)f[gx + 1] << 8; }
-      if (rd[2]) { v.z = p[gx + 2]; codes |= (uint32_t)f[gx + 2] << 16; }
-      if (rd[3]) { v.w = p[gx + 3]; codes |= (uint32_t)f[gx + 3] << 24; }
-    }
-    *reinterpret_cast<float4 *>(&s_z[r * DW_WIN + c4]) = v;
+    float4 v;
     uint32_t mwv[4];
+    if (interior) {
+      v = *reinterpret_cast<const float4 *>(dem + (long long)gy * w.ld + gx);
+      uint32_t codes = *reinterpret_cast<const uint32_t *>(fdr + (long long)gy * w.ld + gx);
+      const uint32_t rowring = (r == 0 || r == DW_WIN - 1) ? (MW_RING | MW_STOP) : 0u;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      uint32_t code = (codes >> (8 * k)) & 0xFFu;
-      int rx = c4 + k;
-      uint32_t mw;
-      if (!dt_d8_valid(code)) {
-        mw = MW_BADCODE | 256u;
+      for (int k = 0; k < 4; k++) mwv[k] = (uint32_t)s_lut[(codes >> (8 * k)) & 0xFFu] | rowring;
+      if (c4 == 0) mwv[0] |= MW_RING | MW_STOP;
+      if (c4 == DW_WIN - 4) mwv[3] |= MW_RING | MW_STOP;
+    } else {
+      v = make_float4(0.f, 0.f, 0.f, 0.f);
+      uint32_t codes = 0;
+      const bool row_ok = gy >= ya && gy < yb;
+      bool rd[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) rd[k] = row_ok && gx + k >= xa && gx + k < xb;
+      if (vec && rd[0] && rd[3]) {
+        v = *reinterpret_cast<const float4 *>(dem + (long long)gy * w.ld + gx);
+        codes = *reinterpret_cast<const uint32_t *>(fdr + (long long)gy * w.ld + gx);
       } else {
-        int dy, dx;
-        dt_d8_delta(code, dy, dx);
-        mw = (uint32_t)(dy * DW_WIN + dx + 256);
-        if (dy != 0 && dx != 0) mw |= MW_DIAG;
-        int ny = w.gy0 + gy + dy, nx = w.gx0 + gx + k + dx;
-        if (ny < 0 || ny >= w.Hg || nx < 0 || nx >= w.Wg) mw |= MW_EDGE;
+        const float *p = dem + (long long)gy * w.ld;
+        const uint8_t *f = fdr + (long long)gy * w.ld;
+        if (rd[0]) { v.x = p[gx]; codes |= (uint32_t)f[gx]; }
+        if (rd[1]) { v.y = p[gx + 1]; codes |= (uint32_t)f[gx + 1] << 8; }
+        if (rd[2]) { v.z = p[gx + 2]; codes |= (uint32_t)f[gx + 2] << 16; }
+        if (rd[3]) { v.w = p[gx + 3]; codes |= (uint32_t)f[gx + 3] << 24; }
       }
-      // ring of the window, or the edge of what is in memory: hand over to the global walk
-      if (r == 0 || r == DW_WIN - 1 || rx == 0 || rx == DW_WIN - 1 || !rd[k]) mw |= MW_RING;
-      mwv[k] = mw;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        uint32_t code = (codes >> (8 * k)) & 0xFFu;
+        int rx = c4 + k;
+        uint32_t mw = s_lut[code];
+        if (!(mw & MW_STOP)) {
+          int dy, dx;
+          dt_d8_delta(code, dy, dx);
+          int ny = w.gy0 + gy + dy, nx = w.gx0 + gx + k + dx;
+          if (ny < 0 || ny >= w.Hg || nx < 0 || nx >= w.Wg) mw |= MW_EDGE | MW_STOP;
+          // successor inside the raster but not in this rank's memory (halo narrower than the margin)
+          else if (gy + dy < ya || gy + dy >= yb || gx + k + dx < xa || gx + k + dx >= xb) mw |= MW_RING | MW_STOP;
+        }
+        // ring of the window, or the edge of what is in memory: hand over to the global walk
+        if (r == 0 || r == DW_WIN - 1 || rx == 0 || rx == DW_WIN - 1 || !rd[k]) mw |= MW_RING | MW_STOP;
+        mwv[k] = mw;
+      }
     }
+    v.x = v.x == DT_NODATA ? ninf : v.x;
+    v.y = v.y == DT_NODATA ? ninf : v.y;
+    v.z = v.z == DT_NODATA ? ninf : v.z;
+    v.w = v.w == DT_NODATA ? ninf : v.w;
+    *reinterpret_cast<float4 *>(&s_z[r * DW_WIN + c4]) = v;
     *reinterpret_cast<uint2 *>(&s_w[r * DW_WIN + c4]) =
         make_uint2(mwv[0] | (mwv[1] << 16), mwv[2] | (mwv[3] << 16));
   }
   __syncthreads();
-  // second staging pass: a move onto a nodata cell never happens (downslope.py:231-281) -- fold that
-  // test into the move word so the walk loop has a single stop condition
-  for (int i = threadIdx.x; i < DW_WIN * DW_WIN; i += 1024) {
-    uint32_t mw = s_w[i];
-    if (!(mw & MW_STOP) && s_z[i + (int)(mw & 0x1FFu) - 256] == DT_NODATA) s_w[i] = (uint16_t)(mw | MW_NODATA);
-  }
-  __syncthreads();
   const double dcard = px, ddiag = px * sqrt(2.0);
+  const uint32_t neg2lds0 = 0u - 2u * lds0 + lds0;  // z address = 2 * (q2 - lds0) + lds0 = (q2 << 1) + neg2lds0
   for (int j = 0; j < (DW_CORE * DW_CORE) / 1024; j++) {
     int c = threadIdx.x + 1024 * j;
     int cy = c / DW_CORE, cx = c - cy * DW_CORE;
     int y0 = tyi * DW_CORE + cy, x0 = txi * DW_CORE + cx;
     if (y0 >= w.H || x0 >= w.W) continue;
-    int pos = (cy + DW_M) * DW_WIN + cx + DW_M;
-    float z0 = s_z[pos];
+    const int pos0 = (cy + DW_M) * DW_WIN + cx + DW_M;
+    float z0 = s_z[pos0];
     long long o = (long long)y0 * w.ld + x0;
     if (z0 <= DT_NODATA) {
       out[o] = DT_NODATA;
       continue;
     }
-    double dist = 0.0;
     float drop = 0.0f;
-    int loop = 0;
+    uint32_t loop = 0, ndacc = 0;  // moves made; diagonal moves (in units of MW_DIAG)
     bool failed = false, slow = false, unresolved = false;
-    // Fast walk inside the window: one loop, one exit test, everything else predicated (the lanes
-    // of a wave iterate until the longest walk ends anyway).  (double)drop < dz  <=>  drop < dzf
-    // (dzf = smallest float >= dz).  The next cell's height and move word are fetched together.
-    uint32_t mw = s_w[pos];
-    bool running = drop < dzf && !(mw & MW_STOP);
-    // every lane still running has made exactly `it` moves: the 5000-move cap is a scalar loop bound
-    for (int it = 0; it < 5000 && __any(running); it++) {
-      if (running) {
-        int np = pos + (int)(mw & 0x1FFu) - 256;
-        // the successor's height and move word in ONE round trip
-        float zt;
-        uint32_t mwn;
-        {
-          uint32_t a4 = lds0 + ((uint32_t)np << 2), a2 = lds0 + ((uint32_t)np << 1);
-          asm volatile("ds_read_b32 %0, %2\n\tds_read_u16 %1, %3 offset:%4\n\ts_waitcnt lgkmcnt(0)"
-                       : "=&v"(zt), "=&v"(mwn)
-                       : "v"(a4), "v"(a2), "n"(DW_WIN * DW_WIN * 4)
-                       : "memory");
-        }
-        dist += (mw & MW_DIAG) ? ddiag : dcard;
-        drop = z0 - zt;
-        pos = np;
-        mw = mwn;
-        loop++;
-        running = drop < dzf && !(mw & MW_STOP);
-      }
+    // Fast walk inside the window.  (double)drop < dz  <=>  drop < dzf (dzf = smallest float >= dz).
+    // q2 = LDS byte address of the current cell's move word minus the array's offset; the next cell's
+    // height and move word are fetched together.
+    uint32_t q2 = lds0 + 2u * (uint32_t)pos0;
+    uint32_t mw = s_w[pos0];
+    // a plain divergent loop (exec-masked, one backward branch); the 5000-move cap of
+    // downslope.py:303-304 is part of the loop condition
+    bool running = drop < dzf && mw < MW_STOP;
+#pragma nounroll
+    while (running) {
+      q2 = q2 + (mw & MW_OFF) - (uint32_t)MW_BIAS;
+      ndacc += mw & MW_DIAG;
+      loop++;
+      uint32_t a4 = (q2 << 1) + neg2lds0;
+      float zt;
+      asm volatile("ds_read_b32 %0, %2\n\tds_read_u16 %1, %3 offset:%4\n\ts_waitcnt lgkmcnt(0)"
+                   : "=v"(zt), "=v"(mw)
+                   : "v"(a4), "v"(q2), "n"(DW_WIN * DW_WIN * 4)
+                   : "memory");
+      drop = z0 - zt;
+      running = drop < dzf && mw < MW_STOP && loop < 5000u;
     }
     if (drop < dzf) {
       // :303-304 / :518-521: 5000 moves without reaching the drop (the cap precedes the drop test, but a
       // lane that reached the drop on its 5000th move is also failed by the reference)
-      if (loop == 5000) failed = true;
+      if (loop == 5000u) failed = true;
       // stopped on a move word: a non-D8 code never moves again (the reference spins to its cap), a move
-      // off the raster or onto nodata stops the walk (downslope.py:209-281); the ring continues below
-      else if (mw & (MW_BADCODE | MW_EDGE | MW_NODATA)) failed = true;
+      // off the raster stops the walk (downslope.py:209-228); the ring continues below
+      else if (mw & (MW_BADCODE | MW_EDGE)) failed = true;
       else slow = true;
-    } else if (loop == 5000) {
+    } else if (drop == __builtin_inff()) {
+      slow = true;  // stepped onto a nodata cell (staged as -inf): the reference stops one move earlier
+    } else if (loop == 5000u) {
       failed = true;
     }
-    if (slow) {  // on the window ring: finish on global memory
-      int y = wy0 + pos / DW_WIN, x = wx0 + pos % DW_WIN;
+    double dist = 0.0;
+    if (!slow) {
+      // count form of the path length, accepted only if every value within the rounding error of the
+      // sequential sum (<= (n + 8) * 2^-53 relative, n = moves) gives the same float32 quotient
+      const uint32_t nd = ndacc / MW_DIAG, nc = loop - nd;
+      dist = dcard * (double)nc + ddiag * (double)nd;
+      if (loop != 0u) {
+        const double q = (double)drop / dist, dl = (double)(loop + 8u) * 1.1102230246251565e-16;
+        const float r = (float)q;
+        if ((float)(q * (1.0 - dl)) != r || (float)(q * (1.0 + dl)) != r) slow = true;
+      }
+    }
+    if (slow) {  // the reference's own walk, from the start, on global memory
+      int y = y0, x = x0;
+      dist = 0.0;
+      drop = 0.0f;
+      loop = 0;
+      failed = false;
       while ((double)drop < dz) {
         if (!dt_readable(w, y, x)) { unresolved = true; break; }  // beyond this rank's halo
         uint32_t code = fdr[(long long)y * w.ld + x];
@@ -1012,7 +1056,7 @@ __global__ __launch_bounds__(1024, 8) void k_downslope_win(const float *__restri
         x = nx;
         dist += (dy != 0 && dx != 0) ? ddiag : dcard;
         drop = z0 - zt;
-        if (++loop == 5000) { failed = true; break; }
+        if (++loop == 5000u) { failed = true; break; }
       }
     }
     if (unresolved) {  // the walk left the memory of this rank: a wider halo is needed

@@ -283,18 +283,20 @@ __global__ __launch_bounds__(256) void k_fa_reduce(const unsigned long long *__r
   unsigned long long r = rec[n];
   if (REC_CODE(r) == 0) return;  // not an exit node
   if (state[n] != 0ull) return;  // not a source of the reduced forest (a source's word stays 0)
-  uint32_t q = (uint32_t)n;
   unsigned long long A = REC_W(r);
+  uint32_t e = entry_of[n], p = parent[n];
   for (int64_t it = 0; it < nnodes; it++) {
-    uint32_t e = entry_of[q];
     if (e == FA_NONE) break;  // rank exit: its total stays in (rec, state)
     atomicAdd(&ext[e], A);
-    uint32_t p = parent[q];
     if (p == FA_NONE) break;
+    // the next hop's operands are fetched while the countdown atomic is in flight
+    unsigned long long rp = rec[p];
+    uint32_t ep = entry_of[p], pp = parent[p];
     unsigned long long old = atomicAdd(&state[p], A - (1ull << FA2_SH));
     if ((old >> FA2_SH) != 1ull) break;
-    A = REC_W(rec[p]) + (old & FA2_MASK) + A;
-    q = p;
+    A = REC_W(rp) + (old & FA2_MASK) + A;
+    e = ep;
+    p = pp;
   }
 }
 
