@@ -860,6 +860,11 @@ __global__ __launch_bounds__(256) void k_downslope(const float *__restrict__ dem
 #define DW_CORE 64
 #define DW_M 24
 #define DW_WIN (DW_CORE + 2 * DW_M) /* 112 */
+// LDS row stride in cells.  Lanes that merged onto one flow path trail each other by a few cells; with a
+// stride of 112 dwords (= 16 mod 32 banks) two cells 2 rows apart in one column share a bank, the common
+// case on south-flowing terrain.  116 = 20 mod 32: same column conflicts only 8 rows apart, the diagonals
+// 32 apart; rows stay 16-byte aligned for the float4 staging stores.
+#define DW_LD 116
 #define MW_OFF 0x3FFu
 #define MW_BIAS 512
 #define MW_DIAG 0x400u
@@ -873,12 +878,12 @@ __global__ __launch_bounds__(1024, 8) void k_downslope_win(const float *__restri
                                                        double px, double dz, float dzf, int raw,
                                                        float *__restrict__ out, int tiles_x, int ntiles,
                                                        int *__restrict__ n_unresolved) {
-  // one LDS block: heights at byte 0, move words at byte DW_WIN*DW_WIN*4 (the walk reads both from one
+  // one LDS block: heights at byte 0, move words at byte DW_LD*DW_WIN*4 (the walk reads both from one
   // address register)
-  __shared__ __attribute__((aligned(16))) unsigned char smem[DW_WIN * DW_WIN * 6];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[DW_LD * DW_WIN * 6];
   __shared__ uint16_t s_lut[256];
   float *s_z = reinterpret_cast<float *>(smem);
-  uint16_t *s_w = reinterpret_cast<uint16_t *>(smem + DW_WIN * DW_WIN * 4);
+  uint16_t *s_w = reinterpret_cast<uint16_t *>(smem + DW_LD * DW_WIN * 4);
   // LDS byte address of smem (0 when it is the kernel's only LDS object, but do not rely on it)
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
   int b = blockIdx.x, tile;
@@ -899,7 +904,7 @@ __global__ __launch_bounds__(1024, 8) void k_downslope_win(const float *__restri
     if (dt_d8_valid(code)) {
       int dy, dx;
       dt_d8_delta(code, dy, dx);
-      mw = (uint32_t)(2 * (dy * DW_WIN + dx) + MW_BIAS);
+      mw = (uint32_t)(2 * (dy * DW_LD + dx) + MW_BIAS);
       if (dy != 0 && dx != 0) mw |= MW_DIAG;
     }
     s_lut[code] = (uint16_t)mw;
@@ -913,21 +918,46 @@ __global__ __launch_bounds__(1024, 8) void k_downslope_win(const float *__restri
   // 112 rows x 28 groups of 4 cells (wx0 is a multiple of 8: float4 / uchar4 stay aligned).  A nodata
   // height is staged as -inf: the walk never moves onto nodata (downslope.py:231-281); a lane that does
   // sees an infinite drop, stops, and is redone by the generic walk.
-  for (int i = threadIdx.x; i < DW_WIN * (DW_WIN / 4); i += 1024) {
-    int r = i / (DW_WIN / 4), c4 = (i - r * (DW_WIN / 4)) * 4;
-    int gy = wy0 + r, gx = wx0 + c4;
-    float4 v;
-    uint32_t mwv[4];
-    if (interior) {
-      v = *reinterpret_cast<const float4 *>(dem + (long long)gy * w.ld + gx);
-      uint32_t codes = *reinterpret_cast<const uint32_t *>(fdr + (long long)gy * w.ld + gx);
-      const uint32_t rowring = (r == 0 || r == DW_WIN - 1) ? (MW_RING | MW_STOP) : 0u;
+  constexpr int NG = DW_WIN * (DW_WIN / 4);  // 3136 groups of 4 cells: up to 4 per thread
+  if (interior) {
+    // all of a thread's loads first (one memory round trip per workgroup instead of three), then decode
+    float4 vv[4];
+    uint32_t cc[4];
 #pragma unroll
-      for (int k = 0; k < 4; k++) mwv[k] = (uint32_t)s_lut[(codes >> (8 * k)) & 0xFFu] | rowring;
-      if (c4 == 0) mwv[0] |= MW_RING | MW_STOP;
-      if (c4 == DW_WIN - 4) mwv[3] |= MW_RING | MW_STOP;
-    } else {
-      v = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int u = 0; u < 4; u++) {
+      int i = threadIdx.x + 1024 * u;
+      if (i < NG) {
+        int r = i / (DW_WIN / 4), c4 = (i - r * (DW_WIN / 4)) * 4;
+        long long g = (long long)(wy0 + r) * w.ld + wx0 + c4;
+        vv[u] = *reinterpret_cast<const float4 *>(dem + g);
+        cc[u] = *reinterpret_cast<const uint32_t *>(fdr + g);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      int i = threadIdx.x + 1024 * u;
+      if (i < NG) {
+        int r = i / (DW_WIN / 4), c4 = (i - r * (DW_WIN / 4)) * 4;
+        const uint32_t rowring = (r == 0 || r == DW_WIN - 1) ? (MW_RING | MW_STOP) : 0u;
+        uint32_t m0 = (uint32_t)s_lut[cc[u] & 0xFFu] | rowring | (c4 == 0 ? (MW_RING | MW_STOP) : 0u);
+        uint32_t m1 = (uint32_t)s_lut[(cc[u] >> 8) & 0xFFu] | rowring;
+        uint32_t m2 = (uint32_t)s_lut[(cc[u] >> 16) & 0xFFu] | rowring;
+        uint32_t m3 = (uint32_t)s_lut[cc[u] >> 24] | rowring | (c4 == DW_WIN - 4 ? (MW_RING | MW_STOP) : 0u);
+        float4 v = vv[u];
+        v.x = v.x == DT_NODATA ? ninf : v.x;
+        v.y = v.y == DT_NODATA ? ninf : v.y;
+        v.z = v.z == DT_NODATA ? ninf : v.z;
+        v.w = v.w == DT_NODATA ? ninf : v.w;
+        *reinterpret_cast<float4 *>(&s_z[r * DW_LD + c4]) = v;
+        *reinterpret_cast<uint2 *>(&s_w[r * DW_LD + c4]) = make_uint2(m0 | (m1 << 16), m2 | (m3 << 16));
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < NG; i += 1024) {
+      int r = i / (DW_WIN / 4), c4 = (i - r * (DW_WIN / 4)) * 4;
+      int gy = wy0 + r, gx = wx0 + c4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      uint32_t mwv[4];
       uint32_t codes = 0;
       const bool row_ok = gy >= ya && gy < yb;
       bool rd[4];
@@ -961,14 +991,14 @@ __global__ __launch_bounds__(1024, 8) void k_downslope_win(const float *__restri
         if (r == 0 || r == DW_WIN - 1 || rx == 0 || rx == DW_WIN - 1 || !rd[k]) mw |= MW_RING | MW_STOP;
         mwv[k] = mw;
       }
+      v.x = v.x == DT_NODATA ? ninf : v.x;
+      v.y = v.y == DT_NODATA ? ninf : v.y;
+      v.z = v.z == DT_NODATA ? ninf : v.z;
+      v.w = v.w == DT_NODATA ? ninf : v.w;
+      *reinterpret_cast<float4 *>(&s_z[r * DW_LD + c4]) = v;
+      *reinterpret_cast<uint2 *>(&s_w[r * DW_LD + c4]) =
+          make_uint2(mwv[0] | (mwv[1] << 16), mwv[2] | (mwv[3] << 16));
     }
-    v.x = v.x == DT_NODATA ? ninf : v.x;
-    v.y = v.y == DT_NODATA ? ninf : v.y;
-    v.z = v.z == DT_NODATA ? ninf : v.z;
-    v.w = v.w == DT_NODATA ? ninf : v.w;
-    *reinterpret_cast<float4 *>(&s_z[r * DW_WIN + c4]) = v;
-    *reinterpret_cast<uint2 *>(&s_w[r * DW_WIN + c4]) =
-        make_uint2(mwv[0] | (mwv[1] << 16), mwv[2] | (mwv[3] << 16));
   }
   __syncthreads();
   const double dcard = px, ddiag = px * sqrt(2.0);
@@ -978,7 +1008,7 @@ __global__ __launch_bounds__(1024, 8) void k_downslope_win(const float *__restri
     int cy = c / DW_CORE, cx = c - cy * DW_CORE;
     int y0 = tyi * DW_CORE + cy, x0 = txi * DW_CORE + cx;
     if (y0 >= w.H || x0 >= w.W) continue;
-    const int pos0 = (cy + DW_M) * DW_WIN + cx + DW_M;
+    const int pos0 = (cy + DW_M) * DW_LD + cx + DW_M;
     float z0 = s_z[pos0];
     long long o = (long long)y0 * w.ld + x0;
     if (z0 <= DT_NODATA) {
@@ -986,42 +1016,63 @@ __global__ __launch_bounds__(1024, 8) void k_downslope_win(const float *__restri
       continue;
     }
     float drop = 0.0f;
-    uint32_t loop = 0, ndacc = 0;  // moves made; diagonal moves (in units of MW_DIAG)
     bool failed = false, slow = false, unresolved = false;
     // Fast walk inside the window.  (double)drop < dz  <=>  drop < dzf (dzf = smallest float >= dz).
     // q2 = LDS byte address of the current cell's move word minus the array's offset; the next cell's
-    // height and move word are fetched together.
-    uint32_t q2 = lds0 + 2u * (uint32_t)pos0;
-    uint32_t mw = s_w[pos0];
-    // a plain divergent loop (exec-masked, one backward branch); the 5000-move cap of
-    // downslope.py:303-304 is part of the loop condition
-    bool running = drop < dzf && mw < MW_STOP;
-#pragma nounroll
-    while (running) {
-      q2 = q2 + (mw & MW_OFF) - (uint32_t)MW_BIAS;
-      ndacc += mw & MW_DIAG;
-      loop++;
-      uint32_t a4 = (q2 << 1) + neg2lds0;
+    // height and move word are fetched together.  The loop is written out: the compiler's version spends
+    // as many scalar instructions on exec-mask bookkeeping as vector instructions on the walk, and the
+    // kernel is bound by instruction issue.  Here the two stop tests are v_cmpx (they clear the lanes
+    // that stop straight in EXEC) and the bookkeeping is ONE add: acc += move word + 2^19, i.e. the number
+    // of moves in bits 19.. and the sum of the move words below (offsets, biased, + 0x400 per diagonal
+    // move; < 2^19 for up to 256 moves).  The offsets sum to the distance walked in LDS, so the
+    // diagonal count falls out afterwards.  7 VALU + 2 LDS instructions per move.  A walk still running
+    // after 256 moves inside the window (a spiral or a D8 cycle) is left to the generic walk, which also
+    // owns the 5000-move cap of downslope.py:303-304.
+    const uint32_t q2_0 = lds0 + 2u * (uint32_t)pos0;
+    uint32_t q2 = q2_0, mw = s_w[pos0], acc = 0;
+    {
+      uint32_t t, cnt;
       float zt;
-      asm volatile("ds_read_b32 %0, %2\n\tds_read_u16 %1, %3 offset:%4\n\ts_waitcnt lgkmcnt(0)"
-                   : "=v"(zt), "=v"(mw)
-                   : "v"(a4), "v"(q2), "n"(DW_WIN * DW_WIN * 4)
-                   : "memory");
-      drop = z0 - zt;
-      running = drop < dzf && mw < MW_STOP && loop < 5000u;
+      uint64_t sv;
+      asm volatile(
+          "s_mov_b64 %[sv], exec\n\t"
+          "s_movk_i32 %[cnt], 255\n\t"
+          "v_cmpx_gt_f32 vcc, %[dzf], %[drop]\n\t"
+          "v_cmpx_gt_u32 vcc, 0x8000, %[mw]\n\t"
+          "s_cbranch_execz 2f\n"
+          "1:\n\t"
+          "v_and_b32 %[t], 0x3ff, %[mw]\n\t"
+          "v_add3_u32 %[acc], %[acc], %[mw], %[k19]\n\t"
+          "v_add3_u32 %[q2], %[q2], %[t], %[nbias]\n\t"
+          "v_lshl_add_u32 %[t], %[q2], 1, %[n2l]\n\t"
+          "ds_read_b32 %[zt], %[t]\n\t"
+          "ds_read_u16 %[mw], %[q2] offset:%[woff]\n\t"
+          "s_sub_u32 %[cnt], %[cnt], 1\n\t"
+          "s_waitcnt lgkmcnt(0)\n\t"
+          "v_sub_f32 %[drop], %[z0], %[zt]\n\t"
+          "s_cbranch_scc1 2f\n\t"  // borrow: that was the 256th move, hand over
+          "v_cmpx_gt_f32 vcc, %[dzf], %[drop]\n\t"
+          "v_cmpx_gt_u32 vcc, 0x8000, %[mw]\n\t"
+          "s_cbranch_execnz 1b\n"
+          "2:\n\t"
+          "s_mov_b64 exec, %[sv]"
+          : [q2] "+v"(q2), [mw] "+v"(mw), [acc] "+v"(acc), [drop] "+v"(drop), [t] "=&v"(t), [zt] "=&v"(zt),
+            [sv] "=&s"(sv), [cnt] "=&s"(cnt)
+          : [z0] "v"(z0), [dzf] "s"(dzf), [nbias] "s"(0u - (uint32_t)MW_BIAS), [n2l] "s"(neg2lds0),
+            [k19] "s"(1u << 19), [woff] "n"(DW_LD * DW_WIN * 4)
+          : "vcc", "scc", "memory");
     }
+    const uint32_t loop = acc >> 19;  // moves made
+    // sum of the move words = (q2 - q2_0) + MW_BIAS * moves + MW_DIAG * diagonal moves
+    const uint32_t ndacc = (acc & 0x7FFFFu) - (q2 - q2_0) - (uint32_t)MW_BIAS * loop;
     if (drop < dzf) {
-      // :303-304 / :518-521: 5000 moves without reaching the drop (the cap precedes the drop test, but a
-      // lane that reached the drop on its 5000th move is also failed by the reference)
-      if (loop == 5000u) failed = true;
-      // stopped on a move word: a non-D8 code never moves again (the reference spins to its cap), a move
-      // off the raster stops the walk (downslope.py:209-228); the ring continues below
-      else if (mw & (MW_BADCODE | MW_EDGE)) failed = true;
+      // stopped on a move word: a move off the raster stops the walk (downslope.py:209-228); a non-D8
+      // code never moves again and the reference spins to its cap: same outcome, "failed" with the walk so
+      // far; the ring and the 255-move limit continue below
+      if (mw & (MW_BADCODE | MW_EDGE)) failed = true;
       else slow = true;
     } else if (drop == __builtin_inff()) {
       slow = true;  // stepped onto a nodata cell (staged as -inf): the reference stops one move earlier
-    } else if (loop == 5000u) {
-      failed = true;
     }
     double dist = 0.0;
     if (!slow) {
@@ -1039,8 +1090,8 @@ __global__ __launch_bounds__(1024, 8) void k_downslope_win(const float *__restri
       int y = y0, x = x0;
       dist = 0.0;
       drop = 0.0f;
-      loop = 0;
       failed = false;
+      uint32_t moves = 0;
       while ((double)drop < dz) {
         if (!dt_readable(w, y, x)) { unresolved = true; break; }  // beyond this rank's halo
         uint32_t code = fdr[(long long)y * w.ld + x];
@@ -1056,7 +1107,7 @@ __global__ __launch_bounds__(1024, 8) void k_downslope_win(const float *__restri
         x = nx;
         dist += (dy != 0 && dx != 0) ? ddiag : dcard;
         drop = z0 - zt;
-        if (++loop == 5000u) { failed = true; break; }
+        if (++moves == 5000u) { failed = true; break; }
       }
     }
     if (unresolved) {  // the walk left the memory of this rank: a wider halo is needed

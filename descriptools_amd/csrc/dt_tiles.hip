@@ -813,8 +813,11 @@ __global__ __launch_bounds__(256) void k_fh_tile3(const uint8_t *__restrict__ fd
                                                  FhRemote rem, double px, float *__restrict__ fdist,
                                                  int32_t *__restrict__ idx32, long long *__restrict__ idx64,
                                                  float *__restrict__ hand, int32_t *__restrict__ a_river) {
-  __shared__ unsigned long long s_st[NT];  // per-END-CELL payload table {river height, accumulation}
-  __shared__ unsigned long long s_x[PS];   // resolved word of the node each exit cell steps onto (+ the step)
+  // per exit slot: the resolved word of the node the exit cell steps onto (+ the step), and the payload
+  // {river height, river accumulation} of the river cell it resolves to.  4 KiB of LDS: the kernel streams
+  // 28 B/cell and needs the occupancy, not a 32 KiB per-cell table.
+  __shared__ unsigned long long s_x[PS];
+  __shared__ unsigned long long s_pay[PS];
   const int tile = blockIdx.x;
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int y0 = ty * TH, x0 = tx * TW;
@@ -825,6 +828,8 @@ __global__ __launch_bounds__(256) void k_fh_tile3(const uint8_t *__restrict__ fd
     unsigned long long s = cache[(size_t)tile * NT + f];
     uint32_t sp = (uint32_t)(s >> 32);
     unsigned long long o = fht_pack(FHT_DEAD, 0, FHT_DONE);
+    float zr = DT_NODATA;
+    int32_t ar = -100;
     // only exit cells (a finished word pointing at itself with kind EXIT / REXIT) are looked up
     bool ex = sp == ((uint32_t)f | (K_EXIT << 12)), rex = sp == ((uint32_t)f | (K_REXIT << 12));
     if (ex || rex) {
@@ -837,52 +842,30 @@ __global__ __launch_bounds__(256) void k_fh_tile3(const uint8_t *__restrict__ fd
       uint32_t nncf = (uint32_t)(ns & 0xFFFFu);
       bool diag = dy != 0 && dx != 0;
       // not done after all rounds == longer than the cap (or an unresolved rank exit)
-      if ((nncf & FHT_DONE) && nptr != FHT_DEAD)
+      if ((nncf & FHT_DONE) && nptr != FHT_DEAD) {
         o = fht_pack(nptr, nnd + (diag ? 1u : 0u), ((nncf & 0x7FFFu) + (diag ? 0u : 1u)) | FHT_DONE);
-    }
-    s_x[threadIdx.x] = o;
-  }
-  unsigned long long wd[CPT];
-#pragma unroll
-  for (int j = 0; j < CPT; j++) wd[j] = cache[(size_t)tile * NT + threadIdx.x + 256 * j];
-  __syncthreads();
-  // payload table {river height, river accumulation} per END cell: the river cell's own values for
-  // in-tile river ends, the resolved (possibly remote) river's for exit ends -- 252 gathers per tile
-  // instead of 2 per cell
-  float zc[CPT];  // own height (also needed for HAND)
-#pragma unroll
-  for (int j = 0; j < CPT; j++) {
-    int c = threadIdx.x + 256 * j;
-    int y = y0 + c / TW, x = x0 + c % TW;
-    zc[j] = DT_NODATA;
-    if (y >= w.H || x >= w.W) continue;
-    long long o = (long long)y * w.ld + x;
-    if (dem) zc[j] = dem[o];
-    uint32_t ptr = (uint32_t)(wd[j] >> 32), ncf = (uint32_t)(wd[j] & 0xFFFFu);
-    if (!(ncf & FHT_DONE) || (ptr & 0xFFFu) != (uint32_t)c) continue;  // not the end cell of a path
-    uint32_t kind = (ptr >> 12) & 7u;
-    float zr = DT_NODATA;
-    int32_t ar = -100;
-    if (kind == K_RIVER) {
-      zr = zc[j];
-      if (acc32) ar = acc32[o];
-    } else if (kind == K_EXIT || kind == K_REXIT) {
-      unsigned long long xs = s_x[dt_slot_of(c / TW, c % TW)];
-      uint32_t xptr = (uint32_t)(xs >> 32);
-      if (xptr != FHT_DEAD) {
-        if (xptr & FHT_REMOTE) {
-          zr = rem.zr[xptr & ~FHT_REMOTE];
-          ar = rem.ar[xptr & ~FHT_REMOTE];
+        if (nptr & FHT_REMOTE) {
+          zr = rem.zr[nptr & ~FHT_REMOTE];
+          ar = rem.ar[nptr & ~FHT_REMOTE];
         } else {
-          long long ro = (long long)(xptr / (uint32_t)w.W) * w.ld + (xptr % (uint32_t)w.W);
+          long long ro = (long long)(nptr / (uint32_t)w.W) * w.ld + (nptr % (uint32_t)w.W);
           if (dem) zr = dem[ro];
           if (acc32) ar = acc32[ro];
         }
       }
-    } else {
-      continue;
     }
-    s_st[c] = ((unsigned long long)(uint32_t)ar << 32) | (unsigned long long)__float_as_uint(zr);
+    s_x[threadIdx.x] = o;
+    s_pay[threadIdx.x] = ((unsigned long long)(uint32_t)ar << 32) | (unsigned long long)__float_as_uint(zr);
+  }
+  unsigned long long wd[CPT];
+#pragma unroll
+  for (int j = 0; j < CPT; j++) wd[j] = cache[(size_t)tile * NT + threadIdx.x + 256 * j];
+  float zc[CPT];  // own height (needed for HAND)
+#pragma unroll
+  for (int j = 0; j < CPT; j++) {
+    int c = threadIdx.x + 256 * j;
+    int y = y0 + c / TW, x = x0 + c % TW;
+    zc[j] = (dem && y < w.H && x < w.W) ? dem[(long long)y * w.ld + x] : DT_NODATA;
   }
   __syncthreads();
   const double dcard = px, ddiag = px * sqrt(2.0);
@@ -914,7 +897,19 @@ __global__ __launch_bounds__(256) void k_fh_tile3(const uint8_t *__restrict__ fd
     }
     const bool remote = ok && (ridx & FHT_REMOTE) != 0u;
     const uint32_t key = ridx & ~FHT_REMOTE;
-    unsigned long long pay = ok ? s_st[f] : 0ull;
+    // payload: the river cell's own height / accumulation when the path ends on a river cell of this tile
+    // (a gather inside the tile's own rows), the exit slot's resolved payload otherwise
+    unsigned long long pay = 0ull;
+    if (ok) {
+      if (kind == K_RIVER) {
+        long long ro = (long long)(y0 + (int)f / TW) * w.ld + x0 + (int)f % TW;
+        float zr = dem ? dem[ro] : DT_NODATA;
+        int32_t ar = acc32 ? acc32[ro] : -100;
+        pay = ((unsigned long long)(uint32_t)ar << 32) | (unsigned long long)__float_as_uint(zr);
+      } else {
+        pay = s_pay[dt_slot_of((int)f / TW, (int)f % TW)];
+      }
+    }
     long long o = (long long)y * w.ld + x;
     if (fdist) fdist[o] = ok ? (float)(dcard * (double)nc + ddiag * (double)nd) : DT_NODATA;
     if (idx32) idx32[o] = (ok && !remote) ? (int32_t)ridx : -100;

@@ -374,3 +374,22 @@ def test_evaluate_resident_matches_host_api(dt):
     assert res["correctness"] == c and res["fit"] == f
     # the int16 pipeline of the example gives the same class counts (exact small integers in float32)
     assert np.array_equal(res["counts"], np.bincount(klass.reshape(-1).astype(np.int64), minlength=4))
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_downslope_arbitrary_direction_field(dt, seed):
+    """random D8 codes (cycles, spirals, non-D8 codes, moves off the raster), rough and flat terrain, nodata:
+    every exit of the windowed walk (drop reached, stop flags, window ring, the 256-move limit, stepping
+    onto nodata, the unsafe-rounding recheck) against the oracle's literal walk."""
+    rng = np.random.default_rng(seed)
+    H, W = 333, 417
+    codes = np.array([1, 2, 4, 8, 16, 32, 64, 128, 0, 3, 255], np.uint8)
+    fdr = codes[rng.integers(0, len(codes), size=(H, W))]
+    fdr[rng.random((H, W)) < 0.5] = 4
+    dem = (rng.random((H, W)) * 40).astype(np.float32)
+    dem[:, 200:] = np.float32(7.25)              # flat half: walks run until a cycle, the edge or the cap
+    dem[rng.random((H, W)) < 0.02] = -100
+    for dz in (5.0, 0.3):
+        want = oracle.downslope(dem, fdr, 10.0, dz)
+        got = dt.downslope.downsloper(dem, fdr, 10.0, dz)
+        assert np.array_equal(got, want, equal_nan=True), int((got != want).sum())
