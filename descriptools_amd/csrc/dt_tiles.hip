@@ -857,6 +857,103 @@ __global__ __launch_bounds__(256) void k_fh_tile3(const uint8_t *__restrict__ fd
     s_x[threadIdx.x] = o;
     s_pay[threadIdx.x] = ((unsigned long long)(uint32_t)ar << 32) | (unsigned long long)__float_as_uint(zr);
   }
+  // block-uniform: whole 64-cell rows of this tile are inside the core and every raster row is 16-byte
+  // aligned -> each lane handles 4 consecutive cells with 16-byte loads and stores
+  const bool vec = x0 + TW <= w.W && (w.ld & 3) == 0 && (!dem || ((uintptr_t)dem & 15) == 0) &&
+                   (!fdist || ((uintptr_t)fdist & 15) == 0) && (!idx32 || ((uintptr_t)idx32 & 15) == 0) &&
+                   (!idx64 || ((uintptr_t)idx64 & 15) == 0) && (!hand || ((uintptr_t)hand & 15) == 0) &&
+                   (!a_river || ((uintptr_t)a_river & 15) == 0);
+  const double dcard = px, ddiag = px * sqrt(2.0);
+  struct CellOut {
+    float fd, h;
+    int32_t i32, ar;
+    long long i64;
+  };
+  // one cell: its pass-1 word s, own height z -> outputs (needs s_x / s_pay: call after the barrier)
+  auto solve = [&](unsigned long long s, float z) -> CellOut {
+    uint32_t ptr = (uint32_t)(s >> 32), nd = (uint32_t)((s >> 16) & 0xFFFFu);
+    uint32_t ncf = (uint32_t)(s & 0xFFFFu), nc = ncf & 0x7FFFu;
+    uint32_t kind = (ptr >> 12) & 7u, f = ptr & 0xFFFu;
+    bool ok = false;
+    uint32_t ridx = 0;  // core-local flat index of the river cell, or FHT_REMOTE | ring index
+    unsigned long long pay = 0ull;
+    if (ncf & FHT_DONE) {
+      if (kind == K_RIVER) {
+        // the path ends on a river cell of this tile: its own height / accumulation (a gather inside the
+        // tile's own rows)
+        ok = true;
+        ridx = (uint32_t)((y0 + (int)f / TW) * w.W + x0 + (int)f % TW);
+        long long ro = (long long)(y0 + (int)f / TW) * w.ld + x0 + (int)f % TW;
+        float zr = dem ? dem[ro] : DT_NODATA;
+        int32_t ar = acc32 ? acc32[ro] : -100;
+        pay = ((unsigned long long)(uint32_t)ar << 32) | (unsigned long long)__float_as_uint(zr);
+      } else if (kind == K_EXIT || kind == K_REXIT) {
+        int slot = dt_slot_of((int)f / TW, (int)f % TW);
+        unsigned long long xs = s_x[slot];
+        uint32_t xptr = (uint32_t)(xs >> 32);
+        if (xptr != FHT_DEAD) {
+          nc += (uint32_t)(xs & 0x7FFFu);
+          nd += (uint32_t)((xs >> 16) & 0xFFFFu);
+          ok = nc + nd <= FHT_CAP;  // flowhand.py:834-837
+          ridx = xptr;
+          pay = s_pay[slot];
+        }
+      }
+    }
+    const bool remote = ok && (ridx & FHT_REMOTE) != 0u;
+    CellOut o;
+    o.fd = ok ? (float)(dcard * (double)nc + ddiag * (double)nd) : DT_NODATA;
+    o.i32 = (ok && !remote) ? (int32_t)ridx : -100;
+    o.i64 = -100;
+    if (idx64 && ok)
+      o.i64 = remote ? rem.gidx[ridx & ~FHT_REMOTE]
+                     : (long long)(w.gy0 + (int)(ridx / (uint32_t)w.W)) * w.Wg + w.gx0 + (int)(ridx % (uint32_t)w.W);
+    o.h = DT_NODATA;
+    if (z != DT_NODATA && ok) {  // flowhand.py:436
+      o.h = z - __uint_as_float((uint32_t)pay);
+      if (o.h < 0.0f && o.h != DT_NODATA) o.h = 0.0f;  // flowhand.py:438
+    }
+    // A_river = fac[idx] carried as payload; cells without a river cell get -100 (GFI is -100 there
+    // anyway: their hand is -100, gfi.py:289)
+    o.ar = ok ? (int32_t)(uint32_t)(pay >> 32) : -100;
+    return o;
+  };
+  if (vec) {
+    constexpr int VPT = NT / 4 / 256;  // 4 groups of 4 cells per lane
+    uint4 wa[VPT], wb[VPT];
+    float4 z4[VPT];
+#pragma unroll
+    for (int u = 0; u < VPT; u++) {
+      int c = 4 * (threadIdx.x + 256 * u);
+      const uint4 *cp = reinterpret_cast<const uint4 *>(cache + (size_t)tile * NT + c);
+      wa[u] = cp[0];
+      wb[u] = cp[1];
+      int y = y0 + c / TW;
+      z4[u] = make_float4(DT_NODATA, DT_NODATA, DT_NODATA, DT_NODATA);
+      if (dem && y < w.H) z4[u] = *reinterpret_cast<const float4 *>(dem + (long long)y * w.ld + x0 + c % TW);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < VPT; u++) {
+      int c = 4 * (threadIdx.x + 256 * u);
+      int y = y0 + c / TW;
+      if (y >= w.H) continue;
+      long long o = (long long)y * w.ld + x0 + c % TW;
+      CellOut r0 = solve(((unsigned long long)wa[u].y << 32) | wa[u].x, z4[u].x);
+      CellOut r1 = solve(((unsigned long long)wa[u].w << 32) | wa[u].z, z4[u].y);
+      CellOut r2 = solve(((unsigned long long)wb[u].y << 32) | wb[u].x, z4[u].z);
+      CellOut r3 = solve(((unsigned long long)wb[u].w << 32) | wb[u].z, z4[u].w);
+      if (fdist) *reinterpret_cast<float4 *>(fdist + o) = make_float4(r0.fd, r1.fd, r2.fd, r3.fd);
+      if (idx32) *reinterpret_cast<int4 *>(idx32 + o) = make_int4(r0.i32, r1.i32, r2.i32, r3.i32);
+      if (idx64) {
+        *reinterpret_cast<longlong2 *>(idx64 + o) = make_longlong2(r0.i64, r1.i64);
+        *reinterpret_cast<longlong2 *>(idx64 + o + 2) = make_longlong2(r2.i64, r3.i64);
+      }
+      if (hand) *reinterpret_cast<float4 *>(hand + o) = make_float4(r0.h, r1.h, r2.h, r3.h);
+      if (a_river) *reinterpret_cast<int4 *>(a_river + o) = make_int4(r0.ar, r1.ar, r2.ar, r3.ar);
+    }
+    return;
+  }
   unsigned long long wd[CPT];
 #pragma unroll
   for (int j = 0; j < CPT; j++) wd[j] = cache[(size_t)tile * NT + threadIdx.x + 256 * j];
@@ -868,68 +965,18 @@ __global__ __launch_bounds__(256) void k_fh_tile3(const uint8_t *__restrict__ fd
     zc[j] = (dem && y < w.H && x < w.W) ? dem[(long long)y * w.ld + x] : DT_NODATA;
   }
   __syncthreads();
-  const double dcard = px, ddiag = px * sqrt(2.0);
 #pragma unroll
   for (int j = 0; j < CPT; j++) {
     int c = threadIdx.x + 256 * j;
     int y = y0 + c / TW, x = x0 + c % TW;
     if (y >= w.H || x >= w.W) continue;
-    unsigned long long s = wd[j];
-    uint32_t ptr = (uint32_t)(s >> 32), nd = (uint32_t)((s >> 16) & 0xFFFFu);
-    uint32_t ncf = (uint32_t)(s & 0xFFFFu), nc = ncf & 0x7FFFu;
-    uint32_t kind = (ptr >> 12) & 7u, f = ptr & 0xFFFu;
-    bool ok = false;
-    uint32_t ridx = 0;  // core-local flat index of the river cell, or FHT_REMOTE | ring index
-    if (ncf & FHT_DONE) {
-      if (kind == K_RIVER) {
-        ok = true;
-        ridx = (uint32_t)((y0 + (int)f / TW) * w.W + x0 + (int)f % TW);
-      } else if (kind == K_EXIT || kind == K_REXIT) {
-        unsigned long long xs = s_x[dt_slot_of((int)f / TW, (int)f % TW)];
-        uint32_t xptr = (uint32_t)(xs >> 32);
-        if (xptr != FHT_DEAD) {
-          nc += (uint32_t)(xs & 0x7FFFu);
-          nd += (uint32_t)((xs >> 16) & 0xFFFFu);
-          ok = nc + nd <= FHT_CAP;  // flowhand.py:834-837
-          ridx = xptr;
-        }
-      }
-    }
-    const bool remote = ok && (ridx & FHT_REMOTE) != 0u;
-    const uint32_t key = ridx & ~FHT_REMOTE;
-    // payload: the river cell's own height / accumulation when the path ends on a river cell of this tile
-    // (a gather inside the tile's own rows), the exit slot's resolved payload otherwise
-    unsigned long long pay = 0ull;
-    if (ok) {
-      if (kind == K_RIVER) {
-        long long ro = (long long)(y0 + (int)f / TW) * w.ld + x0 + (int)f % TW;
-        float zr = dem ? dem[ro] : DT_NODATA;
-        int32_t ar = acc32 ? acc32[ro] : -100;
-        pay = ((unsigned long long)(uint32_t)ar << 32) | (unsigned long long)__float_as_uint(zr);
-      } else {
-        pay = s_pay[dt_slot_of((int)f / TW, (int)f % TW)];
-      }
-    }
+    CellOut r = solve(wd[j], zc[j]);
     long long o = (long long)y * w.ld + x;
-    if (fdist) fdist[o] = ok ? (float)(dcard * (double)nc + ddiag * (double)nd) : DT_NODATA;
-    if (idx32) idx32[o] = (ok && !remote) ? (int32_t)ridx : -100;
-    if (idx64) {
-      long long g = -100;
-      if (ok) g = remote ? rem.gidx[key]
-                         : (long long)(w.gy0 + (int)(ridx / (uint32_t)w.W)) * w.Wg + w.gx0 + (int)(ridx % (uint32_t)w.W);
-      idx64[o] = g;
-    }
-    if (hand) {
-      float h = DT_NODATA, z = zc[j];
-      if (z != DT_NODATA && ok) {  // flowhand.py:436
-        h = z - __uint_as_float((uint32_t)pay);
-        if (h < 0.0f && h != DT_NODATA) h = 0.0f;  // flowhand.py:438
-      }
-      hand[o] = h;
-    }
-    // A_river = fac[idx] carried as payload; cells without a river cell get -100 (GFI is -100 there
-    // anyway: their hand is -100, gfi.py:289)
-    if (a_river) a_river[o] = ok ? (int32_t)(uint32_t)(pay >> 32) : -100;
+    if (fdist) fdist[o] = r.fd;
+    if (idx32) idx32[o] = r.i32;
+    if (idx64) idx64[o] = r.i64;
+    if (hand) hand[o] = r.h;
+    if (a_river) a_river[o] = r.ar;
   }
 }
 
