@@ -344,6 +344,18 @@ __global__ __launch_bounds__(256) void k_fa_tile3(const uint8_t *__restrict__ fd
     s_delta[c] = 0u;
     s_cyc[c] = 0;
   }
+  // pass 1's counts and the heights are fetched now, so that their latency hides behind the serial walks
+  int32_t av[CPT];
+  float zv[CPT];
+#pragma unroll
+  for (int j = 0; j < CPT; j++) {
+    int c = threadIdx.x + 256 * j;
+    int y = y0 + c / TW, x = x0 + c % TW;
+    bool in = y < w.H && x < w.W;
+    long long o = (long long)y * w.ld + x;
+    av[j] = in ? acc32[o] : -100;
+    zv[j] = (HAS_DEM && in) ? dem[o] : 0.0f;
+  }
   __syncthreads();
   if (e != 0ull) {
     int ly, lx;
@@ -358,15 +370,16 @@ __global__ __launch_bounds__(256) void k_fa_tile3(const uint8_t *__restrict__ fd
     }
   }
   __syncthreads();
+#pragma unroll
   for (int j = 0; j < CPT; j++) {
     int c = threadIdx.x + 256 * j;
     int y = y0 + c / TW, x = x0 + c % TW;
     if (y >= w.H || x >= w.W) continue;
     long long o = (long long)y * w.ld + x;
-    int32_t v = acc32[o];
+    int32_t v = av[j];
     if (v != -100) v += (int32_t)s_delta[c];
     if (s_cyc[c]) v = -100;
-    if (HAS_DEM && dem[o] <= DT_NODATA) v = -100;
+    if (HAS_DEM && zv[j] <= DT_NODATA) v = -100;
     acc32[o] = v;
     if (W_RIVER) river[o] = v > river_thr ? 1 : 0;
   }
@@ -394,13 +407,22 @@ __global__ __launch_bounds__(256) void k_fa_jump_init(const unsigned long long *
   jump[n] = j;
   nxt[n] = j;  // the un-doubled successor: k_fa_propagate walks it
 }
-__global__ __launch_bounds__(256) void k_fa_jump(uint32_t *__restrict__ jump, int64_t nnodes) {
-  int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (n >= nnodes) return;
-  uint32_t j = __hip_atomic_load(&jump[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (j == FA_NONE || (j & J_TERM)) return;
-  uint32_t t = __hip_atomic_load(&jump[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(&jump[n], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__global__ __launch_bounds__(256) void k_fa_jump(uint32_t *__restrict__ jump, int64_t nnodes,
+                                                 int *__restrict__ flags, int round) {
+  // flags[r] != 0: after round r some list is still open; rounds after the first quiet one return at once
+  if (round > 0 && flags[round - 1] == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) flags[round] = 0;
+    return;
+  }
+  bool pending = false;
+  for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < nnodes; n += (int64_t)gridDim.x * 256) {
+    uint32_t j = __hip_atomic_load(&jump[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (j == FA_NONE || (j & J_TERM)) continue;
+    uint32_t t = __hip_atomic_load(&jump[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&jump[n], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    pending = pending || !(t == FA_NONE || (t & J_TERM));
+  }
+  if (__any(pending) && (threadIdx.x & 63) == 0) flags[round] = 1;
 }
 
 // one row per cell of the core ring: A = cells of this rank draining out through the cell (0 unless
@@ -506,7 +528,10 @@ int dt_launch_fa_local(hipStream_t s, const DtWin &w, const uint8_t *fdr, void *
     hipLaunchKernelGGL(k_fa_jump_init, gn, b, 0, s, f.rec, f.nnodes, f.entry_of, f.state, f.jump, f.nxt);
     // a path crosses each tile perimeter node at most once; 2^24 tile crossings inside one rank
     // would need a path longer than any raster this library accepts per device
-    for (int r = 0; r < 24; r++) hipLaunchKernelGGL(k_fa_jump, gn, b, 0, s, f.jump, f.nnodes);
+    int *flags = (int *)((char *)f.nxt + dt_align256((size_t)f.nnodes * 4));  // the layout's spare 256 bytes
+    DT_HIP(hipMemsetAsync(flags, 0, 128, s));
+    dim3 gj(gn.x < 4096u ? gn.x : 4096u);
+    for (int r = 0; r < 24; r++) hipLaunchKernelGGL(k_fa_jump, gj, b, 0, s, f.jump, f.nnodes, flags, r);
   }
   return DT_OK;
 }
@@ -727,22 +752,33 @@ __global__ __launch_bounds__(256) void k_fh_ghost_init(unsigned long long *__res
 }
 
 // pass 2: pointer doubling over the perimeter nodes (same word format as the v1 raster kernel)
-__global__ __launch_bounds__(256) void k_fh_node_jump(unsigned long long *__restrict__ state, int64_t n) {
-  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  unsigned long long s = __hip_atomic_load(&state[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  uint32_t ncf = (uint32_t)(s & 0xFFFFu);
-  if (ncf & FHT_DONE) return;
-  uint32_t ptr = (uint32_t)(s >> 32), nd = (uint32_t)((s >> 16) & 0xFFFFu);
-  if (ptr == (uint32_t)i) return;  // unresolved ghost
-  unsigned long long t = __hip_atomic_load(&state[ptr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  uint32_t tptr = (uint32_t)(t >> 32), tnd = (uint32_t)((t >> 16) & 0xFFFFu);
-  uint32_t tncf = (uint32_t)(t & 0xFFFFu);
-  uint32_t nnc = ncf + (tncf & 0x7FFFu), nnd = nd + tnd;
-  unsigned long long o;
-  if (((tncf & FHT_DONE) && tptr == FHT_DEAD) || nnc + nnd > FHT_CAP) o = fht_pack(FHT_DEAD, 0, FHT_DONE);
-  else o = fht_pack(tptr, nnd, nnc | (tncf & FHT_DONE));
-  __hip_atomic_store(&state[i], o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__global__ __launch_bounds__(256) void k_fh_node_jump(unsigned long long *__restrict__ state, int64_t n,
+                                                      int *__restrict__ flags, int round) {
+  // flags[r] != 0: round r left a node that can still make progress.  Rounds after the first quiet one are
+  // no-ops and return at once (the bound of 15 rounds is for 20000-move chains; typical rasters need ~10).
+  if (flags && round > 0 && flags[round - 1] == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) flags[round] = 0;
+    return;
+  }
+  bool pending = false;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    unsigned long long s = __hip_atomic_load(&state[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t ncf = (uint32_t)(s & 0xFFFFu);
+    uint32_t ptr = (uint32_t)(s >> 32), nd = (uint32_t)((s >> 16) & 0xFFFFu);
+    if (!(ncf & FHT_DONE) && ptr != (uint32_t)i) {  // not finished, not an unresolved ghost
+      unsigned long long t = __hip_atomic_load(&state[ptr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      uint32_t tptr = (uint32_t)(t >> 32), tnd = (uint32_t)((t >> 16) & 0xFFFFu);
+      uint32_t tncf = (uint32_t)(t & 0xFFFFu);
+      uint32_t nnc = ncf + (tncf & 0x7FFFu), nnd = nd + tnd;
+      unsigned long long o;
+      if (((tncf & FHT_DONE) && tptr == FHT_DEAD) || nnc + nnd > FHT_CAP) o = fht_pack(FHT_DEAD, 0, FHT_DONE);
+      else o = fht_pack(tptr, nnd, nnc | (tncf & FHT_DONE));
+      __hip_atomic_store(&state[i], o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // still open and not parked on an unresolved ghost (a fixed point pointing at itself)
+      pending = pending || (!(o & (unsigned long long)FHT_DONE) && tptr != ptr);
+    }
+  }
+  if (flags && __any(pending) && (threadIdx.x & 63) == 0) flags[round] = 1;
 }
 
 // rank level: one row per core-ring cell describing the path that ENTERS the rank there:
@@ -1012,7 +1048,11 @@ int dt_launch_fh_local(hipStream_t s, const DtWin &w, const uint8_t *fdr, const 
   hipLaunchKernelGGL(k_fh_tile1, gt, b, 0, s, fdr, river, w, f.tiles_x, (uint32_t)f.nnodes, f.nodes, f.cache);
   hipLaunchKernelGGL(k_fh_ghost_init, dim3((unsigned)((f.P + 255) / 256)), b, 0, s, f.nodes, (uint32_t)f.nnodes, f.P);
   // 15 rounds resolve every chain of <= 20000 moves (each node hop is >= 1 move; 2^15 > 20000)
-  for (int r = 0; r < 15; r++) hipLaunchKernelGGL(k_fh_node_jump, gn, b, 0, s, f.nodes, f.nnodes + f.P);
+  int *flags = (int *)((char *)f.cache + dt_align256((size_t)f.ntiles * NT * 8));  // the layout's spare 256 bytes
+  DT_HIP(hipMemsetAsync(flags, 0, 64, s));
+  dim3 gj(gn.x < 4096u ? gn.x : 4096u);  // grid-stride: a quiet round costs a few microseconds
+  for (int r = 0; r < 15; r++)
+    hipLaunchKernelGGL(k_fh_node_jump, gj, b, 0, s, f.nodes, f.nnodes + f.P, flags, r);
   return DT_OK;
 }
 
@@ -1038,7 +1078,9 @@ int dt_launch_fh_finish(hipStream_t s, const DtWin &w, const float *dem, const u
     hipLaunchKernelGGL(k_fh_ghost_set, dim3((unsigned)((f.P + 255) / 256)), b, 0, s, f.nodes, (uint32_t)f.nnodes,
                        f.P, res_ok, res_nc, res_nd);
     // nodes parked on a ghost pick up its result (they point at it directly: one hop; two for safety)
-    for (int r = 0; r < 2; r++) hipLaunchKernelGGL(k_fh_node_jump, gn, b, 0, s, f.nodes, f.nnodes + f.P);
+    dim3 gj(gn.x < 4096u ? gn.x : 4096u);
+    for (int r = 0; r < 2; r++)
+      hipLaunchKernelGGL(k_fh_node_jump, gj, b, 0, s, f.nodes, f.nnodes + f.P, (int *)nullptr, r);
   }
   FhRemote rem{rem_gidx, rem_zr, rem_ar};
   (void)river;
@@ -1285,7 +1327,7 @@ int dt_launch_rank_solve_flowhand(hipStream_t s, int ty, int tx, const int64_t *
   dim3 g((unsigned)((nn + 255) / 256)), b(256);
   hipLaunchKernelGGL(k_rk_fh_build, g, b, 0, s, L, R, nodes);
   // every hop between ranks is >= 1 move: 15 doublings cover the 20000-move cap
-  for (int r = 0; r < 15; r++) hipLaunchKernelGGL(k_fh_node_jump, g, b, 0, s, nodes, (int64_t)nn);
+  for (int r = 0; r < 15; r++) hipLaunchKernelGGL(k_fh_node_jump, g, b, 0, s, nodes, (int64_t)nn, (int *)nullptr, r);
   hipLaunchKernelGGL(k_rk_fh_result, dim3((unsigned)((P_rank + 255) / 256)), b, 0, s, L, R, nodes, rank,
                      (long long)P_rank, res_ok, res_nc, res_nd, gidx, zr, ar);
   return DT_OK;
