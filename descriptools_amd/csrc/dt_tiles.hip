@@ -94,6 +94,19 @@ __device__ __forceinline__ uint32_t dt_tile_next(uint32_t code, int ly, int lx, 
   return (uint32_t)(ny * TW + nx);
 }
 
+// the same for a tile whose cells and their successors all lie inside the core (block-uniform test
+// dt_tile_interior): validity, the D8 delta and the tile bounds are all that is left
+__device__ __forceinline__ bool dt_tile_interior(const DtWin &w, int y0, int x0) {
+  return y0 >= 1 && x0 >= 1 && y0 + TH + 1 <= w.H && x0 + TW + 1 <= w.W;
+}
+__device__ __forceinline__ uint32_t dt_tile_next_interior(uint32_t code, int ly, int lx) {
+  if (!dt_d8_valid(code)) return NX_SINK;
+  int dy, dx;
+  dt_d8_delta(code, dy, dx);
+  uint32_t ny = (uint32_t)(ly + dy), nx = (uint32_t)(lx + dx);
+  return (ny < (uint32_t)TH && nx < (uint32_t)TW) ? ny * TW + nx : NX_EXIT;
+}
+
 // ===========================================================================================
 // Flow accumulation
 // ===========================================================================================
@@ -117,7 +130,10 @@ __device__ __forceinline__ uint32_t dt_tile_next(uint32_t code, int ly, int lx, 
 __device__ __forceinline__ void dt_tile_sums(uint32_t *s_pv, uint32_t *s_recv, uint8_t *s_cyc) {
   uint2 pv[CPT / 2], np[CPT / 2];
   uint2 *s_pv2 = reinterpret_cast<uint2 *>(s_pv);
-  uint2 *s_recv2 = reinterpret_cast<uint2 *>(s_recv);
+  // s_recv: two 16-bit sums per word (cells 2i, 2i + 1).  What a cell receives in one round are the sums of
+  // disjoint subtrees (<= 4096 cells in total) plus, on an in-tile D8 cycle, the one cycle cell 2^k moves
+  // behind it, whose sum is garbage and may be huge: a cell whose sum exceeds the tile size is on such a
+  // cycle and no longer scatters, so a half never carries into its neighbour (<= 8192 per round)
   for (int round = 0; round < 12; round++) {
     int any = 0;
 #pragma unroll
@@ -128,13 +144,13 @@ __device__ __forceinline__ void dt_tile_sums(uint32_t *s_pv, uint32_t *s_recv, u
       np[j].y = pv[j].y & 0xFFFFu;
       if (pv[j].x & PT_ALIVE) {
         uint32_t t = pv[j].x & PT_IDX;
-        atomicAdd(&s_recv[t], pv[j].x >> 16);
+        if ((pv[j].x >> 16) <= (uint32_t)NT) atomicAdd(&s_recv[t >> 1], (pv[j].x >> 16) << ((t & 1u) * 16u));
         np[j].x = s_pv[t] & 0xFFFFu;
         any = 1;
       }
       if (pv[j].y & PT_ALIVE) {
         uint32_t t = pv[j].y & PT_IDX;
-        atomicAdd(&s_recv[t], pv[j].y >> 16);
+        if ((pv[j].y >> 16) <= (uint32_t)NT) atomicAdd(&s_recv[t >> 1], (pv[j].y >> 16) << ((t & 1u) * 16u));
         np[j].y = s_pv[t] & 0xFFFFu;
         any = 1;
       }
@@ -143,9 +159,10 @@ __device__ __forceinline__ void dt_tile_sums(uint32_t *s_pv, uint32_t *s_recv, u
 #pragma unroll
     for (int j = 0; j < CPT / 2; j++) {
       int c2 = threadIdx.x + 256 * j;
-      uint2 r = s_recv2[c2];
-      if (r.x | r.y) s_recv2[c2] = make_uint2(0u, 0u);
-      s_pv2[c2] = make_uint2((((pv[j].x >> 16) + r.x) << 16) | np[j].x, (((pv[j].y >> 16) + r.y) << 16) | np[j].y);
+      uint32_t r = s_recv[c2];
+      if (r) s_recv[c2] = 0u;
+      s_pv2[c2] = make_uint2((((pv[j].x >> 16) + (r & 0xFFFFu)) << 16) | np[j].x,
+                             (((pv[j].y >> 16) + (r >> 16)) << 16) | np[j].y);
     }
     if (!__syncthreads_or(any)) return;
   }
@@ -180,16 +197,24 @@ __global__ __launch_bounds__(256) void k_fa_tile1(const uint8_t *__restrict__ fd
                                                  int32_t *__restrict__ acc32) {
   __shared__ __attribute__((aligned(16))) uint8_t s_fdr[NT];  // reused as the in-tile cycle mask
   __shared__ __attribute__((aligned(16))) uint32_t s_pv[NT];  // val:16 | idx:12 | PT_EXIT | PT_ALIVE
-  __shared__ __attribute__((aligned(16))) uint32_t s_recv[NT];
+  __shared__ __attribute__((aligned(16))) uint32_t s_recv[NT / 2];  // 16-bit sums, two cells per word
   const int tile = blockIdx.x;
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int y0 = ty * TH, x0 = tx * TW;
   dt_tile_load_fdr(fdr, w, y0, x0, s_fdr);
   __syncthreads();
   uint32_t nx[CPT];
-  for (int j = 0; j < CPT; j++) {
-    int c = threadIdx.x + 256 * j;
-    nx[j] = dt_tile_next(s_fdr[c], c / TW, c % TW, y0, x0, w);
+  if (dt_tile_interior(w, y0, x0)) {
+#pragma unroll
+    for (int j = 0; j < CPT; j++) {
+      int c = threadIdx.x + 256 * j;
+      nx[j] = dt_tile_next_interior(s_fdr[c], c / TW, c % TW);
+    }
+  } else {
+    for (int j = 0; j < CPT; j++) {
+      int c = threadIdx.x + 256 * j;
+      nx[j] = dt_tile_next(s_fdr[c], c / TW, c % TW, y0, x0, w);
+    }
   }
   uint32_t my_code = 0, my_flags = 0;  // D8 code of my perimeter cell when it is an exit cell
   if (threadIdx.x < PS) {
@@ -209,7 +234,7 @@ __global__ __launch_bounds__(256) void k_fa_tile1(const uint8_t *__restrict__ fd
     // in-tile path ends there inherits through the jumps
     bool ex = (n == NX_EXIT || n == NX_REXIT);
     s_pv[c] = (1u << 16) | (n < NT ? (n | PT_ALIVE) : ((uint32_t)c | (ex ? PT_EXIT : 0u)));
-    s_recv[c] = 0u;
+    if (j < CPT / 2) s_recv[c] = 0u;
     s_cyc[c] = 0;
   }
   __syncthreads();
@@ -316,7 +341,7 @@ __global__ __launch_bounds__(256) void k_fa_poison(const unsigned long long *__r
 // through every cell of p's in-tile path: one lane per entry cell walks that path adding ext[p] to
 // an LDS delta raster (integer adds: order-free), then delta is added to pass 1's in-tile counts.
 template <bool HAS_DEM, bool W_RIVER>
-__global__ __launch_bounds__(256) void k_fa_tile3(const uint8_t *__restrict__ fdr,
+__global__ __launch_bounds__(256, 5) void k_fa_tile3(const uint8_t *__restrict__ fdr,
                                                  const float *__restrict__ dem, DtWin w, int tiles_x,
                                                  const unsigned long long *__restrict__ ext,
                                                  int32_t *__restrict__ acc32, int32_t river_thr,
@@ -332,9 +357,17 @@ __global__ __launch_bounds__(256) void k_fa_tile3(const uint8_t *__restrict__ fd
   if (threadIdx.x < PS) e = ext[(size_t)tile * PS + threadIdx.x];
   __syncthreads();
   uint32_t nx[CPT];
-  for (int j = 0; j < CPT; j++) {
-    int c = threadIdx.x + 256 * j;
-    nx[j] = dt_tile_next(s_fdr[c], c / TW, c % TW, y0, x0, w);
+  if (dt_tile_interior(w, y0, x0)) {
+#pragma unroll
+    for (int j = 0; j < CPT; j++) {
+      int c = threadIdx.x + 256 * j;
+      nx[j] = dt_tile_next_interior(s_fdr[c], c / TW, c % TW);
+    }
+  } else {
+    for (int j = 0; j < CPT; j++) {
+      int c = threadIdx.x + 256 * j;
+      nx[j] = dt_tile_next(s_fdr[c], c / TW, c % TW, y0, x0, w);
+    }
   }
   __syncthreads();
   uint8_t *s_cyc = s_fdr;
@@ -634,34 +667,64 @@ __device__ __forceinline__ void fht_solve_tile(const FhTile &T, const uint8_t *_
     if (s_riv[c] == 1) riv |= 1u << j;
   }
   __syncthreads();
-  for (int j = 0; j < CPT; j++) {
-    int c = threadIdx.x + 256 * j;
-    int ly = c / TW, lx = c % TW;
-    int y = y0 + ly, x = x0 + lx;
-    uint32_t code = T.s_fdr[c];
-    unsigned long long s;
-    if (y >= w.H || x >= w.W || code == 0u) {
-      s = fht_pack((uint32_t)c | (K_DEAD << 12), 0, FHT_DONE);  // flowhand.py:601
-    } else if ((riv >> j) & 1u) {
-      s = fht_pack((uint32_t)c | (K_RIVER << 12), 0, FHT_DONE);  // flowhand.py:609-612
-    } else if (!dt_d8_valid(code)) {
-      s = fht_pack((uint32_t)c | (K_DEAD << 12), 0, FHT_DONE);  // non-D8 code: revisit test :830
-    } else {
-      int dy, dx;
-      dt_d8_delta(code, dy, dx);
-      int ty = y + dy, tx = x + dx;
-      if (!dt_in_global(w, ty, tx) || fht_fdr_at(T, ly + dy, lx + dx) == 0u) {
-        s = fht_pack((uint32_t)c | (K_DEAD << 12), 0, FHT_DONE);  // raster exit / arrival on fdr==0
-      } else if (!dt_in_core(w, ty, tx)) {
-        s = fht_pack((uint32_t)c | (K_REXIT << 12), 0, FHT_DONE);
-      } else if (ly + dy < 0 || ly + dy >= TH || lx + dx < 0 || lx + dx >= TW) {
-        s = fht_pack((uint32_t)c | (K_EXIT << 12), 0, FHT_DONE);  // the step itself is added by the user
-      } else {
-        bool diag = dy != 0 && dx != 0;
-        s = fht_pack((uint32_t)((ly + dy) * TW + lx + dx), diag ? 1u : 0u, diag ? 0u : 1u);
+  if (dt_tile_interior(w, y0, x0)) {
+    // every cell and every successor is inside the core: no window tests
+#pragma unroll
+    for (int j = 0; j < CPT; j++) {
+      int c = threadIdx.x + 256 * j;
+      int ly = c / TW, lx = c % TW;
+      uint32_t code = T.s_fdr[c];
+      uint32_t ptr = (uint32_t)c | (K_DEAD << 12), lo = FHT_DONE;  // flowhand.py:601 / non-D8 code :830
+      if (code != 0u && ((riv >> j) & 1u)) {
+        ptr = (uint32_t)c | (K_RIVER << 12);  // flowhand.py:609-612
+      } else if (dt_d8_valid(code)) {
+        int dy, dx;
+        dt_d8_delta(code, dy, dx);
+        uint32_t ny = (uint32_t)(ly + dy), nx = (uint32_t)(lx + dx);
+        bool in_tile = ny < (uint32_t)TH && nx < (uint32_t)TW;
+        uint32_t tcode = in_tile ? (uint32_t)T.s_fdr[ny * TW + nx] : fht_fdr_at(T, ly + dy, lx + dx);
+        if (tcode != 0u) {  // else: arrival on fdr == 0 (flowhand.py:826)
+          if (in_tile) {
+            bool diag = dy != 0 && dx != 0;
+            ptr = ny * TW + nx;
+            lo = diag ? (1u << 16) : 1u;
+          } else {
+            ptr = (uint32_t)c | (K_EXIT << 12);  // the step itself is added by the user
+          }
+        }
       }
+      T.s_st[c] = ((unsigned long long)ptr << 32) | (unsigned long long)lo;
     }
-    T.s_st[c] = s;
+  } else {
+    for (int j = 0; j < CPT; j++) {
+      int c = threadIdx.x + 256 * j;
+      int ly = c / TW, lx = c % TW;
+      int y = y0 + ly, x = x0 + lx;
+      uint32_t code = T.s_fdr[c];
+      unsigned long long s;
+      if (y >= w.H || x >= w.W || code == 0u) {
+        s = fht_pack((uint32_t)c | (K_DEAD << 12), 0, FHT_DONE);  // flowhand.py:601
+      } else if ((riv >> j) & 1u) {
+        s = fht_pack((uint32_t)c | (K_RIVER << 12), 0, FHT_DONE);  // flowhand.py:609-612
+      } else if (!dt_d8_valid(code)) {
+        s = fht_pack((uint32_t)c | (K_DEAD << 12), 0, FHT_DONE);  // non-D8 code: revisit test :830
+      } else {
+        int dy, dx;
+        dt_d8_delta(code, dy, dx);
+        int ty = y + dy, tx = x + dx;
+        if (!dt_in_global(w, ty, tx) || fht_fdr_at(T, ly + dy, lx + dx) == 0u) {
+          s = fht_pack((uint32_t)c | (K_DEAD << 12), 0, FHT_DONE);  // raster exit / arrival on fdr==0
+        } else if (!dt_in_core(w, ty, tx)) {
+          s = fht_pack((uint32_t)c | (K_REXIT << 12), 0, FHT_DONE);
+        } else if (ly + dy < 0 || ly + dy >= TH || lx + dx < 0 || lx + dx >= TW) {
+          s = fht_pack((uint32_t)c | (K_EXIT << 12), 0, FHT_DONE);  // the step itself is added by the user
+        } else {
+          bool diag = dy != 0 && dx != 0;
+          s = fht_pack((uint32_t)((ly + dy) * TW + lx + dx), diag ? 1u : 0u, diag ? 0u : 1u);
+        }
+      }
+      T.s_st[c] = s;
+    }
   }
   __syncthreads();
   // Pointer doubling in place.  The low 32 bits hold n_diag:16 | done:1 | n_card:15, so ONE integer add
