@@ -192,12 +192,14 @@ __device__ __forceinline__ unsigned long long fa_rec(uint32_t W_, uint32_t xslot
 #define REC_XSLOT(r) ((uint32_t)(((r) >> 16) & 0xFFFFu))
 #define REC_CODE(r) ((uint32_t)(((r) >> 8) & 0xFFu))
 
-__global__ __launch_bounds__(256) void k_fa_tile1(const uint8_t *__restrict__ fdr, DtWin w, int tiles_x,
-                                                 unsigned long long *__restrict__ rec,
-                                                 int32_t *__restrict__ acc32) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_fdr[NT];  // reused as the in-tile cycle mask
+__global__ __launch_bounds__(256, 6) void k_fa_tile1(const uint8_t *__restrict__ fdr, DtWin w, int tiles_x,
+                                                    unsigned long long *__restrict__ rec,
+                                                    int32_t *__restrict__ acc32) {
+  // 24 KiB of LDS: six tiles per CU.  The direction codes are staged through the receive array (free until
+  // the rounds start), which is all zero again when the rounds end and then serves as the cycle mask.
   __shared__ __attribute__((aligned(16))) uint32_t s_pv[NT];  // val:16 | idx:12 | PT_EXIT | PT_ALIVE
   __shared__ __attribute__((aligned(16))) uint32_t s_recv[NT / 2];  // 16-bit sums, two cells per word
+  uint8_t *s_fdr = reinterpret_cast<uint8_t *>(s_recv);
   const int tile = blockIdx.x;
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int y0 = ty * TH, x0 = tx * TW;
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(256) void k_fa_tile1(const uint8_t *__restrict__ fd
     if (n == NX_REXIT) my_flags = (uint32_t)REC_RANK_EXIT;
   }
   __syncthreads();
-  uint8_t *s_cyc = s_fdr;
+  uint8_t *s_cyc = reinterpret_cast<uint8_t *>(s_recv);
   for (int j = 0; j < CPT; j++) {
     int c = threadIdx.x + 256 * j;
     uint32_t n = nx[j];
@@ -235,7 +237,6 @@ __global__ __launch_bounds__(256) void k_fa_tile1(const uint8_t *__restrict__ fd
     bool ex = (n == NX_EXIT || n == NX_REXIT);
     s_pv[c] = (1u << 16) | (n < NT ? (n | PT_ALIVE) : ((uint32_t)c | (ex ? PT_EXIT : 0u)));
     if (j < CPT / 2) s_recv[c] = 0u;
-    s_cyc[c] = 0;
   }
   __syncthreads();
   dt_tile_sums(s_pv, s_recv, s_cyc);
@@ -342,13 +343,16 @@ __global__ __launch_bounds__(256) void k_fa_poison(const unsigned long long *__r
 // an LDS delta raster (integer adds: order-free), then delta is added to pass 1's in-tile counts.
 template <bool HAS_DEM, bool W_RIVER>
 __global__ __launch_bounds__(256, 5) void k_fa_tile3(const uint8_t *__restrict__ fdr,
-                                                 const float *__restrict__ dem, DtWin w, int tiles_x,
-                                                 const unsigned long long *__restrict__ ext,
-                                                 int32_t *__restrict__ acc32, int32_t river_thr,
-                                                 int8_t *__restrict__ river) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_fdr[NT];  // reused as the cross-tile cycle mask
+                                                    const float *__restrict__ dem, DtWin w, int tiles_x,
+                                                    const unsigned long long *__restrict__ ext,
+                                                    int32_t *__restrict__ acc32, int32_t river_thr,
+                                                    int8_t *__restrict__ river) {
+  // 24 KiB of LDS: six tiles per CU (the kernel is a latency chain of LDS walks).  The direction codes are
+  // staged through the delta array; bit 31 of a delta (real inflow < 2^31) marks the cells of a cycle
+  // spanning tiles.
   __shared__ uint16_t s_nxt[NT];
-  __shared__ uint32_t s_delta[NT];
+  __shared__ __attribute__((aligned(16))) uint32_t s_delta[NT];
+  uint8_t *s_fdr = reinterpret_cast<uint8_t *>(s_delta);
   const int tile = blockIdx.x;
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int y0 = ty * TH, x0 = tx * TW;
@@ -370,12 +374,10 @@ __global__ __launch_bounds__(256, 5) void k_fa_tile3(const uint8_t *__restrict__
     }
   }
   __syncthreads();
-  uint8_t *s_cyc = s_fdr;
   for (int j = 0; j < CPT; j++) {
     int c = threadIdx.x + 256 * j;
     s_nxt[c] = (uint16_t)nx[j];
     s_delta[c] = 0u;
-    s_cyc[c] = 0;
   }
   // pass 1's counts and the heights are fetched now, so that their latency hides behind the serial walks
   int32_t av[CPT];
@@ -394,12 +396,18 @@ __global__ __launch_bounds__(256, 5) void k_fa_tile3(const uint8_t *__restrict__
     int ly, lx;
     dt_cell_of_slot(threadIdx.x, ly, lx);
     uint32_t c = (uint32_t)(ly * TW + lx);
-    const bool cyc = (e & FA_CYCLE) != 0ull;  // fed by a D8 cycle spanning tiles: the path IS the cycle
-    const uint32_t add = (uint32_t)e;         // real inflow < 2^31
-    for (int it = 0; it < NT && c < NT; it++) {
-      if (cyc) s_cyc[c] = 1;
-      else atomicAdd(&s_delta[c], add);
-      c = s_nxt[c];
+    // fed by a D8 cycle spanning tiles: the path IS the cycle; else the real inflow (< 2^31)
+    const uint32_t add = (e & FA_CYCLE) ? 0x80000000u : (uint32_t)e;
+    if (e & FA_CYCLE) {
+      for (int it = 0; it < NT && c < NT; it++) {
+        atomicOr(&s_delta[c], add);
+        c = s_nxt[c];
+      }
+    } else {
+      for (int it = 0; it < NT && c < NT; it++) {
+        atomicAdd(&s_delta[c], add);
+        c = s_nxt[c];
+      }
     }
   }
   __syncthreads();
@@ -410,8 +418,9 @@ __global__ __launch_bounds__(256, 5) void k_fa_tile3(const uint8_t *__restrict__
     if (y >= w.H || x >= w.W) continue;
     long long o = (long long)y * w.ld + x;
     int32_t v = av[j];
-    if (v != -100) v += (int32_t)s_delta[c];
-    if (s_cyc[c]) v = -100;
+    uint32_t d = s_delta[c];
+    if (v != -100) v += (int32_t)(d & 0x7FFFFFFFu);
+    if (d & 0x80000000u) v = -100;
     if (HAS_DEM && zv[j] <= DT_NODATA) v = -100;
     acc32[o] = v;
     if (W_RIVER) river[o] = v > river_thr ? 1 : 0;
