@@ -913,7 +913,7 @@ struct FhRemote {  // payload of rank exits (multi-GPU), all indexed by core-rin
   const int32_t *ar;
 };
 
-__global__ __launch_bounds__(256) void k_fh_tile3(const uint8_t *__restrict__ fdr,
+__global__ __launch_bounds__(256, 6) void k_fh_tile3(const uint8_t *__restrict__ fdr,
                                                  const float *__restrict__ dem,
                                                  const int32_t *__restrict__ acc32, DtWin w, int tiles_x,
                                                  uint32_t nnodes, const unsigned long long *__restrict__ nodes,
@@ -1027,59 +1027,55 @@ __global__ __launch_bounds__(256) void k_fh_tile3(const uint8_t *__restrict__ fd
     return o;
   };
   if (vec) {
-    constexpr int VPT = NT / 4 / 256;  // 4 groups of 4 cells per lane
-    uint4 wa[VPT], wb[VPT];
-    float4 z4[VPT];
+    // 4 groups of 4 cells per lane, two at a time: 24 registers of loads in flight per lane and twice the
+    // waves per SIMD instead of 48 and half of them
+    constexpr int VPT = NT / 4 / 256, VH = 2;
+#pragma unroll 1
+    for (int h = 0; h < VPT / VH; h++) {
+      uint4 wa[VH], wb[VH];
+      float4 z4[VH];
 #pragma unroll
-    for (int u = 0; u < VPT; u++) {
-      int c = 4 * (threadIdx.x + 256 * u);
-      const uint4 *cp = reinterpret_cast<const uint4 *>(cache + (size_t)tile * NT + c);
-      wa[u] = cp[0];
-      wb[u] = cp[1];
-      int y = y0 + c / TW;
-      z4[u] = make_float4(DT_NODATA, DT_NODATA, DT_NODATA, DT_NODATA);
-      if (dem && y < w.H) z4[u] = *reinterpret_cast<const float4 *>(dem + (long long)y * w.ld + x0 + c % TW);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < VPT; u++) {
-      int c = 4 * (threadIdx.x + 256 * u);
-      int y = y0 + c / TW;
-      if (y >= w.H) continue;
-      long long o = (long long)y * w.ld + x0 + c % TW;
-      CellOut r0 = solve(((unsigned long long)wa[u].y << 32) | wa[u].x, z4[u].x);
-      CellOut r1 = solve(((unsigned long long)wa[u].w << 32) | wa[u].z, z4[u].y);
-      CellOut r2 = solve(((unsigned long long)wb[u].y << 32) | wb[u].x, z4[u].z);
-      CellOut r3 = solve(((unsigned long long)wb[u].w << 32) | wb[u].z, z4[u].w);
-      if (fdist) *reinterpret_cast<float4 *>(fdist + o) = make_float4(r0.fd, r1.fd, r2.fd, r3.fd);
-      if (idx32) *reinterpret_cast<int4 *>(idx32 + o) = make_int4(r0.i32, r1.i32, r2.i32, r3.i32);
-      if (idx64) {
-        *reinterpret_cast<longlong2 *>(idx64 + o) = make_longlong2(r0.i64, r1.i64);
-        *reinterpret_cast<longlong2 *>(idx64 + o + 2) = make_longlong2(r2.i64, r3.i64);
+      for (int u = 0; u < VH; u++) {
+        int c = 4 * (threadIdx.x + 256 * (h * VH + u));
+        const uint4 *cp = reinterpret_cast<const uint4 *>(cache + (size_t)tile * NT + c);
+        wa[u] = cp[0];
+        wb[u] = cp[1];
+        int y = y0 + c / TW;
+        z4[u] = make_float4(DT_NODATA, DT_NODATA, DT_NODATA, DT_NODATA);
+        if (dem && y < w.H) z4[u] = *reinterpret_cast<const float4 *>(dem + (long long)y * w.ld + x0 + c % TW);
       }
-      if (hand) *reinterpret_cast<float4 *>(hand + o) = make_float4(r0.h, r1.h, r2.h, r3.h);
-      if (a_river) *reinterpret_cast<int4 *>(a_river + o) = make_int4(r0.ar, r1.ar, r2.ar, r3.ar);
+      if (h == 0) __syncthreads();  // s_x / s_pay
+#pragma unroll
+      for (int u = 0; u < VH; u++) {
+        int c = 4 * (threadIdx.x + 256 * (h * VH + u));
+        int y = y0 + c / TW;
+        if (y >= w.H) continue;
+        long long o = (long long)y * w.ld + x0 + c % TW;
+        CellOut r0 = solve(((unsigned long long)wa[u].y << 32) | wa[u].x, z4[u].x);
+        CellOut r1 = solve(((unsigned long long)wa[u].w << 32) | wa[u].z, z4[u].y);
+        CellOut r2 = solve(((unsigned long long)wb[u].y << 32) | wb[u].x, z4[u].z);
+        CellOut r3 = solve(((unsigned long long)wb[u].w << 32) | wb[u].z, z4[u].w);
+        if (fdist) *reinterpret_cast<float4 *>(fdist + o) = make_float4(r0.fd, r1.fd, r2.fd, r3.fd);
+        if (idx32) *reinterpret_cast<int4 *>(idx32 + o) = make_int4(r0.i32, r1.i32, r2.i32, r3.i32);
+        if (idx64) {
+          *reinterpret_cast<longlong2 *>(idx64 + o) = make_longlong2(r0.i64, r1.i64);
+          *reinterpret_cast<longlong2 *>(idx64 + o + 2) = make_longlong2(r2.i64, r3.i64);
+        }
+        if (hand) *reinterpret_cast<float4 *>(hand + o) = make_float4(r0.h, r1.h, r2.h, r3.h);
+        if (a_river) *reinterpret_cast<int4 *>(a_river + o) = make_int4(r0.ar, r1.ar, r2.ar, r3.ar);
+      }
     }
     return;
   }
-  unsigned long long wd[CPT];
-#pragma unroll
-  for (int j = 0; j < CPT; j++) wd[j] = cache[(size_t)tile * NT + threadIdx.x + 256 * j];
-  float zc[CPT];  // own height (needed for HAND)
-#pragma unroll
-  for (int j = 0; j < CPT; j++) {
-    int c = threadIdx.x + 256 * j;
-    int y = y0 + c / TW, x = x0 + c % TW;
-    zc[j] = (dem && y < w.H && x < w.W) ? dem[(long long)y * w.ld + x] : DT_NODATA;
-  }
+  // ragged tiles and unaligned rasters: one cell at a time (rare: keep it small, not fast)
   __syncthreads();
-#pragma unroll
+#pragma unroll 1
   for (int j = 0; j < CPT; j++) {
     int c = threadIdx.x + 256 * j;
     int y = y0 + c / TW, x = x0 + c % TW;
     if (y >= w.H || x >= w.W) continue;
-    CellOut r = solve(wd[j], zc[j]);
     long long o = (long long)y * w.ld + x;
+    CellOut r = solve(cache[(size_t)tile * NT + c], dem ? dem[o] : DT_NODATA);
     if (fdist) fdist[o] = r.fd;
     if (idx32) idx32[o] = r.i32;
     if (idx64) idx64[o] = r.i64;
