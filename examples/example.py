@@ -19,17 +19,19 @@ import descriptools_amd.gfi as gfi  # noqa: E402
 import descriptools_amd.evaluation as evaluation  # noqa: E402
 
 
+import descriptools_amd.rasterio_lite as rio  # noqa: E402
+
+EX = os.path.join(ROOT, "tests", "golden", "example")
+
+
 def read(name):
-    from PIL import Image
-    Image.MAX_IMAGE_PIXELS = None
-    return np.array(Image.open(os.path.join(ROOT, "tests", "golden", "example", name)))
+    return rio.read(os.path.join(EX, name))[0]
 
 
 def main():
-    dem_f, fac_f = read("12_dem.tif"), read("12_fac.tif")
-    dem = np.where(dem_f < -1e30, -100, dem_f).astype("int16")      # example.py:33,42
+    dem, meta = rio.read_masked(os.path.join(EX, "12_dem.tif"), -100, "int16")   # example.py:33,42
     fdr = read("12_fdr.tif")
-    fac = np.where(fac_f < -1e30, -100, fac_f).astype("int")        # example.py:39,43
+    fac, _ = rio.read_masked(os.path.join(EX, "12_fac.tif"), -100, "int")        # example.py:39,43
     px = 12.5
     river = np.where(fac > 128000, 1, 0).astype("int8")             # example.py:52
     t0 = time.time()
@@ -63,6 +65,12 @@ def main():
     assert c == 0.8581615676712259 and f == 0.7240945135019289
     assert abs(float(sl[v].max()) - 192.33304) < 1e-4 and abs(float(down[v].max()) - 1.9233304) < 1e-6
     assert abs(float(TopoI[v].max()) - 26.16775) < 1e-4 and abs(float(geofi[hand != -100].max()) - 10.92763) < 1e-4
+    # example.py:201-217 writes the classified map as a GeoTIFF aligned with the inputs
+    out_dir = os.environ.get("DT_EXAMPLE_OUT")
+    if out_dir:
+        os.makedirs(out_dir, exist_ok=True)
+        rio.write(os.path.join(out_dir, "hand_class.tif"), class_map.astype(np.uint8), like=meta, nodata=0)
+        rio.write(os.path.join(out_dir, "hand.tif"), hand.astype(np.float32), like=meta, nodata=-100.0)
     print("example OK")
 
 
