@@ -29,8 +29,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 ach
 # op -> (algorithmic bytes per cell).  "d8" writes fdr only (slope comes out of the
 # fused slope+TWI stencil: dem 4 + fac 4 read, slope 4 + TI 4 + MTI 4 written = the north_star's
 # 20 B/cell; the slope-in-radians raster is an optional extra output that the chain does not need).
-OPS = [("d8", 5), ("flowacc_river", 5 + 1), ("flowhand", 18 + 4), ("slope_twi", 20),
-       ("gfi_lnhlh", 4 + 4 + 4 + 4 + 4), ("downslope", 9)]
+OPS = [("d8", 5), ("downslope", 9), ("flowacc_river", 5 + 1), ("flowhand", 18 + 4), ("slope_twi", 20),
+       ("gfi_lnhlh", 4 + 4 + 4 + 4 + 4)]
 
 
 # kernels behind each op (names as rocprofv3 prints them) -- used to attach the PMC-measured HBM
@@ -70,6 +70,9 @@ def main():
     ap.add_argument("--size", type=int, default=16384, help="tile edge per GPU")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap", action="store_true", help="run downslope as a second branch on its own stream "
+                    "beside flow accumulation / HAND (Chain(overlap=True)): faster end to end, but the per-kernel "
+                    "timings stop being attributable; off by default")
     ap.add_argument("--tiled", action="store_true", help="N = 1 through the multi-rank path (1 x 1 layout): "
                                                          "measures what the tiling machinery costs")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and use the "
@@ -112,6 +115,9 @@ def main():
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
     ctx = Context(device=local_rank, stream=stream.cuda_stream)
+    # second branch of the chain (downslope beside flow accumulation / HAND, chain.Chain.run): its own stream
+    stream2 = torch.cuda.Stream(device=dev) if args.overlap else stream
+    ctx2 = Context(device=local_rank, stream=stream2.cuda_stream) if args.overlap else ctx
 
     # ---- tile layout: ranks tile a (ty*S) x (tx*S) DEM; rank r owns tile (r // tx, r % tx) ----
     tx = 1
@@ -135,35 +141,44 @@ def main():
 
     dem = alloc((H, W), np.float32)
     _lib.check(L.dt_dev_synth_dem(ctx.h, args.seed, Hg, Wg, y0, x0, H, W, 0, dem.data_ptr()))
-    ch = chain.Chain(H, W, ctx=ctx, px=10.0, river_threshold=(H * W) // 512, alloc=alloc_ptr)
+    ch = chain.Chain(H, W, ctx=ctx, px=10.0, river_threshold=(H * W) // 512, alloc=alloc_ptr, side_ctx=ctx2,
+                     overlap=args.overlap)
     p = ch.p
-    c = ctx.h
+    c, c2 = ctx.h, ctx2.h
     N = H * W
 
+    # the ops of chain.Chain.run, in its order and on its stream(s): (name, stream, call); without --overlap
+    # ctx2 is ctx and downslope simply runs after D8
     def op_calls():
         return [
-            ("d8", lambda: L.dt_dev_slope_d8(c, dem.data_ptr(), H, W, ch.px, None, p("fdr"), None)),
-            ("flowacc_river", lambda: L.dt_dev_flowacc_river(c, p("fdr"), dem.data_ptr(), H, W,
-                                                             ch.river_threshold, p("fac"), p("river"))),
-            ("flowhand", lambda: L.dt_dev_flowhand(c, dem.data_ptr(), p("fdr"), p("river"), p("fac"), H, W,
-                                                   ch.px, p("fdist"), p("idx"), p("hand"), p("a_river"))),
-            ("slope_twi", lambda: L.dt_dev_slope_twi(c, dem.data_ptr(), p("fac"), H, W, ch.px, ch.n_top,
-                                                     p("slope"), None, p("ti"), p("mti"))),
-            ("gfi_lnhlh", lambda: L.dt_dev_gfi_lnhlh(c, p("hand"), p("a_river"), p("fac"), N, ch.n_gfi, ch.b,
-                                                     ch.px, p("gfi"), p("lnhlh"))),
-            ("downslope", lambda: L.dt_dev_downslope(c, dem.data_ptr(), p("fdr"), H, W, ch.px, ch.dz, 0,
-                                                     p("down"))),
+            ("d8", stream, lambda: L.dt_dev_slope_d8(c, dem.data_ptr(), H, W, ch.px, None, p("fdr"), None)),
+            ("downslope", stream2, lambda: L.dt_dev_downslope(c2, dem.data_ptr(), p("fdr"), H, W, ch.px, ch.dz, 0,
+                                                              p("down"))),
+            ("flowacc_river", stream, lambda: L.dt_dev_flowacc_river(c, p("fdr"), dem.data_ptr(), H, W,
+                                                                     ch.river_threshold, p("fac"), p("river"))),
+            ("flowhand", stream, lambda: L.dt_dev_flowhand(c, dem.data_ptr(), p("fdr"), p("river"), p("fac"), H,
+                                                           W, ch.px, p("fdist"), p("idx"), p("hand"),
+                                                           p("a_river"))),
+            ("slope_twi", stream, lambda: L.dt_dev_slope_twi(c, dem.data_ptr(), p("fac"), H, W, ch.px, ch.n_top,
+                                                             p("slope"), None, p("ti"), p("mti"))),
+            ("gfi_lnhlh", stream, lambda: L.dt_dev_gfi_lnhlh(c, p("hand"), p("a_river"), p("fac"), N, ch.n_gfi,
+                                                             ch.b, ch.px, p("gfi"), p("lnhlh"))),
         ]
 
     calls = op_calls()
+    assert [n for n, _, _ in calls] == [n for n, _ in OPS]
 
     def step(events=None):
-        for i, (name, fn) in enumerate(calls):
+        for i, (name, st, fn) in enumerate(calls):
+            if name == "downslope" and args.overlap:
+                ctx.fork(ctx2)  # after D8
             if events is not None:
-                events[i][0].record(stream)
+                events[i][0].record(st)
             _lib.check(fn())
             if events is not None:
-                events[i][1].record(stream)
+                events[i][1].record(st)
+        if args.overlap:
+            ctx.join(ctx2)
 
     def barrier():
         if world > 1:
@@ -206,7 +221,9 @@ def main():
             "note": "dominant single kernel; achieved = algorithmic bytes/cell x cells / mean kernel time (HIP "
                     "events on the launch stream, timed region); traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
                     "from separate rocprofv3 --pmc runs committed under profiles/; per_op lists every op "
-                    "(flowacc_river and flowhand are multi-kernel ops: their frac is of the op as a whole)"}
+                    "(flowacc_river and flowhand are multi-kernel ops: their frac is of the op as a whole)"
+                    + (".  --overlap: downslope runs on a second stream beside flow accumulation / HAND, so the "
+                       "per-op times overlap and add up to more than ms_per_step" if args.overlap else "")}
 
     # practical HBM ceiling of this device: a float4 grid-stride copy through the same library
     src, dst = alloc((H, W), np.float32), alloc((H, W), np.float32)
@@ -232,7 +249,8 @@ def main():
                                "(d8, flowacc, river mask, flowhand/HAND, fused slope+TI+MTI, GFI, ln(hl/H), "
                                "downslope), device-resident" % (S, S),
                    "global_dem": "%dx%d" % (Hg, Wg), "px": 10.0, "river_threshold_cells": ch.river_threshold,
-                   "parallelism": "1 tile per GPU" if world > 1 else "single GPU"},
+                   "parallelism": ("1 tile per GPU" if world > 1 else "single GPU")
+                   + (", downslope on a second stream (--overlap)" if args.overlap else "")},
         "roofline": roof,
         "per_op": per_op,
         "hbm_copy_ceiling_GBs": round(copy_gbs, 1),
@@ -272,11 +290,11 @@ def main_tiled(args, torch, dist, world, rank, local_rank, dev):
     cpu_red = use_dist and dist.get_backend() == "gloo"
 
     for _ in range(args.warmup):
-        tiling.run_rank(tile, layout, exchange)
+        tiling.run_rank(tile, layout, exchange, overlap=args.overlap)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        tiling.run_rank(tile, layout, exchange)
+        tiling.run_rank(tile, layout, exchange, overlap=args.overlap)
     barrier()
     dt = time.perf_counter() - t0
     unres = torch.tensor([tile.unresolved_downslope()], dtype=torch.int64, device="cpu" if cpu_red else dev)

@@ -41,6 +41,7 @@ extern "C" int dt_ctx_create(int device, void *stream, dt_ctx **out) {
   c->scratch_used = 0;
   c->scratch2 = nullptr;
   c->scratch2_bytes = 0;
+  c->ev = nullptr;
   if (stream) {
     c->stream = (hipStream_t)stream;
     c->own_stream = false;
@@ -63,6 +64,7 @@ extern "C" int dt_ctx_destroy(dt_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   if (c->scratch) (void)hipFree(c->scratch);
   if (c->scratch2) (void)hipFree(c->scratch2);
+  if (c->ev) (void)hipEventDestroy(c->ev);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return DT_OK;
@@ -82,6 +84,20 @@ extern "C" int dt_ctx_set_stream(dt_ctx *c, void *stream) {
   return DT_OK;
 }
 extern "C" void *dt_ctx_stream(dt_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+// `waiter`'s stream waits for everything enqueued so far on `signaller`'s stream (no host synchronisation)
+static int dt_ctx_order(dt_ctx *signaller, dt_ctx *waiter) {
+  DT_REQUIRE(signaller != nullptr && waiter != nullptr, "ctx is NULL");
+  DT_REQUIRE(signaller->device == waiter->device, "contexts on different devices");
+  if (signaller->stream == waiter->stream) return DT_OK;
+  DT_HIP(hipSetDevice(signaller->device));
+  if (!signaller->ev) DT_HIP(hipEventCreateWithFlags(&signaller->ev, hipEventDisableTiming));
+  DT_HIP(hipEventRecord(signaller->ev, signaller->stream));
+  DT_HIP(hipStreamWaitEvent(waiter->stream, signaller->ev, 0));
+  return DT_OK;
+}
+extern "C" int dt_ctx_fork(dt_ctx *parent, dt_ctx *child) { return dt_ctx_order(parent, child); }
+extern "C" int dt_ctx_join(dt_ctx *parent, dt_ctx *child) { return dt_ctx_order(child, parent); }
 extern "C" int dt_ctx_sync(dt_ctx *c) {
   DT_REQUIRE(c != nullptr, "ctx is NULL");
   DT_HIP(hipStreamSynchronize(c->stream));

@@ -46,6 +46,7 @@ struct dt_ctx {
   size_t scratch_used;  // bump pointer, reset at the start of every entry point
   char *scratch2;       // rank-level solves (must not disturb the two-phase tile scratch)
   size_t scratch2_bytes;
+  hipEvent_t ev;        // fork / join with another context's stream (created on first use)
 };
 
 // grow-only scratch, bump-allocated per entry point (256-B aligned)

@@ -57,6 +57,14 @@ class Context:
     def sync(self):
         check(_lib.lib().dt_ctx_sync(self.h))
 
+    def fork(self, child):
+        """`child`'s stream waits (on the device) for everything enqueued so far on this context's stream."""
+        check(_lib.lib().dt_ctx_fork(self.h, child.h))
+
+    def join(self, child):
+        """this context's stream waits (on the device) for everything enqueued so far on `child`'s."""
+        check(_lib.lib().dt_ctx_join(self.h, child.h))
+
     @property
     def stream(self):
         return _lib.lib().dt_ctx_stream(self.h)

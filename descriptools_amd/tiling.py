@@ -270,6 +270,7 @@ class RankTile:
         self.He, self.We = self.H + 2 * halo, self.W + 2 * halo
         self.dev = torch.device("cuda", device)
         self.ctx = Context(device=device, stream=stream)
+        self.side_ctx = Context(device=device)  # the downslope branch (own stream), see run_rank
         # torch ops below (fills, copies, the ring gather) run on torch's current stream: when that is not
         # the context's stream the two are ordered by hand (_torch_begin / _torch_end)
         self._foreign = stream is None or int(stream) != int(torch.cuda.current_stream(self.dev).cuda_stream)
@@ -464,10 +465,18 @@ class RankTile:
                                           t["fac"].data_ptr(), n, self.n_gfi, self.b, self.px,
                                           t["gfi"].data_ptr(), t["lnhlh"].data_ptr()))
 
-    def downslope(self):
-        """downslope on the core window (needs only dem + fdr: independent of the exchanges)."""
-        self._chk(self.L.dt_dev_downslope_w(self.ctx.h, C.byref(self.win), self.p("dem"), self.p("fdr"), self.px,
+    def downslope(self, side=False):
+        """downslope on the core window (needs only dem + fdr: independent of the exchanges).  side=True:
+        as a second branch on the side context's stream, forked here (after D8) and joined by join_side()."""
+        ctx = self.ctx
+        if side:
+            self.ctx.fork(self.side_ctx)
+            ctx = self.side_ctx
+        self._chk(self.L.dt_dev_downslope_w(ctx.h, C.byref(self.win), self.p("dem"), self.p("fdr"), self.px,
                                             self.dz, 0, self.p("down"), self.n_unres.data_ptr()))
+
+    def join_side(self):
+        self.ctx.join(self.side_ctx)
 
     def pointwise(self):
         self.slope_twi()
@@ -475,6 +484,7 @@ class RankTile:
         self.downslope()
 
     def unresolved_downslope(self):
+        self.side_ctx.sync()
         self.ctx.sync()
         return int(self.n_unres.item())
 
@@ -617,15 +627,20 @@ class Exchange:
             self._done = None
 
 
-def run_rank(tile, layout, exchange):
+def run_rank(tile, layout, exchange, overlap=False):
     """One step of one rank.  The two all-gathers are the only communication; the independent kernels
-    (downslope; slope+TI+MTI) are queued between each gather's launch and the wait on it, so they
-    overlap it.  Nothing in the step synchronises with the host."""
+    (downslope; slope+TI+MTI) are queued between each gather's launch and the wait on it, so they overlap it.
+    overlap=True: downslope instead runs as a second compute branch on its own stream from the D8 kernel
+    to the end of the step (beside the flow kernels as well as the exchanges; chain.Chain's `overlap`).
+    Nothing in the step synchronises with the host."""
     tile.d8()
+    if overlap:
+        tile.downslope(side=True)
     tile.fa_local(sync=False)
     tile.fill_ring_codes()
     rows = exchange.gather(tile.fa_row, exchange.fa_all)
-    tile.downslope()
+    if not overlap:
+        tile.downslope()
     exchange.wait()
     tile.fa_solve_finish(rows)
     tile.fh_local(sync=False)
@@ -634,6 +649,8 @@ def run_rank(tile, layout, exchange):
     exchange.wait()
     tile.fh_solve_finish(rows)
     tile.gfi()
+    if overlap:
+        tile.join_side()
 
 
 def simulate(tiles, layout):

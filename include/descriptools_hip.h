@@ -57,6 +57,12 @@ int dt_ctx_create(int device, void *stream, dt_ctx **out);
 int dt_ctx_destroy(dt_ctx *ctx);
 int dt_ctx_set_stream(dt_ctx *ctx, void *stream);
 void *dt_ctx_stream(dt_ctx *ctx);
+/* Two contexts of one device as concurrent branches of a pipeline: after dt_ctx_fork the child's stream waits
+ * for everything enqueued so far on the parent's; after dt_ctx_join the parent's waits for the child's.
+ * Device-side ordering only (events), the host never blocks.  The chain uses it to run downslope beside the
+ * flow-accumulation / HAND kernels, whose latency chains leave most of the GPU idle. */
+int dt_ctx_fork(dt_ctx *parent, dt_ctx *child);
+int dt_ctx_join(dt_ctx *parent, dt_ctx *child);
 int dt_ctx_sync(dt_ctx *ctx);
 int64_t dt_ctx_scratch_bytes(dt_ctx *ctx);
 

@@ -393,3 +393,13 @@ def test_downslope_arbitrary_direction_field(dt, seed):
         want = oracle.downslope(dem, fdr, 10.0, dz)
         got = dt.downslope.downsloper(dem, fdr, 10.0, dz)
         assert np.array_equal(got, want, equal_nan=True), int((got != want).sum())
+
+
+def test_chain_overlap_branch_gives_the_same_rasters(dt):
+    """Chain(overlap=True) runs downslope on a second stream (dt_ctx_fork / dt_ctx_join): same results."""
+    from descriptools_amd import chain
+    dem = oracle.synth_dem(3, 700, 900, 0, 0, 700, 900, 2)
+    a = chain.run_host(dem, 10.0)
+    b = chain.run_host(dem, 10.0, overlap=True)
+    for k in a:
+        assert np.array_equal(a[k], b[k], equal_nan=True), k

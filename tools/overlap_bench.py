@@ -24,14 +24,18 @@ def step(overlap):
         ev = torch.cuda.Event(); ev.record(s1); s2.wait_event(ev)
         _lib.check(L.dt_dev_downslope(c2.h, dem.data_ptr(), p("fdr"), H, W, ch.px, ch.dz, 0, p("down")))
     _lib.check(L.dt_dev_flowacc_river(c1.h, p("fdr"), dem.data_ptr(), H, W, ch.river_threshold, p("fac"), p("river")))
+    if overlap == 2:  # slope+TI+MTI also on the side stream, behind flow accumulation
+        ev3 = torch.cuda.Event(); ev3.record(s1); s2.wait_event(ev3)
+        _lib.check(L.dt_dev_slope_twi(c2.h, dem.data_ptr(), p("fac"), H, W, ch.px, ch.n_top, p("slope"), None, p("ti"), p("mti")))
     _lib.check(L.dt_dev_flowhand(c1.h, dem.data_ptr(), p("fdr"), p("river"), p("fac"), H, W, ch.px, p("fdist"), p("idx"), p("hand"), p("a_river")))
-    _lib.check(L.dt_dev_slope_twi(c1.h, dem.data_ptr(), p("fac"), H, W, ch.px, ch.n_top, p("slope"), p("slope_rad"), p("ti"), p("mti")))
+    if overlap != 2:
+        _lib.check(L.dt_dev_slope_twi(c1.h, dem.data_ptr(), p("fac"), H, W, ch.px, ch.n_top, p("slope"), None, p("ti"), p("mti")))
     _lib.check(L.dt_dev_gfi_lnhlh(c1.h, p("hand"), p("a_river"), p("fac"), N, ch.n_gfi, ch.b, ch.px, p("gfi"), p("lnhlh")))
     if overlap:
         ev2 = torch.cuda.Event(); ev2.record(s2); s1.wait_event(ev2)
     else:
         _lib.check(L.dt_dev_downslope(c1.h, dem.data_ptr(), p("fdr"), H, W, ch.px, ch.dz, 0, p("down")))
-for overlap in (False, True, False, True):
+for overlap in (0, 1, 2, 0, 1, 2):
     for _ in range(2): step(overlap)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(5): step(overlap)
