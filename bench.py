@@ -29,8 +29,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 ach
 # op -> (algorithmic bytes per cell).  "d8" writes fdr only (slope comes out of the
 # fused slope+TWI stencil: dem 4 + fac 4 read, slope 4 + TI 4 + MTI 4 written = the north_star's
 # 20 B/cell; the slope-in-radians raster is an optional extra output that the chain does not need).
-OPS = [("d8", 5), ("downslope", 9), ("flowacc_river", 5 + 1), ("flowhand", 18 + 4), ("slope_twi", 20),
-       ("gfi_lnhlh", 4 + 4 + 4 + 4 + 4)]
+# algorithmic bytes per cell (unfused definitions): HAND 18 + GFI 12 + ln(hl/H) 12 for the fused op
+OPS = [("d8", 5), ("downslope", 9), ("flowacc_river", 5 + 1), ("flowhand_gfi", 18 + 12 + 12), ("slope_twi", 20)]
 
 
 # kernels behind each op (names as rocprofv3 prints them) -- used to attach the PMC-measured HBM
@@ -39,9 +39,8 @@ OP_KERNELS = {
     "d8": ["k_stencil<false, true, false, false>"],
     "flowacc_river": ["k_fa_tile1", "k_fa_link", "k_fa_reduce", "k_fa_poison", "k_fa_tile3<true, true>",
                       "__amd_rocclr_fillBufferAligned"],
-    "flowhand": ["k_fh_tile1", "k_fh_ghost_init", "k_fh_node_jump", "k_fh_tile3"],
+    "flowhand_gfi": ["k_fh_tile1", "k_fh_ghost_init", "k_fh_node_jump", "k_fh_tile3"],
     "slope_twi": ["k_stencil<true, false, false, true>"],
-    "gfi_lnhlh": ["k_gfi_both"],
     "downslope": ["k_downslope_win"],
 }
 PMC_FILE = os.path.join(ROOT, "profiles", "r1", "v5_pmc_traffic.json")
@@ -156,13 +155,12 @@ def main():
                                                               p("down"))),
             ("flowacc_river", stream, lambda: L.dt_dev_flowacc_river(c, p("fdr"), dem.data_ptr(), H, W,
                                                                      ch.river_threshold, p("fac"), p("river"))),
-            ("flowhand", stream, lambda: L.dt_dev_flowhand(c, dem.data_ptr(), p("fdr"), p("river"), p("fac"), H,
-                                                           W, ch.px, p("fdist"), p("idx"), p("hand"),
-                                                           p("a_river"))),
+            ("flowhand_gfi", stream, lambda: L.dt_dev_flowhand_gfi(c, dem.data_ptr(), p("fdr"), p("river"),
+                                                                   p("fac"), H, W, ch.px, ch.n_gfi, ch.b,
+                                                                   p("fdist"), p("idx"), p("hand"), None,
+                                                                   p("gfi"), p("lnhlh"))),
             ("slope_twi", stream, lambda: L.dt_dev_slope_twi(c, dem.data_ptr(), p("fac"), H, W, ch.px, ch.n_top,
                                                              p("slope"), None, p("ti"), p("mti"))),
-            ("gfi_lnhlh", stream, lambda: L.dt_dev_gfi_lnhlh(c, p("hand"), p("a_river"), p("fac"), N, ch.n_gfi,
-                                                             ch.b, ch.px, p("gfi"), p("lnhlh"))),
         ]
 
     calls = op_calls()
@@ -221,7 +219,7 @@ def main():
             "note": "dominant single kernel; achieved = algorithmic bytes/cell x cells / mean kernel time (HIP "
                     "events on the launch stream, timed region); traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
                     "from separate rocprofv3 --pmc runs committed under profiles/; per_op lists every op "
-                    "(flowacc_river and flowhand are multi-kernel ops: their frac is of the op as a whole)"
+                    "(flowacc_river and flowhand_gfi are multi-kernel ops: their frac is of the op as a whole)"
                     + (".  --overlap: downslope runs on a second stream beside flow accumulation / HAND, so the "
                        "per-op times overlap and add up to more than ms_per_step" if args.overlap else "")}
 
@@ -246,7 +244,7 @@ def main():
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%dx%d synthetic tilted-integer-fBm DEM per GPU, full chain "
-                               "(d8, flowacc, river mask, flowhand/HAND, fused slope+TI+MTI, GFI, ln(hl/H), "
+                               "(d8, flowacc, river mask, flowhand/HAND with fused GFI + ln(hl/H), fused slope+TI+MTI, "
                                "downslope), device-resident" % (S, S),
                    "global_dem": "%dx%d" % (Hg, Wg), "px": 10.0, "river_threshold_cells": ch.river_threshold,
                    "parallelism": ("1 tile per GPU" if world > 1 else "single GPU")

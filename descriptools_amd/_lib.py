@@ -75,6 +75,9 @@ _SIGS = {
     "dt_dev_unique_extremes_f32": (ci, [vp, vp, i64, vp]),
     "dt_dev_minmax_scale_f32": (ci, [vp, vp, i64, C.c_float, C.c_float, C.c_float, vp]),
     "dt_dev_membench_copy": (ci, [vp, vp, vp, i64, ci]),
+    "dt_dev_flowhand_gfi": (ci, [vp, vp, vp, vp, vp, i64, i64, f64, f64, f64, vp, vp, vp, vp, vp, vp]),
+    "dt_dev_flowhand_gfi_finish_w": (ci, [vp, vp, vp, vp, vp, vp, f64, f64, f64, vp, vp, vp, vp, vp,
+                                          vp, vp, vp, vp, vp, vp, vp, vp]),
     "dt_ctx_fork": (ci, [vp, vp]),
     "dt_ctx_join": (ci, [vp, vp]),
     "dt_dev_rank_solve_flowacc": (ci, [vp, ci, ci, c_i64p, c_i64p, i64, vp, i64, c_i64p, ci, i64, vp]),

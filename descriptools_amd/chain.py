@@ -56,12 +56,11 @@ class Chain:
             self.ctx.fork(self.side)
             check(L.dt_dev_downslope(self.side.h, dem_ptr, p("fdr"), H, W, self.px, self.dz, 0, p("down")))
         check(L.dt_dev_flowacc_river(c, p("fdr"), dem_ptr, H, W, self.river_threshold, p("fac"), p("river")))
-        check(L.dt_dev_flowhand(c, dem_ptr, p("fdr"), p("river"), p("fac"), H, W, self.px, p("fdist"),
-                                p("idx"), p("hand"), p("a_river")))
+        # HAND with GFI and ln(hl/H) evaluated in its last tile pass (one pass over the rasters less)
+        check(L.dt_dev_flowhand_gfi(c, dem_ptr, p("fdr"), p("river"), p("fac"), H, W, self.px, self.n_gfi, self.b,
+                                    p("fdist"), p("idx"), p("hand"), p("a_river"), p("gfi"), p("lnhlh")))
         check(L.dt_dev_slope_twi(c, dem_ptr, p("fac"), H, W, self.px, self.n_top, p("slope"),
                                  p("slope_rad") if self.want_slope_rad else None, p("ti"), p("mti")))
-        check(L.dt_dev_gfi_lnhlh(c, p("hand"), p("a_river"), p("fac"), N, self.n_gfi, self.b, self.px,
-                                 p("gfi"), p("lnhlh")))
         if self.side is not None:
             self.ctx.join(self.side)
         else:

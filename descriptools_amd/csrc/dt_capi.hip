@@ -301,6 +301,26 @@ extern "C" int dt_dev_flowhand(dt_ctx *c, const float *dem, const uint8_t *fdr, 
   return DT_OK;
 }
 
+// HAND + GFI + ln(hl/H) in one go: the last tile pass of dt_dev_flowhand also evaluates gfi.py:268-294 and
+// :404-440 from the values it holds in registers.  a_river may be NULL (it is only an intermediate).
+extern "C" int dt_dev_flowhand_gfi(dt_ctx *c, const float *dem, const uint8_t *fdr, const int8_t *river,
+                                   const int32_t *acc32, int64_t H, int64_t W, double px, double n_gfi,
+                                   double b, float *fdist, int32_t *idx32, float *hand, int32_t *a_river,
+                                   float *gfi, float *lnhlh) {
+  DT_CTX(c);
+  DT_TRY(dt_check_hw(H, W));
+  DT_REQUIRE((dem && fdr && river && acc32 && gfi && lnhlh) || H * W == 0, "NULL raster");
+  size_t need = dt_flowhand_tiled_scratch(H, W);
+  DT_TRY(dt_scratch_reset(c, need));
+  void *scr = dt_scratch_take(c, need);
+  DtWin w = dt_full_window(H, W);
+  DT_TRY(dt_launch_fh_local(c->stream, w, fdr, river, scr, need));
+  DT_TRY(dt_launch_fh_finish(c->stream, w, dem, fdr, river, acc32, px, scr, nullptr, nullptr, nullptr, nullptr,
+                             nullptr, nullptr, fdist, idx32, nullptr, hand, a_river, gfi, lnhlh, n_gfi, b, px));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+
 extern "C" int dt_dev_twi(dt_ctx *c, const int32_t *acc32, const float *slope_rad, int64_t N, double px,
                           double n_top, float *ti, float *mti) {
   DT_CTX(c);
@@ -520,6 +540,26 @@ extern "C" int dt_dev_flowhand_finish_w(dt_ctx *c, const dt_window *win, const f
   DT_TRY(dt_launch_fh_finish(c->stream, w, dem, fdr, river, acc32, px, c->scratch, res_ok, res_nc, res_nd,
                              (const long long *)rem_gidx, rem_zr, rem_ar, fdist, idx32, (long long *)idx64, hand,
                              a_river));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+
+// dt_dev_flowhand_finish_w with the fused GFI / ln(hl/H) epilogue (see dt_dev_flowhand_gfi)
+extern "C" int dt_dev_flowhand_gfi_finish_w(dt_ctx *c, const dt_window *win, const float *dem, const uint8_t *fdr,
+                                            const int8_t *river, const int32_t *acc32, double px, double n_gfi,
+                                            double b, const uint8_t *res_ok, const int32_t *res_nc,
+                                            const int32_t *res_nd, const int64_t *rem_gidx, const float *rem_zr,
+                                            const int32_t *rem_ar, float *fdist, int32_t *idx32, int64_t *idx64,
+                                            float *hand, int32_t *a_river, float *gfi, float *lnhlh) {
+  DT_CTX(c);
+  DtWin w;
+  DT_TRY(dt_convert_window(win, &w));
+  DT_REQUIRE(dem && fdr && river && acc32 && gfi && lnhlh, "NULL raster");
+  DT_REQUIRE(!res_ok || (res_nc && res_nd && rem_gidx && rem_zr && rem_ar), "incomplete rank-exit results");
+  DT_REQUIRE(c->scratch && c->scratch_bytes >= dt_flowhand_tiled_scratch(w.H, w.W), "no local phase before finish");
+  DT_TRY(dt_launch_fh_finish(c->stream, w, dem, fdr, river, acc32, px, c->scratch, res_ok, res_nc, res_nd,
+                             (const long long *)rem_gidx, rem_zr, rem_ar, fdist, idx32, (long long *)idx64, hand,
+                             a_river, gfi, lnhlh, n_gfi, b, px));
   DT_HIP(hipGetLastError());
   return DT_OK;
 }

@@ -53,7 +53,8 @@ int dt_launch_fh_finish(hipStream_t s, const DtWin &w, const float *dem, const u
                         const int8_t *river, const int32_t *acc32, double px, void *scratch,
                         const uint8_t *res_ok, const int32_t *res_nc, const int32_t *res_nd,
                         const long long *rem_gidx, const float *rem_zr, const int32_t *rem_ar, float *fdist,
-                        int32_t *idx32, long long *idx64, float *hand, int32_t *a_river);
+                        int32_t *idx32, long long *idx64, float *hand, int32_t *a_river, float *gfi = nullptr,
+                        float *lnhlh = nullptr, double n_gfi = 0.0, double b_gfi = 1.0, double size = 1.0);
 int dt_launch_gfi_both(hipStream_t s, const float *hand, const int32_t *a_river, const int32_t *fac,
                        int64_t n, double expo, double b, double size, float *gfi, float *lnhlh);
 int dt_launch_unique_extremes(hipStream_t s, const float *x, int64_t n, uint32_t *work4, float *out3);

@@ -147,3 +147,28 @@ __device__ __forceinline__ double dt_atanf_pos(float q) {
   for (int k = 4; k >= 0; k--) h = fmaf(h, t, dt_atan_c32[k]);
   return fma(sgn * (double)x, (double)h, base);
 }
+
+// GFI and ln(hl/H) in one pass: hand is read once and ln(h + 0.01) evaluated once (3 logs / cell
+// instead of 4, 12 + 4 bytes / cell instead of 24)
+__device__ __forceinline__ void dt_gfi_both_cell(float h, int32_t ar, int32_t f, double expo, double c0,
+                                                 const DtLogEntry *s_tab, float &g_out, float &l_out) {
+  if (h <= DT_NODATA) {
+    g_out = DT_NODATA;
+    l_out = DT_NODATA;
+    return;
+  }
+  if (h > -0.005f && ar > 0 && f >= 0) {  // float32 fast path (dt_math.h)
+    double lh = c0 - dt_lnf((float)((double)h + 0.01));
+    double g = lh + expo * dt_lnf((float)ar);
+    double l = lh + (f == 0 ? 0.0 : expo * dt_lnf((float)f));
+    if (fabs(g) >= DT_FAST_MIN && fabs(l) >= DT_FAST_MIN) {
+      g_out = (float)g;
+      l_out = (float)l;
+      return;
+    }
+  }
+  double lh = c0 - dt_fast_log((double)h + 0.01, s_tab);
+  g_out = (float)(lh + expo * dt_fast_log((double)ar, s_tab));
+  l_out = (float)(lh + (f == 0 ? 0.0 : expo * dt_fast_log((double)f, s_tab)));
+}
+

@@ -25,6 +25,7 @@
 // bit-identical to the v1 kernels and to the oracle for any tiling.
 #include "dt_common.h"
 #include "dt_kernels.h"
+#include "dt_math.h"
 
 #define TW 64
 #define TH 64
@@ -907,6 +908,14 @@ __global__ __launch_bounds__(256) void k_fh_ghost_set(unsigned long long *__rest
 }
 
 // pass 3: resolved node words -> rasters
+// optional fused epilogue: GFI and ln(hl/H) (gfi.py:268-294, :404-440) from the HAND and river accumulation
+// this kernel has in registers and the cell's own accumulation -- saves the separate pass over hand,
+// A_river and fac (and, when a_river is not asked for, that raster altogether)
+struct FhGfi {
+  float *gfi, *lnhlh;  // NULL: not fused
+  double expo, c0;     // n, ln b + n ln(size^2)
+  const DtLogEntry *tab;
+};
 struct FhRemote {  // payload of rank exits (multi-GPU), all indexed by core-ring index; NULL when unused
   const long long *gidx;
   const float *zr;
@@ -920,7 +929,8 @@ __global__ __launch_bounds__(256, 6) void k_fh_tile3(const uint8_t *__restrict__
                                                  const unsigned long long *__restrict__ cache,
                                                  FhRemote rem, double px, float *__restrict__ fdist,
                                                  int32_t *__restrict__ idx32, long long *__restrict__ idx64,
-                                                 float *__restrict__ hand, int32_t *__restrict__ a_river) {
+                                                 float *__restrict__ hand, int32_t *__restrict__ a_river,
+                                                 FhGfi G) {
   // per exit slot: the resolved word of the node the exit cell steps onto (+ the step), and the payload
   // {river height, river accumulation} of the river cell it resolves to.  4 KiB of LDS: the kernel streams
   // 28 B/cell and needs the occupancy, not a 32 KiB per-cell table.
@@ -970,7 +980,8 @@ __global__ __launch_bounds__(256, 6) void k_fh_tile3(const uint8_t *__restrict__
   const bool vec = x0 + TW <= w.W && (w.ld & 3) == 0 && (!dem || ((uintptr_t)dem & 15) == 0) &&
                    (!fdist || ((uintptr_t)fdist & 15) == 0) && (!idx32 || ((uintptr_t)idx32 & 15) == 0) &&
                    (!idx64 || ((uintptr_t)idx64 & 15) == 0) && (!hand || ((uintptr_t)hand & 15) == 0) &&
-                   (!a_river || ((uintptr_t)a_river & 15) == 0);
+                   (!a_river || ((uintptr_t)a_river & 15) == 0) &&
+                   (!G.gfi || ((((uintptr_t)G.gfi | (uintptr_t)G.lnhlh | (uintptr_t)acc32) & 15) == 0));
   const double dcard = px, ddiag = px * sqrt(2.0);
   struct CellOut {
     float fd, h;
@@ -1063,6 +1074,16 @@ __global__ __launch_bounds__(256, 6) void k_fh_tile3(const uint8_t *__restrict__
         }
         if (hand) *reinterpret_cast<float4 *>(hand + o) = make_float4(r0.h, r1.h, r2.h, r3.h);
         if (a_river) *reinterpret_cast<int4 *>(a_river + o) = make_int4(r0.ar, r1.ar, r2.ar, r3.ar);
+        if (G.gfi) {
+          int4 f = *reinterpret_cast<const int4 *>(acc32 + o);  // own accumulation (aligned like the outputs)
+          float4 g, l;
+          dt_gfi_both_cell(r0.h, r0.ar, f.x, G.expo, G.c0, G.tab, g.x, l.x);
+          dt_gfi_both_cell(r1.h, r1.ar, f.y, G.expo, G.c0, G.tab, g.y, l.y);
+          dt_gfi_both_cell(r2.h, r2.ar, f.z, G.expo, G.c0, G.tab, g.z, l.z);
+          dt_gfi_both_cell(r3.h, r3.ar, f.w, G.expo, G.c0, G.tab, g.w, l.w);
+          *reinterpret_cast<float4 *>(G.gfi + o) = g;
+          *reinterpret_cast<float4 *>(G.lnhlh + o) = l;
+        }
       }
     }
     return;
@@ -1081,6 +1102,12 @@ __global__ __launch_bounds__(256, 6) void k_fh_tile3(const uint8_t *__restrict__
     if (idx64) idx64[o] = r.i64;
     if (hand) hand[o] = r.h;
     if (a_river) a_river[o] = r.ar;
+    if (G.gfi) {
+      float g, l;
+      dt_gfi_both_cell(r.h, r.ar, acc32[o], G.expo, G.c0, G.tab, g, l);
+      G.gfi[o] = g;
+      G.lnhlh[o] = l;
+    }
   }
 }
 
@@ -1138,7 +1165,8 @@ int dt_launch_fh_finish(hipStream_t s, const DtWin &w, const float *dem, const u
                         const int8_t *river, const int32_t *acc32, double px, void *scratch,
                         const uint8_t *res_ok, const int32_t *res_nc, const int32_t *res_nd,
                         const long long *rem_gidx, const float *rem_zr, const int32_t *rem_ar, float *fdist,
-                        int32_t *idx32, long long *idx64, float *hand, int32_t *a_river) {
+                        int32_t *idx32, long long *idx64, float *hand, int32_t *a_river, float *gfi,
+                        float *lnhlh, double n_gfi, double b_gfi, double size) {
   if (w.H == 0 || w.W == 0) return DT_OK;
   FhScratch f = fh_layout(w, scratch);
   dim3 gt((unsigned)f.ntiles), b(256), gn((unsigned)((f.nnodes + f.P + 255) / 256));
@@ -1151,9 +1179,14 @@ int dt_launch_fh_finish(hipStream_t s, const DtWin &w, const float *dem, const u
       hipLaunchKernelGGL(k_fh_node_jump, gj, b, 0, s, f.nodes, f.nnodes + f.P, (int *)nullptr, r);
   }
   FhRemote rem{rem_gidx, rem_zr, rem_ar};
+  FhGfi G{nullptr, nullptr, 0.0, 0.0, nullptr};
+  if (gfi && lnhlh) {
+    DT_REQUIRE(dem && acc32, "fused GFI needs dem and the accumulation raster");
+    G = FhGfi{gfi, lnhlh, n_gfi, log(b_gfi) + n_gfi * log(size * size), dt_math_device_table(s)};
+  }
   (void)river;
   hipLaunchKernelGGL(k_fh_tile3, gt, b, 0, s, fdr, dem, acc32, w, f.tiles_x, (uint32_t)f.nnodes, f.nodes, f.cache,
-                     rem, px, fdist, idx32, idx64, hand, a_river);
+                     rem, px, fdist, idx32, idx64, hand, a_river, G);
   return DT_OK;
 }
 

@@ -419,17 +419,25 @@ class RankTile:
                                                  self._ext.data_ptr(), self.river_threshold, self.p("fac"),
                                                  self.p("river")))
 
-    def fh_solve_finish(self, rows):
+    def fh_solve_finish(self, rows, fuse_gfi=False, want_a_river=True):
+        """rank-level HAND solve on the GPU, then pass 3; fuse_gfi: GFI and ln(hl/H) in the same pass (the
+        river-accumulation raster is then only an optional by-product)."""
         self._keep_rows2 = rows
         r = self._res
         self._chk(self.L.dt_dev_rank_solve_flowhand(self.ctx.h, self.layout.ty, self.layout.tx, self._heights,
                                                     self._widths, self.pmax, rows.data_ptr(),
                                                     FH_ROW_BYTES * self.pmax, self._fh_offs, self.rank, self.P,
                                                     *[a.data_ptr() for a in r]))
-        self._chk(self.L.dt_dev_flowhand_finish_w(self.ctx.h, C.byref(self.win), self.p("dem"), self.p("fdr"),
-                                                  self.p("river"), self.p("fac"), self.px,
-                                                  *[a.data_ptr() for a in r], self.p("fdist"), None,
-                                                  self.p("idx"), self.p("hand"), self.p("a_river")))
+        if fuse_gfi:
+            self._chk(self.L.dt_dev_flowhand_gfi_finish_w(
+                self.ctx.h, C.byref(self.win), self.p("dem"), self.p("fdr"), self.p("river"), self.p("fac"),
+                self.px, self.n_gfi, self.b, *[a.data_ptr() for a in r], self.p("fdist"), None, self.p("idx"),
+                self.p("hand"), self.p("a_river") if want_a_river else None, self.p("gfi"), self.p("lnhlh")))
+        else:
+            self._chk(self.L.dt_dev_flowhand_finish_w(self.ctx.h, C.byref(self.win), self.p("dem"), self.p("fdr"),
+                                                      self.p("river"), self.p("fac"), self.px,
+                                                      *[a.data_ptr() for a in r], self.p("fdist"), None,
+                                                      self.p("idx"), self.p("hand"), self.p("a_river")))
 
     def fh_local(self, sync=True):
         v = self._fh_v
@@ -647,8 +655,7 @@ def run_rank(tile, layout, exchange, overlap=False):
     rows = exchange.gather(tile.fh_row, exchange.fh_all)
     tile.slope_twi()
     exchange.wait()
-    tile.fh_solve_finish(rows)
-    tile.gfi()
+    tile.fh_solve_finish(rows, fuse_gfi=True, want_a_river=False)
     if overlap:
         tile.join_side()
 
@@ -693,5 +700,6 @@ def simulate_dev(tiles, layout):
         t.fh_local(sync=False)
     rows = gather([t.fh_row for t in tiles])
     for t in tiles:
-        t.fh_solve_finish(rows)
-        t.pointwise()
+        t.fh_solve_finish(rows, fuse_gfi=True)
+        t.slope_twi()
+        t.downslope()

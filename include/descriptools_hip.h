@@ -159,6 +159,12 @@ int dt_dev_river_mask(dt_ctx *ctx, const int32_t *acc32, int64_t N, int64_t thre
 int dt_dev_flowhand(dt_ctx *ctx, const float *dem, const uint8_t *fdr, const int8_t *river,
                     const int32_t *acc32, int64_t H, int64_t W, double px, float *fdist,
                     int32_t *idx32, float *hand, int32_t *a_river);
+/* the same plus GFI and ln(hl/H) (gfi.py:268-294, :404-440; size = px as in example.py:81-91) evaluated in the
+ * last tile pass from the HAND / river accumulation it holds in registers: one pass over the rasters less than
+ * dt_dev_flowhand + dt_dev_gfi_lnhlh.  a_river may be NULL. */
+int dt_dev_flowhand_gfi(dt_ctx *ctx, const float *dem, const uint8_t *fdr, const int8_t *river,
+                        const int32_t *acc32, int64_t H, int64_t W, double px, double n_gfi, double b,
+                        float *fdist, int32_t *idx32, float *hand, int32_t *a_river, float *gfi, float *lnhlh);
 int dt_dev_twi(dt_ctx *ctx, const int32_t *acc32, const float *slope_rad, int64_t N, double px,
                double n_top, float *ti, float *mti);
 /* a_river[i] = fac[idx[i]] (or anything where hand <= -100) */
@@ -210,6 +216,12 @@ int dt_dev_flowhand_finish_w(dt_ctx *ctx, const dt_window *win, const float *dem
                              const int32_t *res_nc, const int32_t *res_nd, const int64_t *rem_gidx,
                              const float *rem_zr, const int32_t *rem_ar, float *fdist, int32_t *idx32,
                              int64_t *idx64, float *hand, int32_t *a_river);
+int dt_dev_flowhand_gfi_finish_w(dt_ctx *ctx, const dt_window *win, const float *dem, const uint8_t *fdr,
+                                 const int8_t *river, const int32_t *acc32, double px, double n_gfi, double b,
+                                 const uint8_t *res_ok, const int32_t *res_nc, const int32_t *res_nd,
+                                 const int64_t *rem_gidx, const float *rem_zr, const int32_t *rem_ar,
+                                 float *fdist, int32_t *idx32, int64_t *idx64, float *hand, int32_t *a_river,
+                                 float *gfi, float *lnhlh);
 
 /* evaluation on resident rasters.  out3_dev (device float[3]) = smallest,
  * second-smallest distinct and largest value of x, i.e. np.unique(x)[0], [1], [-1] as
