@@ -772,14 +772,31 @@ __device__ __forceinline__ void fht_solve_tile(const FhTile &T, const uint8_t *_
   __syncthreads();
 }
 
+// The in-tile word cache: 4 bytes per cell (f:12 | kind:3 | n_diag:8 | n_card:8, every cached word is
+// "done") when no path of the tile has more than 255 moves of a kind, the full 8-byte words otherwise; one
+// flag byte per tile.  The narrow words sit in the first half of the tile's 8-byte slot.
+__device__ __forceinline__ uint32_t fh_cache_pack(unsigned long long s) {
+  uint32_t ptr = (uint32_t)(s >> 32);
+  return (ptr & 0x7FFFu) | ((uint32_t)((s >> 16) & 0xFFu) << 15) | ((uint32_t)(s & 0xFFu) << 23);
+}
+__device__ __forceinline__ unsigned long long fh_cache_unpack(uint32_t v) {
+  return fht_pack(v & 0x7FFFu, (v >> 15) & 0xFFu, ((v >> 23) & 0xFFu) | FHT_DONE);
+}
+__device__ __forceinline__ unsigned long long fh_cache_get(const unsigned long long *__restrict__ cache, bool wide,
+                                                            int tile, int c) {
+  if (wide) return cache[(size_t)tile * NT + c];
+  return fh_cache_unpack(reinterpret_cast<const uint32_t *>(cache + (size_t)tile * NT)[c]);
+}
+
 // pass 1: perimeter node words
-// `cache` keeps every cell's resolved in-tile word (8 bytes, tile-major: cache[tile * NT + c]) so that
+// `cache` keeps every cell's resolved in-tile word (tile-major: slot cache[tile * NT ...]) so that
 // pass 3 does not have to solve the tile again: 16 bytes / cell of streaming HBM traffic instead of a
 // second LDS-bound pointer doubling.
 __global__ __launch_bounds__(256) void k_fh_tile1(const uint8_t *__restrict__ fdr,
                                                  const int8_t *__restrict__ river, DtWin w, int tiles_x,
                                                  uint32_t nnodes, unsigned long long *__restrict__ nodes,
-                                                 unsigned long long *__restrict__ cache) {
+                                                 unsigned long long *__restrict__ cache,
+                                                 uint8_t *__restrict__ cache_wide) {
   __shared__ __attribute__((aligned(16))) uint8_t s_fdr[NT];
   __shared__ uint8_t s_halo[2 * (TW + 2) + 2 * TH];
   __shared__ __attribute__((aligned(16))) unsigned long long s_st[NT];
@@ -811,9 +828,22 @@ __global__ __launch_bounds__(256) void k_fh_tile1(const uint8_t *__restrict__ fd
     }
     nodes[(size_t)tile * PS + threadIdx.x] = o;
   }
+  unsigned long long wv[CPT];
+  int wide = 0;
+#pragma unroll
   for (int j = 0; j < CPT; j++) {
-    int c = threadIdx.x + 256 * j;
-    cache[(size_t)tile * NT + c] = s_st[c];
+    wv[j] = s_st[threadIdx.x + 256 * j];
+    wide |= (((uint32_t)wv[j] & 0x7FFFu) > 255u || ((uint32_t)(wv[j] >> 16) & 0xFFFFu) > 255u) ? 1 : 0;
+  }
+  wide = __syncthreads_or(wide);
+  if (threadIdx.x == 0) cache_wide[tile] = (uint8_t)wide;
+  if (wide) {
+#pragma unroll
+    for (int j = 0; j < CPT; j++) cache[(size_t)tile * NT + threadIdx.x + 256 * j] = wv[j];
+  } else {
+    uint32_t *c32 = reinterpret_cast<uint32_t *>(cache + (size_t)tile * NT);
+#pragma unroll
+    for (int j = 0; j < CPT; j++) c32[threadIdx.x + 256 * j] = fh_cache_pack(wv[j]);
   }
 }
 
@@ -927,6 +957,7 @@ __global__ __launch_bounds__(256, 6) void k_fh_tile3(const uint8_t *__restrict__
                                                  const int32_t *__restrict__ acc32, DtWin w, int tiles_x,
                                                  uint32_t nnodes, const unsigned long long *__restrict__ nodes,
                                                  const unsigned long long *__restrict__ cache,
+                                                 const uint8_t *__restrict__ cache_wide,
                                                  FhRemote rem, double px, float *__restrict__ fdist,
                                                  int32_t *__restrict__ idx32, long long *__restrict__ idx64,
                                                  float *__restrict__ hand, int32_t *__restrict__ a_river,
@@ -939,11 +970,12 @@ __global__ __launch_bounds__(256, 6) void k_fh_tile3(const uint8_t *__restrict__
   const int tile = blockIdx.x;
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int y0 = ty * TH, x0 = tx * TW;
+  const bool wide = cache_wide[tile] != 0;  // block-uniform
   if (threadIdx.x < PS) {
     int ly, lx;
     dt_cell_of_slot(threadIdx.x, ly, lx);
     int f = ly * TW + lx;
-    unsigned long long s = cache[(size_t)tile * NT + f];
+    unsigned long long s = fh_cache_get(cache, wide, tile, f);
     uint32_t sp = (uint32_t)(s >> 32);
     unsigned long long o = fht_pack(FHT_DEAD, 0, FHT_DONE);
     float zr = DT_NODATA;
@@ -1048,9 +1080,17 @@ __global__ __launch_bounds__(256, 6) void k_fh_tile3(const uint8_t *__restrict__
 #pragma unroll
       for (int u = 0; u < VH; u++) {
         int c = 4 * (threadIdx.x + 256 * (h * VH + u));
-        const uint4 *cp = reinterpret_cast<const uint4 *>(cache + (size_t)tile * NT + c);
-        wa[u] = cp[0];
-        wb[u] = cp[1];
+        if (wide) {
+          const uint4 *cp = reinterpret_cast<const uint4 *>(cache + (size_t)tile * NT + c);
+          wa[u] = cp[0];
+          wb[u] = cp[1];
+        } else {  // four narrow words in one 16-byte load
+          uint4 v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint32_t *>(cache + (size_t)tile * NT) + c);
+          unsigned long long a = fh_cache_unpack(v.x), b2 = fh_cache_unpack(v.y), c2 = fh_cache_unpack(v.z),
+                             d2 = fh_cache_unpack(v.w);
+          wa[u] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b2, (uint32_t)(b2 >> 32));
+          wb[u] = make_uint4((uint32_t)c2, (uint32_t)(c2 >> 32), (uint32_t)d2, (uint32_t)(d2 >> 32));
+        }
         int y = y0 + c / TW;
         z4[u] = make_float4(DT_NODATA, DT_NODATA, DT_NODATA, DT_NODATA);
         if (dem && y < w.H) z4[u] = *reinterpret_cast<const float4 *>(dem + (long long)y * w.ld + x0 + c % TW);
@@ -1096,7 +1136,7 @@ __global__ __launch_bounds__(256, 6) void k_fh_tile3(const uint8_t *__restrict__
     int y = y0 + c / TW, x = x0 + c % TW;
     if (y >= w.H || x >= w.W) continue;
     long long o = (long long)y * w.ld + x;
-    CellOut r = solve(cache[(size_t)tile * NT + c], dem ? dem[o] : DT_NODATA);
+    CellOut r = solve(fh_cache_get(cache, wide, tile, c), dem ? dem[o] : DT_NODATA);
     if (fdist) fdist[o] = r.fd;
     if (idx32) idx32[o] = r.i32;
     if (idx64) idx64[o] = r.i64;
@@ -1113,6 +1153,7 @@ __global__ __launch_bounds__(256, 6) void k_fh_tile3(const uint8_t *__restrict__
 
 struct FhScratch {
   unsigned long long *nodes, *cache;
+  uint8_t *cache_wide;  // one flag per tile
   int64_t nnodes, ntiles, P;
   int tiles_x;
 };
@@ -1124,12 +1165,13 @@ static FhScratch fh_layout(const DtWin &w, void *scratch) {
   f.P = dt_perim_count(w.H, w.W);
   f.nodes = (unsigned long long *)scratch;
   f.cache = (unsigned long long *)((char *)scratch + dt_align256(((size_t)f.nnodes + (size_t)f.P) * 8));
+  f.cache_wide = (uint8_t *)f.cache + dt_align256((size_t)f.ntiles * NT * 8) + 256;  // after the round flags
   return f;
 }
 size_t dt_flowhand_tiled_scratch(int64_t H, int64_t W) {
   int64_t ntiles = ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
   return dt_align256(((size_t)ntiles * PS + (size_t)dt_perim_count((int)H, (int)W)) * 8) +
-         dt_align256((size_t)ntiles * NT * 8) + 256;
+         dt_align256((size_t)ntiles * NT * 8) + 256 + dt_align256((size_t)ntiles);
 }
 
 // phase 1: tile pass + perimeter node doubling (rank exits park on their ghosts)
@@ -1140,7 +1182,8 @@ int dt_launch_fh_local(hipStream_t s, const DtWin &w, const uint8_t *fdr, const 
   FhScratch f = fh_layout(w, scratch);
   DT_REQUIRE(f.nnodes + f.P < 0x7FFFFFF0ll, "raster too large for one device tile");
   dim3 gt((unsigned)f.ntiles), b(256), gn((unsigned)((f.nnodes + f.P + 255) / 256));
-  hipLaunchKernelGGL(k_fh_tile1, gt, b, 0, s, fdr, river, w, f.tiles_x, (uint32_t)f.nnodes, f.nodes, f.cache);
+  hipLaunchKernelGGL(k_fh_tile1, gt, b, 0, s, fdr, river, w, f.tiles_x, (uint32_t)f.nnodes, f.nodes, f.cache,
+                     f.cache_wide);
   hipLaunchKernelGGL(k_fh_ghost_init, dim3((unsigned)((f.P + 255) / 256)), b, 0, s, f.nodes, (uint32_t)f.nnodes, f.P);
   // 15 rounds resolve every chain of <= 20000 moves (each node hop is >= 1 move; 2^15 > 20000)
   int *flags = (int *)((char *)f.cache + dt_align256((size_t)f.ntiles * NT * 8));  // the layout's spare 256 bytes
@@ -1186,7 +1229,7 @@ int dt_launch_fh_finish(hipStream_t s, const DtWin &w, const float *dem, const u
   }
   (void)river;
   hipLaunchKernelGGL(k_fh_tile3, gt, b, 0, s, fdr, dem, acc32, w, f.tiles_x, (uint32_t)f.nnodes, f.nodes, f.cache,
-                     rem, px, fdist, idx32, idx64, hand, a_river, G);
+                     f.cache_wide, rem, px, fdist, idx32, idx64, hand, a_river, G);
   return DT_OK;
 }
 

@@ -403,3 +403,29 @@ def test_chain_overlap_branch_gives_the_same_rasters(dt):
     b = chain.run_host(dem, 10.0, overlap=True)
     for k in a:
         assert np.array_equal(a[k], b[k], equal_nan=True), k
+
+
+def test_flowhand_long_in_tile_paths(dt):
+    """boustrophedon paths that stay inside 64 x 64 tiles for thousands of moves: the in-tile move counts
+    exceed 8 bits (the wide form of the HAND word cache) and the doubling needs all its rounds."""
+    H, W = 128, 192
+    fdr = np.zeros((H, W), np.uint8)
+    for y in range(H):
+        fdr[y, :] = 1 if y % 2 == 0 else 16          # east on even rows, west on odd rows
+        fdr[y, W - 1 if y % 2 == 0 else 0] = 4        # turn south at the end of the row
+    fdr[H - 1, 0 if (H - 1) % 2 else W - 1] = 4       # last cell flows off the raster
+    # a second family: serpentines confined to 64-wide columns
+    for x0 in (0, 64):
+        for y in range(64):
+            fdr[y, x0:x0 + 64] = 1 if y % 2 == 0 else 16
+            fdr[y, x0 + 63 if y % 2 == 0 else x0] = 4
+    rng = np.random.default_rng(5)
+    dem = (rng.random((H, W)) * 50 + 10).astype(np.float32)
+    river = np.zeros((H, W), np.int8)
+    river[63, 0] = river[63, 64] = 1
+    river[H - 1, W // 2] = 1
+    fd_o, idx_o, hand_o = oracle.flowhand(dem, fdr, river, 10.0)
+    fd, idx, hand = dt.flowhand.flow_hand_index(dem, fdr, river, 10.0)
+    assert np.array_equal(idx, idx_o) and np.array_equal(hand, hand_o)
+    assert (idx_o >= 0).sum() > 8000 and fd_o.max() > 40000
+    assert_float_close(fd, fd_o, rtol=1e-6, what="flow distance")
