@@ -195,7 +195,7 @@ __device__ __forceinline__ unsigned long long fa_rec(uint32_t W_, uint32_t xslot
 
 __global__ __launch_bounds__(256, 6) void k_fa_tile1(const uint8_t *__restrict__ fdr, DtWin w, int tiles_x,
                                                     unsigned long long *__restrict__ rec,
-                                                    int32_t *__restrict__ acc32) {
+                                                    uint16_t *__restrict__ loc16) {
   // 24 KiB of LDS: six tiles per CU.  The direction codes are staged through the receive array (free until
   // the rounds start), which is all zero again when the rounds end and then serves as the cycle mask.
   __shared__ __attribute__((aligned(16))) uint32_t s_pv[NT];  // val:16 | idx:12 | PT_EXIT | PT_ALIVE
@@ -253,11 +253,11 @@ __global__ __launch_bounds__(256, 6) void k_fa_tile1(const uint8_t *__restrict__
     }
     rec[(size_t)tile * PS + threadIdx.x] = fa_rec(my_code ? (p >> 16) : 0u, xs, my_code, my_flags);
   }
-  // in-tile accumulation (upstream cells of this tile only); pass 3 adds what enters from outside
+  // in-tile accumulation (upstream cells of this tile only, <= 4095: 2 bytes per cell, tile-major; 0xFFFF =
+  // on an in-tile cycle); pass 3 adds what enters from outside
   for (int j = 0; j < CPT; j++) {
     int c = threadIdx.x + 256 * j;
-    int y = y0 + c / TW, x = x0 + c % TW;
-    if (y < w.H && x < w.W) acc32[(long long)y * w.ld + x] = s_cyc[c] ? -100 : (int32_t)((s_pv[c] >> 16) - 1u);
+    loc16[(size_t)tile * NT + c] = s_cyc[c] ? (uint16_t)0xFFFFu : (uint16_t)((s_pv[c] >> 16) - 1u);
   }
 }
 
@@ -346,6 +346,7 @@ template <bool HAS_DEM, bool W_RIVER>
 __global__ __launch_bounds__(256, 5) void k_fa_tile3(const uint8_t *__restrict__ fdr,
                                                     const float *__restrict__ dem, DtWin w, int tiles_x,
                                                     const unsigned long long *__restrict__ ext,
+                                                    const uint16_t *__restrict__ loc16,
                                                     int32_t *__restrict__ acc32, int32_t river_thr,
                                                     int8_t *__restrict__ river) {
   // 24 KiB of LDS: six tiles per CU (the kernel is a latency chain of LDS walks).  The direction codes are
@@ -389,7 +390,8 @@ __global__ __launch_bounds__(256, 5) void k_fa_tile3(const uint8_t *__restrict__
     int y = y0 + c / TW, x = x0 + c % TW;
     bool in = y < w.H && x < w.W;
     long long o = (long long)y * w.ld + x;
-    av[j] = in ? acc32[o] : -100;
+    uint32_t l16 = loc16[(size_t)tile * NT + c];
+    av[j] = l16 == 0xFFFFu ? -100 : (int32_t)l16;
     zv[j] = (HAS_DEM && in) ? dem[o] : 0.0f;
   }
   __syncthreads();
@@ -529,6 +531,7 @@ __global__ __launch_bounds__(256) void k_fa_propagate(DtWin w, int tiles_x, int6
 struct FaScratch {
   unsigned long long *rec, *state, *ext;
   uint32_t *entry_of, *parent, *jump, *nxt;
+  uint16_t *loc16;  // pass 1's in-tile counts, tile-major
   int64_t nnodes, ntiles;
   int tiles_x;
 };
@@ -545,13 +548,15 @@ static FaScratch fa_layout(const DtWin &w, void *scratch) {
   f.entry_of = (uint32_t *)p;  p += n4;
   f.parent = (uint32_t *)p;  p += n4;
   f.jump = (uint32_t *)p;  p += n4;
-  f.nxt = (uint32_t *)p;
+  f.nxt = (uint32_t *)p;  p += n4;
+  p += 256;  // round flags of the jump kernels
+  f.loc16 = (uint16_t *)p;
   return f;
 }
 size_t dt_flowacc_tiled_scratch(int64_t H, int64_t W) {
   int64_t ntiles = ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
   size_t nn = (size_t)ntiles * PS;
-  return dt_align256(nn * 8) * 3 + dt_align256(nn * 4) * 4 + 256;
+  return dt_align256(nn * 8) * 3 + dt_align256(nn * 4) * 4 + 256 + dt_align256((size_t)ntiles * NT * 2);
 }
 
 // phase 1: tile pass + local perimeter graph.  With `rank_level` the rank-exit jumps are resolved too
@@ -564,7 +569,8 @@ int dt_launch_fa_local(hipStream_t s, const DtWin &w, const uint8_t *fdr, void *
   DT_REQUIRE(f.nnodes < 0x7FFFFFF0ll, "raster too large for one device tile");
   DT_HIP(hipMemsetAsync(f.state, 0, dt_align256((size_t)f.nnodes * 8) * 2, s));
   dim3 gt((unsigned)f.ntiles), b(256), gn((unsigned)((f.nnodes + 255) / 256));
-  hipLaunchKernelGGL(k_fa_tile1, gt, b, 0, s, fdr, w, f.tiles_x, f.rec, acc32);
+  (void)acc32;  // written by pass 3 only
+  hipLaunchKernelGGL(k_fa_tile1, gt, b, 0, s, fdr, w, f.tiles_x, f.rec, f.loc16);
   hipLaunchKernelGGL(k_fa_link, gn, b, 0, s, f.rec, f.nnodes, f.tiles_x, f.entry_of, f.parent, f.state);
   hipLaunchKernelGGL(k_fa_reduce, gn, b, 0, s, f.rec, f.nnodes, f.entry_of, f.parent, f.state, f.ext);
   if (rank_level) {
@@ -604,10 +610,10 @@ int dt_launch_fa_finish(hipStream_t s, const DtWin &w, const uint8_t *fdr, const
   }
   hipLaunchKernelGGL(k_fa_poison, gn, b, 0, s, f.rec, f.nnodes, f.entry_of, f.state, f.ext);
   int32_t thr = river_thr > 2147483647ll ? 2147483647 : (river_thr < -2147483647ll ? -2147483647 : (int32_t)river_thr);
-  if (dem && river) hipLaunchKernelGGL((k_fa_tile3<true, true>), gt, b, 0, s, fdr, dem, w, f.tiles_x, f.ext, acc32, thr, river);
-  else if (dem) hipLaunchKernelGGL((k_fa_tile3<true, false>), gt, b, 0, s, fdr, dem, w, f.tiles_x, f.ext, acc32, thr, river);
-  else if (river) hipLaunchKernelGGL((k_fa_tile3<false, true>), gt, b, 0, s, fdr, dem, w, f.tiles_x, f.ext, acc32, thr, river);
-  else hipLaunchKernelGGL((k_fa_tile3<false, false>), gt, b, 0, s, fdr, dem, w, f.tiles_x, f.ext, acc32, thr, river);
+  if (dem && river) hipLaunchKernelGGL((k_fa_tile3<true, true>), gt, b, 0, s, fdr, dem, w, f.tiles_x, f.ext, f.loc16, acc32, thr, river);
+  else if (dem) hipLaunchKernelGGL((k_fa_tile3<true, false>), gt, b, 0, s, fdr, dem, w, f.tiles_x, f.ext, f.loc16, acc32, thr, river);
+  else if (river) hipLaunchKernelGGL((k_fa_tile3<false, true>), gt, b, 0, s, fdr, dem, w, f.tiles_x, f.ext, f.loc16, acc32, thr, river);
+  else hipLaunchKernelGGL((k_fa_tile3<false, false>), gt, b, 0, s, fdr, dem, w, f.tiles_x, f.ext, f.loc16, acc32, thr, river);
   return DT_OK;
 }
 
