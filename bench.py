@@ -43,7 +43,7 @@ OP_KERNELS = {
     "slope_twi": ["k_stencil<true, false, false, true>"],
     "downslope": ["k_downslope_win"],
 }
-PMC_FILE = os.path.join(ROOT, "profiles", "r1", "v5_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r1", "v6_pmc_traffic.json")
 
 
 def pmc_traffic(op, size):
@@ -55,7 +55,7 @@ def pmc_traffic(op, size):
         tot = 0.0
         for k in OP_KERNELS[op]:
             e = d["kernels"][k]
-            tot += max(e["launches_per_step"], 1) * (2.0 * e["fetch_kb"] + e["write_kb"]) * 1024.0
+            tot += (2.0 * e["fetch_kb_step"] + e["write_kb_step"]) * 1024.0
         return tot
     except Exception:
         return None
