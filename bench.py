@@ -39,7 +39,7 @@ OP_KERNELS = {
     "d8": ["k_stencil<false, true, false, false>"],
     "flowacc_river": ["k_fa_tile1", "k_fa_link", "k_fa_reduce", "k_fa_poison", "k_fa_tile3<true, true>",
                       "__amd_rocclr_fillBufferAligned"],
-    "flowhand_gfi": ["k_fh_tile1", "k_fh_ghost_init", "k_fh_node_jump", "k_fh_tile3"],
+    "flowhand_gfi": ["k_fh_tile1n", "k_fh_tile1", "k_fh_ghost_init", "k_fh_node_jump", "k_fh_tile3"],
     "slope_twi": ["k_stencil<true, false, false, true>"],
     "downslope": ["k_downslope_win"],
 }

@@ -802,11 +802,12 @@ __global__ __launch_bounds__(256) void k_fh_tile1(const uint8_t *__restrict__ fd
                                                  const int8_t *__restrict__ river, DtWin w, int tiles_x,
                                                  uint32_t nnodes, unsigned long long *__restrict__ nodes,
                                                  unsigned long long *__restrict__ cache,
-                                                 uint8_t *__restrict__ cache_wide) {
+                                                 uint8_t *__restrict__ cache_wide, int only_marked) {
   __shared__ __attribute__((aligned(16))) uint8_t s_fdr[NT];
   __shared__ uint8_t s_halo[2 * (TW + 2) + 2 * TH];
   __shared__ __attribute__((aligned(16))) unsigned long long s_st[NT];
   const int tile = blockIdx.x;
+  if (only_marked && cache_wide[tile] != 2) return;  // block-uniform: k_fh_tile1n did this tile
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int y0 = ty * TH, x0 = tx * TW;
   FhTile T{s_fdr, s_halo, s_st};
@@ -850,6 +851,152 @@ __global__ __launch_bounds__(256) void k_fh_tile1(const uint8_t *__restrict__ fd
     uint32_t *c32 = reinterpret_cast<uint32_t *>(cache + (size_t)tile * NT);
 #pragma unroll
     for (int j = 0; j < CPT; j++) c32[threadIdx.x + 256 * j] = fh_cache_pack(wv[j]);
+  }
+}
+
+// ---- pass 1, narrow form -----------------------------------------------------------------------------
+// The same tile solve with one 32-bit LDS word per cell,  n_card:9 | n_diag:9 | done:1 | ptr:12  (bit 8 of a
+// count is a guard: counts are <= 255 before an addition, so a sum cannot carry into the next field), and the
+// kind of a path's end in a byte array indexed by the end cell.  21 KiB of LDS less than the 64-bit form:
+// six tiles per CU instead of four, and half the LDS bytes per doubling step.  A tile in which some path
+// makes more than 255 moves of a kind cannot be represented: its workgroup stops, marks the tile
+// (cache_wide = 2) and the 64-bit kernel, launched afterwards over all tiles, redoes exactly the marked ones.
+#define FN_CNT 0x3FFFFu  /* both counts */
+#define FN_DONE 0x40000u
+#define FN_LOW 0x7FFFFu  /* counts + done: what ONE addition propagates */
+#define FN_OVF 0x20100u  /* a count above 255 */
+#define FN_PTR_SH 19
+__global__ __launch_bounds__(256, 6) void k_fh_tile1n(const uint8_t *__restrict__ fdr,
+                                                     const int8_t *__restrict__ river, DtWin w, int tiles_x,
+                                                     uint32_t nnodes, unsigned long long *__restrict__ nodes,
+                                                     unsigned long long *__restrict__ cache,
+                                                     uint8_t *__restrict__ cache_wide) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_fdr[NT];
+  __shared__ uint8_t s_halo[2 * (TW + 2) + 2 * TH];
+  __shared__ __attribute__((aligned(16))) uint32_t s_w[NT];
+  __shared__ __attribute__((aligned(16))) uint8_t s_kind[NT];  // first the river mask, then the end kinds
+  __shared__ int s_ovf;
+  const int tile = blockIdx.x;
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const int y0 = ty * TH, x0 = tx * TW;
+  FhTile T{s_fdr, s_halo, nullptr};
+  dt_tile_load_fdr(fdr, w, y0, x0, s_fdr);
+  for (int i = threadIdx.x; i < 2 * (TW + 2) + 2 * TH; i += 256) {
+    int y, x;
+    if (i < TW + 2) { y = y0 - 1; x = x0 - 1 + i; }
+    else if (i < 2 * (TW + 2)) { y = y0 + TH; x = x0 - 1 + (i - (TW + 2)); }
+    else if (i < 2 * (TW + 2) + TH) { y = y0 + (i - 2 * (TW + 2)); x = x0 - 1; }
+    else { y = y0 + (i - 2 * (TW + 2) - TH); x = x0 + TW; }
+    uint8_t v = 0;
+    if (dt_readable(w, y, x)) v = fdr[(long long)y * w.ld + x];
+    s_halo[i] = v;
+  }
+  dt_tile_load_fdr(reinterpret_cast<const uint8_t *>(river), w, y0, x0, s_kind);
+  if (threadIdx.x == 0) s_ovf = 0;
+  __syncthreads();
+  uint32_t riv = 0;
+#pragma unroll
+  for (int j = 0; j < CPT; j++)
+    if (s_kind[threadIdx.x + 256 * j] == 1) riv |= 1u << j;
+  __syncthreads();
+  const bool interior = dt_tile_interior(w, y0, x0);
+  for (int j = 0; j < CPT; j++) {
+    int c = threadIdx.x + 256 * j;
+    int ly = c / TW, lx = c % TW;
+    int y = y0 + ly, x = x0 + lx;
+    uint32_t code = s_fdr[c];
+    uint32_t word = ((uint32_t)c << FN_PTR_SH) | FN_DONE, kind = K_DEAD;  // flowhand.py:601 / non-D8 code :830
+    if ((interior || (y < w.H && x < w.W)) && code != 0u) {
+      if ((riv >> j) & 1u) {
+        kind = K_RIVER;  // flowhand.py:609-612
+      } else if (dt_d8_valid(code)) {
+        int dy, dx;
+        dt_d8_delta(code, dy, dx);
+        uint32_t ny = (uint32_t)(ly + dy), nx = (uint32_t)(lx + dx);
+        bool in_tile = ny < (uint32_t)TH && nx < (uint32_t)TW;
+        // raster exit / arrival on fdr == 0 (flowhand.py:623-628, :826) stay dead
+        if ((interior || dt_in_global(w, y + dy, x + dx)) && fht_fdr_at(T, ly + dy, lx + dx) != 0u) {
+          if (!interior && !dt_in_core(w, y + dy, x + dx)) kind = K_REXIT;
+          else if (!in_tile) kind = K_EXIT;  // the step itself is added by the user
+          else word = ((ny * TW + nx) << FN_PTR_SH) | ((dy != 0 && dx != 0) ? (1u << 9) : 1u);
+        }
+      }
+    }
+    s_w[c] = word;
+    s_kind[c] = (uint8_t)kind;
+  }
+  __syncthreads();
+  // pointer doubling in place; ONE addition of the low 19 bits adds both counts and inherits the done bit
+  uint2 *s_w2 = reinterpret_cast<uint2 *>(s_w);  // lane owns adjacent cell pairs
+  for (int round = 0; round < 13; round++) {
+    int changed = 0;
+    uint32_t ovf = 0;
+#pragma unroll
+    for (int j = 0; j < CPT / 2; j++) {
+      int c2 = threadIdx.x + 256 * j;
+      uint2 v = s_w2[c2];
+      bool dx = (v.x & FN_DONE) != 0u, dy = (v.y & FN_DONE) != 0u;
+      if (dx && dy) continue;
+      if (!dx) {
+        uint32_t t = s_w[v.x >> FN_PTR_SH];
+        uint32_t sum = (v.x & FN_LOW) + (t & FN_LOW);
+        ovf |= sum & FN_OVF;
+        v.x = (t & ~FN_LOW) | sum;
+      }
+      if (!dy) {
+        uint32_t t = s_w[v.y >> FN_PTR_SH];
+        uint32_t sum = (v.y & FN_LOW) + (t & FN_LOW);
+        ovf |= sum & FN_OVF;
+        v.y = (t & ~FN_LOW) | sum;
+      }
+      s_w2[c2] = v;
+      changed = 1;
+    }
+    if (ovf) s_ovf = 1;
+    if (!__syncthreads_or(changed)) break;
+    if (s_ovf) break;  // block-uniform: written before the barrier
+  }
+  if (s_ovf) {
+    if (threadIdx.x == 0) cache_wide[tile] = 2;  // for k_fh_tile1
+    return;
+  }
+  // cells unfinished after 13 rounds run into an in-tile D8 cycle: dead (flowhand.py:830-837)
+  uint32_t wv[CPT];
+#pragma unroll
+  for (int j = 0; j < CPT; j++) {
+    int c = threadIdx.x + 256 * j;
+    uint32_t v = s_w[c];
+    uint32_t f = v >> FN_PTR_SH, kind = s_kind[f];
+    if (!(v & FN_DONE)) { f = (uint32_t)c; kind = K_DEAD; v = 0; }
+    wv[j] = f | (kind << 12) | (((v >> 9) & 0xFFu) << 15) | ((v & 0xFFu) << 23);  // the cache's narrow word
+  }
+  if (threadIdx.x == 0) cache_wide[tile] = 0;
+  uint32_t *c32 = reinterpret_cast<uint32_t *>(cache + (size_t)tile * NT);
+#pragma unroll
+  for (int j = 0; j < CPT; j++) c32[threadIdx.x + 256 * j] = wv[j];
+  __syncthreads();  // everybody has read s_w: reuse it to hand the perimeter lanes their cells' final words
+#pragma unroll
+  for (int j = 0; j < CPT; j++) s_w[threadIdx.x + 256 * j] = wv[j];
+  __syncthreads();
+  if (threadIdx.x < PS) {
+    int ly, lx;
+    dt_cell_of_slot(threadIdx.x, ly, lx);
+    unsigned long long sw = fh_cache_unpack(s_w[ly * TW + lx]);
+    uint32_t ptr = (uint32_t)(sw >> 32), nd = (uint32_t)((sw >> 16) & 0xFFFFu), nc = (uint32_t)sw & 0x7FFFu;
+    uint32_t kind = (ptr >> 12) & 7u, f = ptr & 0xFFFu;
+    int fy = (int)f / TW, fx = (int)f % TW;
+    unsigned long long o = fht_pack(FHT_DEAD, 0, FHT_DONE);
+    if (kind == K_RIVER) {
+      o = fht_pack((uint32_t)((y0 + fy) * w.W + x0 + fx), nd, nc | FHT_DONE);
+    } else if (kind == K_EXIT || kind == K_REXIT) {
+      int dy, dx;
+      dt_d8_delta(s_fdr[f], dy, dx);
+      bool diag = dy != 0 && dx != 0;
+      uint32_t node = kind == K_EXIT ? dt_node_of(y0 + fy + dy, x0 + fx + dx, tiles_x)
+                                     : nnodes + (uint32_t)dt_perim_index(w.H, w.W, y0 + fy, x0 + fx);
+      o = fht_pack(node, nd + (diag ? 1u : 0u), nc + (diag ? 0u : 1u));
+    }
+    nodes[(size_t)tile * PS + threadIdx.x] = o;
   }
 }
 
@@ -1188,8 +1335,12 @@ int dt_launch_fh_local(hipStream_t s, const DtWin &w, const uint8_t *fdr, const 
   FhScratch f = fh_layout(w, scratch);
   DT_REQUIRE(f.nnodes + f.P < 0x7FFFFFF0ll, "raster too large for one device tile");
   dim3 gt((unsigned)f.ntiles), b(256), gn((unsigned)((f.nnodes + f.P + 255) / 256));
-  hipLaunchKernelGGL(k_fh_tile1, gt, b, 0, s, fdr, river, w, f.tiles_x, (uint32_t)f.nnodes, f.nodes, f.cache,
+  // narrow solve everywhere, then the 64-bit solve for the tiles it had to give up (usually none: the
+  // second launch is 65536 workgroups that read one byte and leave)
+  hipLaunchKernelGGL(k_fh_tile1n, gt, b, 0, s, fdr, river, w, f.tiles_x, (uint32_t)f.nnodes, f.nodes, f.cache,
                      f.cache_wide);
+  hipLaunchKernelGGL(k_fh_tile1, gt, b, 0, s, fdr, river, w, f.tiles_x, (uint32_t)f.nnodes, f.nodes, f.cache,
+                     f.cache_wide, 1);
   hipLaunchKernelGGL(k_fh_ghost_init, dim3((unsigned)((f.P + 255) / 256)), b, 0, s, f.nodes, (uint32_t)f.nnodes, f.P);
   // 15 rounds resolve every chain of <= 20000 moves (each node hop is >= 1 move; 2^15 > 20000)
   int *flags = (int *)((char *)f.cache + dt_align256((size_t)f.ntiles * NT * 8));  // the layout's spare 256 bytes
