@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256) void k_fa_poison(const unsigned long long *__r
 // through every cell of p's in-tile path: one lane per entry cell walks that path adding ext[p] to
 // an LDS delta raster (integer adds: order-free), then delta is added to pass 1's in-tile counts.
 template <bool HAS_DEM, bool W_RIVER>
-__global__ __launch_bounds__(256, 5) void k_fa_tile3(const uint8_t *__restrict__ fdr,
+__global__ __launch_bounds__(256, 6) void k_fa_tile3(const uint8_t *__restrict__ fdr,
                                                     const float *__restrict__ dem, DtWin w, int tiles_x,
                                                     const unsigned long long *__restrict__ ext,
                                                     const uint16_t *__restrict__ loc16,
@@ -381,18 +381,36 @@ __global__ __launch_bounds__(256, 5) void k_fa_tile3(const uint8_t *__restrict__
     s_nxt[c] = (uint16_t)nx[j];
     s_delta[c] = 0u;
   }
-  // pass 1's counts and the heights are fetched now, so that their latency hides behind the serial walks
+  // pass 1's counts and the heights are fetched now, so that their latency hides behind the serial walks.
+  // Block-uniform fast form: whole 64-cell rows inside the core, 16-byte aligned rasters -> each lane owns 4
+  // groups of 4 consecutive cells (8- and 16-byte loads, 16- and 4-byte stores)
+  const bool vec = x0 + TW <= w.W && (w.ld & 3) == 0 && (((uintptr_t)acc32 & 15) == 0) &&
+                   (!HAS_DEM || ((uintptr_t)dem & 15) == 0) && (!W_RIVER || ((uintptr_t)river & 3) == 0);
+  constexpr int VPT = NT / 4 / 256;
+  uint2 l4[VPT];
+  float4 z4[VPT];
   int32_t av[CPT];
   float zv[CPT];
+  if (vec) {
 #pragma unroll
-  for (int j = 0; j < CPT; j++) {
-    int c = threadIdx.x + 256 * j;
-    int y = y0 + c / TW, x = x0 + c % TW;
-    bool in = y < w.H && x < w.W;
-    long long o = (long long)y * w.ld + x;
-    uint32_t l16 = loc16[(size_t)tile * NT + c];
-    av[j] = l16 == 0xFFFFu ? -100 : (int32_t)l16;
-    zv[j] = (HAS_DEM && in) ? dem[o] : 0.0f;
+    for (int u = 0; u < VPT; u++) {
+      int c = 4 * (threadIdx.x + 256 * u);
+      int y = y0 + c / TW;
+      l4[u] = *reinterpret_cast<const uint2 *>(loc16 + (size_t)tile * NT + c);
+      z4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (HAS_DEM && y < w.H) z4[u] = *reinterpret_cast<const float4 *>(dem + (long long)y * w.ld + x0 + c % TW);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < CPT; j++) {
+      int c = threadIdx.x + 256 * j;
+      int y = y0 + c / TW, x = x0 + c % TW;
+      bool in = y < w.H && x < w.W;
+      long long o = (long long)y * w.ld + x;
+      uint32_t l16 = loc16[(size_t)tile * NT + c];
+      av[j] = l16 == 0xFFFFu ? -100 : (int32_t)l16;
+      zv[j] = (HAS_DEM && in) ? dem[o] : 0.0f;
+    }
   }
   __syncthreads();
   if (e != 0ull) {
@@ -414,17 +432,39 @@ __global__ __launch_bounds__(256, 5) void k_fa_tile3(const uint8_t *__restrict__
     }
   }
   __syncthreads();
+  auto finish = [&](uint32_t l16, uint32_t d, float z) -> int32_t {
+    int32_t v = l16 == 0xFFFFu ? -100 : (int32_t)l16;
+    if (v != -100) v += (int32_t)(d & 0x7FFFFFFFu);
+    if (d & 0x80000000u) v = -100;
+    if (HAS_DEM && z <= DT_NODATA) v = -100;
+    return v;
+  };
+  if (vec) {
+#pragma unroll
+    for (int u = 0; u < VPT; u++) {
+      int c = 4 * (threadIdx.x + 256 * u);
+      int y = y0 + c / TW;
+      if (y >= w.H) continue;
+      long long o = (long long)y * w.ld + x0 + c % TW;
+      uint4 d = *reinterpret_cast<const uint4 *>(&s_delta[c]);
+      int4 v = make_int4(finish(l4[u].x & 0xFFFFu, d.x, z4[u].x), finish(l4[u].x >> 16, d.y, z4[u].y),
+                         finish(l4[u].y & 0xFFFFu, d.z, z4[u].z), finish(l4[u].y >> 16, d.w, z4[u].w));
+      *reinterpret_cast<int4 *>(acc32 + o) = v;
+      if (W_RIVER) {
+        uint32_t r = (v.x > river_thr ? 1u : 0u) | (v.y > river_thr ? 0x100u : 0u) |
+                     (v.z > river_thr ? 0x10000u : 0u) | (v.w > river_thr ? 0x1000000u : 0u);
+        *reinterpret_cast<uint32_t *>(river + o) = r;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < CPT; j++) {
     int c = threadIdx.x + 256 * j;
     int y = y0 + c / TW, x = x0 + c % TW;
     if (y >= w.H || x >= w.W) continue;
     long long o = (long long)y * w.ld + x;
-    int32_t v = av[j];
-    uint32_t d = s_delta[c];
-    if (v != -100) v += (int32_t)(d & 0x7FFFFFFFu);
-    if (d & 0x80000000u) v = -100;
-    if (HAS_DEM && zv[j] <= DT_NODATA) v = -100;
+    int32_t v = finish(av[j] == -100 ? 0xFFFFu : (uint32_t)av[j], s_delta[c], zv[j]);
     acc32[o] = v;
     if (W_RIVER) river[o] = v > river_thr ? 1 : 0;
   }
