@@ -255,9 +255,17 @@ __global__ __launch_bounds__(256, 6) void k_fa_tile1(const uint8_t *__restrict__
   }
   // in-tile accumulation (upstream cells of this tile only, <= 4095: 2 bytes per cell, tile-major; 0xFFFF =
   // on an in-tile cycle); pass 3 adds what enters from outside
-  for (int j = 0; j < CPT; j++) {
-    int c = threadIdx.x + 256 * j;
-    loc16[(size_t)tile * NT + c] = s_cyc[c] ? (uint16_t)0xFFFFu : (uint16_t)((s_pv[c] >> 16) - 1u);
+  // (4 cells per lane: one 16-byte LDS read, one 4-byte mask read, one 8-byte store)
+#pragma unroll
+  for (int u = 0; u < NT / 4 / 256; u++) {
+    int c = 4 * (threadIdx.x + 256 * u);
+    uint4 pv = *reinterpret_cast<const uint4 *>(&s_pv[c]);
+    uint32_t cy = *reinterpret_cast<const uint32_t *>(&s_cyc[c]);
+    uint32_t a = (cy & 0xFFu) ? 0xFFFFu : ((pv.x >> 16) - 1u) & 0xFFFFu;
+    uint32_t b = (cy & 0xFF00u) ? 0xFFFFu : ((pv.y >> 16) - 1u) & 0xFFFFu;
+    uint32_t d = (cy & 0xFF0000u) ? 0xFFFFu : ((pv.z >> 16) - 1u) & 0xFFFFu;
+    uint32_t e = (cy & 0xFF000000u) ? 0xFFFFu : ((pv.w >> 16) - 1u) & 0xFFFFu;
+    *reinterpret_cast<uint2 *>(loc16 + (size_t)tile * NT + c) = make_uint2(a | (b << 16), d | (e << 16));
   }
 }
 
@@ -1011,13 +1019,16 @@ __global__ __launch_bounds__(256, 6) void k_fh_tile1n(const uint8_t *__restrict_
     wv[j] = f | (kind << 12) | (((v >> 9) & 0xFFu) << 15) | ((v & 0xFFu) << 23);  // the cache's narrow word
   }
   if (threadIdx.x == 0) cache_wide[tile] = 0;
-  uint32_t *c32 = reinterpret_cast<uint32_t *>(cache + (size_t)tile * NT);
-#pragma unroll
-  for (int j = 0; j < CPT; j++) c32[threadIdx.x + 256 * j] = wv[j];
-  __syncthreads();  // everybody has read s_w: reuse it to hand the perimeter lanes their cells' final words
+  __syncthreads();  // everybody has read s_w: reuse it for the final words (cache store, perimeter lanes)
 #pragma unroll
   for (int j = 0; j < CPT; j++) s_w[threadIdx.x + 256 * j] = wv[j];
   __syncthreads();
+  uint32_t *c32 = reinterpret_cast<uint32_t *>(cache + (size_t)tile * NT);
+#pragma unroll
+  for (int u = 0; u < NT / 4 / 256; u++) {
+    int c = 4 * (threadIdx.x + 256 * u);
+    *reinterpret_cast<uint4 *>(c32 + c) = *reinterpret_cast<const uint4 *>(&s_w[c]);
+  }
   if (threadIdx.x < PS) {
     int ly, lx;
     dt_cell_of_slot(threadIdx.x, ly, lx);
