@@ -874,6 +874,31 @@ __global__ __launch_bounds__(1024, 8) void k_downslope_win(const float *__restri
   // readable cells (inside the global raster and in memory): rows [ya, yb), columns [xa, xb)
   const int ya = max(-w.halo, -w.gy0), yb = min(w.H + w.halo, w.Hg - w.gy0);
   const int xa = max(-w.halo, -w.gx0), xb = min(w.W + w.halo, w.Wg - w.gx0);
+  // block-uniform: every window cell is in memory and no move from it can leave the global raster
+  const bool interior = vec && wy0 >= ya && wy0 + DW_WIN <= yb && wx0 >= xa && wx0 + DW_WIN <= xb &&
+                        w.gy0 + wy0 >= 1 && w.gy0 + wy0 + DW_WIN <= w.Hg - 1 && w.gx0 + wx0 >= 1 &&
+                        w.gx0 + wx0 + DW_WIN <= w.Wg - 1;
+  const float ninf = -__builtin_inff();
+  // 112 rows x 28 groups of 4 cells (wx0 is a multiple of 8: float4 / uchar4 stay aligned).  A nodata
+  // height is staged as -inf: the walk never moves onto nodata (downslope.py:231-281); a lane that does
+  // sees an infinite drop, stops, and is redone by the generic walk.
+  constexpr int NG = DW_WIN * (DW_WIN / 4);  // 3136 groups of 4 cells: up to 4 per thread
+  // all of a thread's loads first (one memory round trip per workgroup instead of three), then the table
+  // and its barrier (which so overlap the loads), then decode
+  float4 vv[4];
+  uint32_t cc[4];
+  if (interior) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      int i = threadIdx.x + 1024 * u;
+      if (i < NG) {
+        int r = i / (DW_WIN / 4), c4 = (i - r * (DW_WIN / 4)) * 4;
+        long long g = (long long)(wy0 + r) * w.ld + wx0 + c4;
+        vv[u] = *reinterpret_cast<const float4 *>(dem + g);
+        cc[u] = *reinterpret_cast<const uint32_t *>(fdr + g);
+      }
+    }
+  }
   // D8 code -> move word (256 entries: one LDS read per cell instead of ~15 VALU instructions)
   if (threadIdx.x < 256) {
     uint32_t code = threadIdx.x, mw = MW_BADCODE | MW_STOP | MW_BIAS;
@@ -886,29 +911,7 @@ __global__ __launch_bounds__(1024, 8) void k_downslope_win(const float *__restri
     s_lut[code] = (uint16_t)mw;
   }
   __syncthreads();
-  // block-uniform: every window cell is in memory and no move from it can leave the global raster
-  const bool interior = vec && wy0 >= ya && wy0 + DW_WIN <= yb && wx0 >= xa && wx0 + DW_WIN <= xb &&
-                        w.gy0 + wy0 >= 1 && w.gy0 + wy0 + DW_WIN <= w.Hg - 1 && w.gx0 + wx0 >= 1 &&
-                        w.gx0 + wx0 + DW_WIN <= w.Wg - 1;
-  const float ninf = -__builtin_inff();
-  // 112 rows x 28 groups of 4 cells (wx0 is a multiple of 8: float4 / uchar4 stay aligned).  A nodata
-  // height is staged as -inf: the walk never moves onto nodata (downslope.py:231-281); a lane that does
-  // sees an infinite drop, stops, and is redone by the generic walk.
-  constexpr int NG = DW_WIN * (DW_WIN / 4);  // 3136 groups of 4 cells: up to 4 per thread
   if (interior) {
-    // all of a thread's loads first (one memory round trip per workgroup instead of three), then decode
-    float4 vv[4];
-    uint32_t cc[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      int i = threadIdx.x + 1024 * u;
-      if (i < NG) {
-        int r = i / (DW_WIN / 4), c4 = (i - r * (DW_WIN / 4)) * 4;
-        long long g = (long long)(wy0 + r) * w.ld + wx0 + c4;
-        vv[u] = *reinterpret_cast<const float4 *>(dem + g);
-        cc[u] = *reinterpret_cast<const uint32_t *>(fdr + g);
-      }
-    }
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       int i = threadIdx.x + 1024 * u;
