@@ -127,7 +127,17 @@ struct SlopeCell {
 
 // scan positions: NW0 N1 NE2 W3 E4 SW5 S6 SE7.  NEED_CODE = false (slope only): the D8 bookkeeping
 // (which neighbour, scan position for ties) is skipped -- the slope value does not depend on it.
-template <bool NEED_CODE>
+// scan position (NW 0, N 1, NE 2, W 3, E 4, SW 5, S 6, SE 7; 8 = none) of a D8 code
+__device__ __forceinline__ int dt_scan_pos(uint32_t code) {
+  if (code == 0u) return 8;
+  // bit index of the code 0..7 = E SE S SW W NW N NE -> position 4 7 6 5 3 0 1 2
+  return (int)((0x21035674u >> (4 * (__ffs((int)code) - 1))) & 0xFu);
+}
+
+// Neighbour heights arrive with nodata (== -100) replaced by +inf (done once per cell when the tile is
+// staged): c - inf = -inf never beats a candidate, which is the reference's "neighbour == -100 skipped"
+// (slope.py:247) without a test per neighbour.  `c` is the centre's original value.
+template <bool NEED_CODE, bool NEED_SLOPE>
 __device__ __forceinline__ SlopeCell dt_slope_cell(float c, float nw, float n, float ne, float w,
                                                   float e, float sw, float s, float se,
                                                   double inv_card, double inv_diag, double dcard,
@@ -138,52 +148,51 @@ __device__ __forceinline__ SlopeCell dt_slope_cell(float c, float nw, float n, f
     r.code = 0;
     return r;
   }
-  // cardinals in scan order N, W, E, S; neighbour == -100 skipped (slope.py:247)
+  // cardinals in scan order N, W, E, S, then the diagonals NW, NE, SW, SE; strict > keeps the first maximum
   float cb = 0.0f, db = 0.0f;
-  int cpos = 8, dpos = 8;
   uint32_t ccode = 0, dcode = 0;
   if (NEED_CODE) {
-#define DT_CAND(nb, best, bcode, bpos, code_, pos_) \
-  {                                                 \
-    float d_ = c - (nb);                            \
-    if ((nb) != DT_NODATA && d_ > best) {           \
-      best = d_;                                    \
-      bcode = code_;                                \
-      bpos = pos_;                                  \
-    }                                               \
+#define DT_CAND(nb, best, bcode, code_) \
+  {                                     \
+    float d_ = c - (nb);                \
+    if (d_ > best) {                    \
+      best = d_;                        \
+      bcode = code_;                    \
+    }                                   \
   }
-    DT_CAND(n, cb, ccode, cpos, 64u, 1)
-    DT_CAND(w, cb, ccode, cpos, 16u, 3)
-    DT_CAND(e, cb, ccode, cpos, 1u, 4)
-    DT_CAND(s, cb, ccode, cpos, 4u, 6)
-    DT_CAND(nw, db, dcode, dpos, 32u, 0)
-    DT_CAND(ne, db, dcode, dpos, 128u, 2)
-    DT_CAND(sw, db, dcode, dpos, 8u, 5)
-    DT_CAND(se, db, dcode, dpos, 2u, 7)
+    DT_CAND(n, cb, ccode, 64u)
+    DT_CAND(w, cb, ccode, 16u)
+    DT_CAND(e, cb, ccode, 1u)
+    DT_CAND(s, cb, ccode, 4u)
+    DT_CAND(nw, db, dcode, 32u)
+    DT_CAND(ne, db, dcode, 128u)
+    DT_CAND(sw, db, dcode, 8u)
+    DT_CAND(se, db, dcode, 2u)
 #undef DT_CAND
   } else {
-#define DT_DIFF(nb) ((nb) != DT_NODATA ? c - (nb) : 0.0f)
-    cb = fmaxf(fmaxf(fmaxf(DT_DIFF(n), DT_DIFF(w)), fmaxf(DT_DIFF(e), DT_DIFF(s))), 0.0f);
-    db = fmaxf(fmaxf(fmaxf(DT_DIFF(nw), DT_DIFF(ne)), fmaxf(DT_DIFF(sw), DT_DIFF(se))), 0.0f);
-#undef DT_DIFF
+    cb = fmaxf(fmaxf(fmaxf(c - n, c - w), fmaxf(c - e, c - s)), 0.0f);
+    db = fmaxf(fmaxf(fmaxf(c - nw, c - ne), fmaxf(c - sw, c - se)), 0.0f);
   }
   // Exact float64 divisions are ~15 instructions each.  Fast path: multiply by the (correctly rounded)
   // reciprocals -- within 3 float64 ulp of the reference's quotient -- and accept the result only if
-  // neither the cardinal / diagonal comparison nor the final float32 rounding can be affected by
-  // those ulps (checked below); otherwise divide.  Results are bit-identical either way.
+  // neither the cardinal / diagonal comparison nor (when the slope is wanted) the final float32 rounding
+  // can be affected by those ulps; otherwise divide.  Results are bit-identical either way.
   double vc = (double)cb * inv_card, vd = (double)db * inv_diag;
   const double EPS = 8.9e-16;  // 4 ulp, relative
   double vmax = vc > vd ? vc : vd;
   bool ambiguous = (vc != vd) && fabs(vc - vd) <= EPS * vmax;
-  float f_lo = (float)(vmax * (100.0 * (1.0 - EPS))), f_hi = (float)(vmax * (100.0 * (1.0 + EPS)));
-  ambiguous = ambiguous || (f_lo != f_hi);
+  if (NEED_SLOPE) {
+    float f_lo = (float)(vmax * (100.0 * (1.0 - EPS))), f_hi = (float)(vmax * (100.0 * (1.0 + EPS)));
+    ambiguous = ambiguous || (f_lo != f_hi);
+  }
   if (ambiguous) {
     vc = cb > 0.0f ? (double)cb / dcard : 0.0;
     vd = db > 0.0f ? (double)db / ddiag : 0.0;
   }
   double v;
   uint32_t code;
-  if (vc > vd || (vc == vd && cpos < dpos)) {
+  // equal quotients: the candidate met first in scan order wins (positions looked up only then)
+  if (vc > vd || (vc == vd && dt_scan_pos(ccode) < dt_scan_pos(dcode))) {
     v = vc;
     code = ccode;
   } else {
@@ -267,6 +276,7 @@ __global__ __launch_bounds__(256) void k_stencil(const float *__restrict__ dem, 
   // cells outside the core but inside the global raster come from the halo of the window ----
   const int ylo = -(w.gy0 > 0 ? 1 : 0), yhi = H + (w.gy0 + H < w.Hg ? 1 : 0);  // readable rows [ylo, yhi)
   const int xlo = -(w.gx0 > 0 ? 1 : 0), xhi = W + (w.gx0 + W < w.Wg ? 1 : 0);
+  const float pinf = __builtin_inff();
   for (int i = threadIdx.x; i < (SD_TY + 2) * (SD_TX / 4); i += 256) {
     int r = i / (SD_TX / 4), c4 = i - r * (SD_TX / 4);
     int gy = y0 - 1 + r, gx = x0 + c4 * 4;
@@ -282,6 +292,11 @@ __global__ __launch_bounds__(256) void k_stencil(const float *__restrict__ dem, 
         if (gx + 3 < xhi) v.w = p[3];
       }
     }
+    // nodata (and everything outside the raster) as +inf: see dt_slope_cell
+    v.x = v.x == DT_NODATA ? pinf : v.x;
+    v.y = v.y == DT_NODATA ? pinf : v.y;
+    v.z = v.z == DT_NODATA ? pinf : v.z;
+    v.w = v.w == DT_NODATA ? pinf : v.w;
     *reinterpret_cast<float4 *>(&t[r * SD_LDW + 4 + c4 * 4]) = v;
   }
   for (int i = threadIdx.x; i < (SD_TY + 2) * 2; i += 256) {
@@ -289,7 +304,7 @@ __global__ __launch_bounds__(256) void k_stencil(const float *__restrict__ dem, 
     int gy = y0 - 1 + r, gx = side ? x0 + SD_TX : x0 - 1;
     float v = DT_NODATA;
     if (gy >= ylo && gy < yhi && gx >= xlo && gx < xhi) v = dem[(long long)gy * w.ld + gx];
-    t[r * SD_LDW + (side ? 4 + SD_TX : 3)] = v;
+    t[r * SD_LDW + (side ? 4 + SD_TX : 3)] = v == DT_NODATA ? pinf : v;
   }
   __syncthreads();
 
@@ -345,14 +360,16 @@ __global__ __launch_bounds__(256) void k_stencil(const float *__restrict__ dem, 
       uint32_t codes = 0;
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        SlopeCell sc = dt_slope_cell<W_FDR>(bb[k + 1], a[k], a[k + 1], a[k + 2], bb[k], bb[k + 2], cc[k],
-                                     cc[k + 1], cc[k + 2], inv_card, inv_diag, dcard, ddiag);
+        const float cz = bb[k + 1] == pinf ? DT_NODATA : bb[k + 1];  // the centre's own value
+        SlopeCell sc = dt_slope_cell<W_FDR, (W_SLOPE || W_RAD || W_TWI)>(cz, a[k], a[k + 1], a[k + 2], bb[k],
+                                                                       bb[k + 2], cc[k], cc[k + 1], cc[k + 2],
+                                                                       inv_card, inv_diag, dcard, ddiag);
         so[k] = sc.slope;
         uint32_t code = sc.code;
         if (W_FDR) {
           // N1 border rule: a border cell with no lower neighbour drains out of the raster
           int gyy = w.gy0 + gy, gxx = w.gx0 + gx + k;  // global position
-          if (code == 0u && bb[k + 1] > DT_NODATA) {
+          if (code == 0u && cz > DT_NODATA) {
             if (gyy == w.Hg - 1) code = 4u;
             else if (gyy == 0) code = 64u;
             else if (gxx == 0) code = 16u;
@@ -360,7 +377,7 @@ __global__ __launch_bounds__(256) void k_stencil(const float *__restrict__ dem, 
           }
           codes |= code << (8 * k);
         }
-        if (W_RAD || W_TWI) ro[k] = dt_slope_rad(sc.slope, bb[k + 1]);
+        if (W_RAD || W_TWI) ro[k] = dt_slope_rad(sc.slope, cz);
         if (W_TWI) {
           int32_t f32v = k == 0 ? facv[j].x : (k == 1 ? facv[j].y : (k == 2 ? facv[j].z : facv[j].w));
           dt_twi_cell((int64_t)f32v, ro[k], lnpx2, n_top, tio[k], mtio[k], s_tab);
