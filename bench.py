@@ -29,8 +29,13 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 ach
 # op -> (algorithmic bytes per cell).  "d8" writes fdr only (slope comes out of the
 # fused slope+TWI stencil: dem 4 + fac 4 read, slope 4 + TI 4 + MTI 4 written = the north_star's
 # 20 B/cell; the slope-in-radians raster is an optional extra output that the chain does not need).
-# algorithmic bytes per cell (unfused definitions): HAND 18 + GFI 12 + ln(hl/H) 12 for the fused op
-OPS = [("d8", 5), ("downslope", 9), ("flowacc_river", 5 + 1), ("flowhand_gfi", 18 + 12 + 12), ("slope_twi", 20)]
+# Algorithmic (compulsory) bytes per cell of each op as it is fused here (SURVEY.md 8d lists the unfused
+# definitions, which add up to the chain's 90 B): HAND + GFI + ln(hl/H) in one go reads fdr 1 + river 1 (pass 1)
+# and dem 4 + fac 4 (last pass) and writes fdist, idx, hand, gfi, lnhlh (20).  The op is timed as its two
+# phases -- the windowed entry points with the whole raster as the window, the same kernels as
+# dt_dev_flowhand_gfi -- so that its last pass, one kernel, has a duration of its own.
+OPS = [("d8", 5), ("downslope", 9), ("flowacc_river", 5 + 1), ("flowhand_local", 2), ("flowhand_gfi_finish", 28),
+       ("slope_twi", 20)]
 
 
 # kernels behind each op (names as rocprofv3 prints them) -- used to attach the PMC-measured HBM
@@ -39,11 +44,12 @@ OP_KERNELS = {
     "d8": ["k_stencil<false, true, false, false>"],
     "flowacc_river": ["k_fa_tile1", "k_fa_link", "k_fa_reduce", "k_fa_poison", "k_fa_tile3<true, true>",
                       "__amd_rocclr_fillBufferAligned"],
-    "flowhand_gfi": ["k_fh_tile1n", "k_fh_tile1", "k_fh_ghost_init", "k_fh_node_jump", "k_fh_tile3"],
+    "flowhand_local": ["k_fh_tile1n", "k_fh_tile1", "k_fh_ghost_init", "k_fh_node_jump", "k_fh_rank_summary"],
+    "flowhand_gfi_finish": ["k_fh_tile3"],
     "slope_twi": ["k_stencil<true, false, false, true>"],
     "downslope": ["k_downslope_win"],
 }
-PMC_FILE = os.path.join(ROOT, "profiles", "r1", "v7_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r1", "v8_pmc_traffic.json")
 
 
 def pmc_traffic(op, size):
@@ -146,6 +152,13 @@ def main():
     c, c2 = ctx.h, ctx2.h
     N = H * W
 
+    # HAND as its two phases: the window is the whole raster; the ring summary of phase 1 (for other ranks) is
+    # written and ignored
+    import ctypes as C
+    full = _lib.Window(H, W, W, 0, 0, H, W, 0)
+    P = int(L.dt_perim_cells(H, W))
+    ring = [torch.empty(max(P, 1), dtype=dt_, device=dev) for dt_ in (torch.uint8, torch.int32, torch.int32,
+                                                                        torch.int32, torch.float32, torch.int32)]
     # the ops of chain.Chain.run, in its order and on its stream(s): (name, stream, call); without --overlap
     # ctx2 is ctx and downslope simply runs after D8
     def op_calls():
@@ -155,10 +168,11 @@ def main():
                                                               p("down"))),
             ("flowacc_river", stream, lambda: L.dt_dev_flowacc_river(c, p("fdr"), dem.data_ptr(), H, W,
                                                                      ch.river_threshold, p("fac"), p("river"))),
-            ("flowhand_gfi", stream, lambda: L.dt_dev_flowhand_gfi(c, dem.data_ptr(), p("fdr"), p("river"),
-                                                                   p("fac"), H, W, ch.px, ch.n_gfi, ch.b,
-                                                                   p("fdist"), p("idx"), p("hand"), None,
-                                                                   p("gfi"), p("lnhlh"))),
+            ("flowhand_local", stream, lambda: L.dt_dev_flowhand_local_w(
+                c, C.byref(full), dem.data_ptr(), p("fdr"), p("river"), p("fac"), *[t.data_ptr() for t in ring])),
+            ("flowhand_gfi_finish", stream, lambda: L.dt_dev_flowhand_gfi_finish_w(
+                c, C.byref(full), dem.data_ptr(), p("fdr"), p("river"), p("fac"), ch.px, ch.n_gfi, ch.b, None, None,
+                None, None, None, None, p("fdist"), p("idx"), None, p("hand"), None, p("gfi"), p("lnhlh"))),
             ("slope_twi", stream, lambda: L.dt_dev_slope_twi(c, dem.data_ptr(), p("fac"), H, W, ch.px, ch.n_top,
                                                              p("slope"), None, p("ti"), p("mti"))),
         ]
@@ -209,8 +223,8 @@ def main():
         tr = pmc_traffic(name, S)
         per_op[name]["traffic_bytes"] = None if tr is None else int(tr)
         per_op[name]["kernels"] = [k for k in OP_KERNELS[name] if not k.startswith("__amd")]
-    # the dominant KERNEL: ops that are one kernel are timed exactly by their events; the multi-kernel ops
-    # (flow accumulation, HAND) are passes of <= 1.9 ms each (profiles/), shorter than the downslope kernel
+    # the dominant KERNEL: ops that are one kernel are timed exactly by their events; the kernels of the
+    # multi-kernel ops (flow accumulation, HAND's first phase) are <= 1.4 ms each (profiles/)
     single = [k for k in per_op if len(per_op[k]["kernels"]) == 1]
     dom = max(single, key=lambda k: per_op[k]["ms"])
     roof = {"kernel": per_op[dom]["kernels"][0], "op": dom, "bound": "hbm",
@@ -219,7 +233,7 @@ def main():
             "note": "dominant single kernel; achieved = algorithmic bytes/cell x cells / mean kernel time (HIP "
                     "events on the launch stream, timed region); traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
                     "from separate rocprofv3 --pmc runs committed under profiles/; per_op lists every op "
-                    "(flowacc_river and flowhand_gfi are multi-kernel ops: their frac is of the op as a whole)"
+                    "(flowacc_river and flowhand_local are multi-kernel ops: their frac is of the op as a whole)"
                     + (".  --overlap: downslope runs on a second stream beside flow accumulation / HAND, so the "
                        "per-op times overlap and add up to more than ms_per_step" if args.overlap else "")}
 
