@@ -421,7 +421,7 @@ extern "C" int dt_dev_minmax_scale_f32(dt_ctx *c, const float *x, int64_t N, flo
 
 extern "C" int dt_dev_membench_copy(dt_ctx *c, const float *a, float *b, int64_t N, int blocks) {
   DT_CTX(c);
-  DT_REQUIRE(a && b && N >= 0 && blocks > 0, "bad arguments");
+  DT_REQUIRE(a && b && N >= 0 && blocks != 0, "bad arguments");
   DT_TRY(dt_launch_membench_copy(c->stream, a, b, N, blocks));
   DT_HIP(hipGetLastError());
   return DT_OK;

@@ -232,8 +232,10 @@ int dt_dev_unique_extremes_f32(dt_ctx *ctx, const float *x, int64_t N, float *ou
 int dt_dev_minmax_scale_f32(dt_ctx *ctx, const float *x, int64_t N, float mn, float mx, float nodata,
                             double *desc);
 
-/* float4 grid-stride copy of N floats with `blocks` workgroups: the practical HBM ceiling on this device,
- * reported by tools/stencil_bench.py next to the kernels' rates */
+/* Device-to-device copy of N floats, the practical HBM ceiling the roofline fractions are put beside:
+ * blocks > 0: float4 grid-stride copy with that many workgroups; blocks < 0: the buffer walked as rows of 16384
+ * floats in 1024 x 4 patches, one per workgroup (N a multiple of 65536) -- the faster of the two forms on
+ * MI355X (6.1 vs 5.4 TB/s), bench.py reports the better one */
 int dt_dev_membench_copy(dt_ctx *ctx, const float *a, float *b, int64_t N, int blocks);
 
 /* Rank-level solves on the GPU (multi-GPU): `rows_dev` holds one all-gathered byte row per rank
