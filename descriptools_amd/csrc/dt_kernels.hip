@@ -245,7 +245,7 @@ __device__ __forceinline__ float dt_slope_rad(float slope_pct, float dem) {
 }
 
 template <bool W_SLOPE, bool W_FDR, bool W_RAD, bool W_TWI>
-__global__ __launch_bounds__(256) void k_stencil(const float *__restrict__ dem, DtWin w,
+__global__ __launch_bounds__(256, 6) void k_stencil(const float *__restrict__ dem, DtWin w,
                                                 double px, float *__restrict__ slope,
                                                 uint8_t *__restrict__ fdr,
                                                 float *__restrict__ slope_rad,
