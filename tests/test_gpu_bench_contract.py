@@ -1,0 +1,44 @@
+"""GPU (-m gpu): bench.py's one-line JSON contract at a small size -- the keys the driver reads, the roofline
+and cpu_baseline objects, and the N = 1 run through the multi-rank path."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*extra):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--size", "2048", "--steps", "2",
+                          "--warmup", "1", *extra], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line on stdout"
+    return json.loads(lines[0])
+
+
+def test_bench_line_contract():
+    d = _run()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["unit"] == "Mcells/s" and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 2048 * 2048 / (d["ms_per_step"] * 1e-3) / 1e6) <= 0.01 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["kernel"].startswith("k_")
+    assert r["traffic"] is None  # the committed PMC summary is for 16384^2 only
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "Mcells/s" and c["value"] > 0 and c["sample"]
+    assert sum(v["ms"] for v in d["per_op"].values()) <= 1.2 * d["ms_per_step"] + 0.5
+
+
+def test_bench_tiled_path_at_one_rank():
+    d = _run("--tiled", "--no-cpu-baseline")
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["downslope_walks_beyond_halo"] == 0
+    assert "rank tiles" in d["config"]["parallelism"]
