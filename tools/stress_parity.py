@@ -1,5 +1,5 @@
 """Randomised differential test, GPU path vs oracle, over many shapes / seeds (not part of the pytest suites:
-minutes of oracle time).  Exits non-zero on the first mismatch.   python tools/stress_parity.py [cases] [seed0]"""
+minutes of oracle time).  Exits non-zero on the first mismatch.   python tools/stress_parity.py [cases] [seed0] [max_side]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -13,12 +13,15 @@ from descriptools_amd import chain, tiling
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+max_side = int(sys.argv[3]) if len(sys.argv) > 3 else 700
 codes = np.array([1, 2, 4, 8, 16, 32, 64, 128], np.uint8)
 bad = 0
 for k in range(cases):
     rng = np.random.default_rng(seed0 + k)
-    H, W = int(rng.integers(3, 700)), int(rng.integers(3, 700))
+    H, W = int(rng.integers(3, max_side)), int(rng.integers(3, max_side))
     mode = k % 4
+    if max_side > 1000:
+        mode = 0 if k % 2 == 0 else 3  # terrain only: the oracle's literal walks on adversarial fields take hours
     px = float(rng.choice([10.0, 12.5, 30.0, 1.0]))
     if mode == 0:      # synthetic terrain with nodata, the chain's own D8
         dem = oracle.synth_dem(seed0 + k, 4096, 4096, int(rng.integers(0, 3000)), int(rng.integers(0, 3000)), H, W, int(rng.integers(0, 6)))
@@ -59,7 +62,7 @@ for k in range(cases):
     ds = downslope.downsloper(dem, fdr, px, dz)
     if not np.array_equal(ds, ds_o, equal_nan=True):
         print("MISMATCH downslope", k, H, W, mode, dz, int((ds != ds_o).sum())); bad += 1
-    if k % 10 == 0:
+    if k % 10 == 0 or max_side > 1000:
         print("case", k, H, W, "mode", mode, "ok" if bad == 0 else "BAD %d" % bad, flush=True)
 print("cases", cases, "mismatching ops", bad)
 sys.exit(1 if bad else 0)
