@@ -593,13 +593,13 @@ __global__ __launch_bounds__(256, 6) void k_fa_tile3(const uint8_t *__restrict__
 }
 
 // ---- rank level (multi-GPU) ------------------------------------------------------------------------
-// jump[n]: the exit node the path entering the core at perimeter node n leaves its tile through,
-// followed across tiles until it reaches a rank exit (bit 31 set: terminal) or ends (FA_NONE).
+// nxt[n]: the entry node that follows perimeter node n on its path through the rank -- the node its tile's
+// exit steps onto -- or that exit itself when it leaves the rank (bit 31: terminal), or FA_NONE (path ends).
 #define J_TERM 0x80000000u
-__global__ __launch_bounds__(256) void k_fa_jump_init(const unsigned long long *__restrict__ rec,
-                                                     int64_t nnodes, const uint32_t *__restrict__ entry_of,
-                                                     const unsigned long long *__restrict__ state,
-                                                     uint32_t *__restrict__ jump, uint32_t *__restrict__ nxt) {
+__global__ __launch_bounds__(256) void k_fa_nxt_init(const unsigned long long *__restrict__ rec, int64_t nnodes,
+                                                    const uint32_t *__restrict__ entry_of,
+                                                    const unsigned long long *__restrict__ state,
+                                                    uint32_t *__restrict__ nxt) {
   int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (n >= nnodes) return;
   uint32_t xs = REC_XSLOT(rec[n]);
@@ -611,36 +611,20 @@ __global__ __launch_bounds__(256) void k_fa_jump_init(const unsigned long long *
     if (rec[q] & REC_RANK_EXIT) j = q | J_TERM;
     else if ((state[q] >> FA2_SH) == 0ull) j = entry_of[q];
   }
-  jump[n] = j;
-  nxt[n] = j;  // the un-doubled successor: k_fa_propagate walks it
-}
-__global__ __launch_bounds__(256) void k_fa_jump(uint32_t *__restrict__ jump, int64_t nnodes,
-                                                 int *__restrict__ flags, int round) {
-  // flags[r] != 0: after round r some list is still open; rounds after the first quiet one return at once
-  if (round > 0 && flags[round - 1] == 0) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) flags[round] = 0;
-    return;
-  }
-  bool pending = false;
-  for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < nnodes; n += (int64_t)gridDim.x * 256) {
-    uint32_t j = __hip_atomic_load(&jump[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (j == FA_NONE || (j & J_TERM)) continue;
-    uint32_t t = __hip_atomic_load(&jump[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&jump[n], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    pending = pending || !(t == FA_NONE || (t & J_TERM));
-  }
-  if (__any(pending) && (threadIdx.x & 63) == 0) flags[round] = 1;
+  nxt[n] = j;
 }
 
 // one row per cell of the core ring: A = cells of this rank draining out through the cell (0 unless
 // it is a rank exit), code = its D8 code if rank exit, xr = ring index of the rank exit reached by a
-// path ENTERING the rank at this cell (-1: ends inside; -2: unresolved, i.e. a cycle inside the rank)
+// path ENTERING the rank at this cell (-1: ends inside), found by walking the successor list: 65 k lanes,
+// each at most as many hops as its path crosses tiles (a pointer doubling over all 16.6 M perimeter nodes
+// costs more than these few latency chains)
 __global__ __launch_bounds__(256) void k_fa_rank_summary(DtWin w, int tiles_x,
                                                         const unsigned long long *__restrict__ rec,
                                                         const unsigned long long *__restrict__ state,
-                                                        const uint32_t *__restrict__ jump, int64_t P,
-                                                        int64_t *__restrict__ A, int32_t *__restrict__ xr,
-                                                        uint8_t *__restrict__ code) {
+                                                        const uint32_t *__restrict__ nxt, int64_t nnodes,
+                                                        int64_t P, int64_t *__restrict__ A,
+                                                        int32_t *__restrict__ xr, uint8_t *__restrict__ code) {
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= P) return;
   int y, x;
@@ -650,18 +634,18 @@ __global__ __launch_bounds__(256) void k_fa_rank_summary(DtWin w, int tiles_x,
   bool rex = (r & REC_RANK_EXIT) != 0ull;
   A[i] = rex ? (int64_t)(REC_W(r) + (state[n] & FA2_MASK)) : 0;
   code[i] = rex ? (uint8_t)REC_CODE(r) : 0;
-  uint32_t j = jump[n];
+  uint32_t j = nxt[n];
   int32_t out = -1;
-  if (j != FA_NONE) {
+  for (int64_t it = 0; it < nnodes && j != FA_NONE; it++) {
     if (j & J_TERM) {
       uint32_t q = j & ~J_TERM;
       int tile = (int)(q / PS), slot = (int)(q - (uint32_t)tile * PS);
       int ly, lx;
       dt_cell_of_slot(slot, ly, lx);
       out = (int32_t)dt_perim_index(w.H, w.W, (tile / tiles_x) * TH + ly, (tile % tiles_x) * TW + lx);
-    } else {
-      out = -2;
+      break;
     }
+    j = nxt[j];
   }
   xr[i] = out;
 }
@@ -692,7 +676,7 @@ __global__ __launch_bounds__(256) void k_fa_propagate(DtWin w, int tiles_x, int6
 
 struct FaScratch {
   unsigned long long *rec, *state, *ext;
-  uint32_t *entry_of, *parent, *jump, *nxt;
+  uint32_t *entry_of, *parent, *nxt;
   uint16_t *loc16;  // pass 1's in-tile counts, tile-major
   int64_t nnodes, ntiles;
   int tiles_x;
@@ -709,20 +693,18 @@ static FaScratch fa_layout(const DtWin &w, void *scratch) {
   f.ext = (unsigned long long *)p;  p += n8;
   f.entry_of = (uint32_t *)p;  p += n4;
   f.parent = (uint32_t *)p;  p += n4;
-  f.jump = (uint32_t *)p;  p += n4;
   f.nxt = (uint32_t *)p;  p += n4;
-  p += 256;  // round flags of the jump kernels
   f.loc16 = (uint16_t *)p;
   return f;
 }
 size_t dt_flowacc_tiled_scratch(int64_t H, int64_t W) {
   int64_t ntiles = ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
   size_t nn = (size_t)ntiles * PS;
-  return dt_align256(nn * 8) * 3 + dt_align256(nn * 4) * 4 + 256 + dt_align256((size_t)ntiles * NT * 2);
+  return dt_align256(nn * 8) * 3 + dt_align256(nn * 4) * 3 + 256 + dt_align256((size_t)ntiles * NT * 2);
 }
 
-// phase 1: tile pass + local perimeter graph.  With `rank_level` the rank-exit jumps are resolved too
-// (needed for dt_launch_fa_summary).
+// phase 1: tile pass + local perimeter graph.  With `rank_level` the entry successor lists are built too
+// (needed for dt_launch_fa_summary and the inflow of dt_launch_fa_finish).
 int dt_launch_fa_local(hipStream_t s, const DtWin &w, const uint8_t *fdr, void *scratch, size_t scratch_bytes,
                        int32_t *acc32, int rank_level) {
   if (w.H == 0 || w.W == 0) return DT_OK;
@@ -737,13 +719,7 @@ int dt_launch_fa_local(hipStream_t s, const DtWin &w, const uint8_t *fdr, void *
   hipLaunchKernelGGL(k_fa_link, gn, b, 0, s, f.rec, f.nnodes, f.tiles_x, f.entry_of, f.parent, f.state);
   hipLaunchKernelGGL(k_fa_reduce, gn, b, 0, s, f.rec, f.nnodes, f.entry_of, f.parent, f.state, f.ext);
   if (rank_level) {
-    hipLaunchKernelGGL(k_fa_jump_init, gn, b, 0, s, f.rec, f.nnodes, f.entry_of, f.state, f.jump, f.nxt);
-    // a path crosses each tile perimeter node at most once; 2^24 tile crossings inside one rank
-    // would need a path longer than any raster this library accepts per device
-    int *flags = (int *)((char *)f.nxt + dt_align256((size_t)f.nnodes * 4));  // the layout's spare 256 bytes
-    DT_HIP(hipMemsetAsync(flags, 0, 128, s));
-    dim3 gj(gn.x < 4096u ? gn.x : 4096u);
-    for (int r = 0; r < 24; r++) hipLaunchKernelGGL(k_fa_jump, gj, b, 0, s, f.jump, f.nnodes, flags, r);
+    hipLaunchKernelGGL(k_fa_nxt_init, gn, b, 0, s, f.rec, f.nnodes, f.entry_of, f.state, f.nxt);
   }
   return DT_OK;
 }
@@ -754,7 +730,7 @@ int dt_launch_fa_summary(hipStream_t s, const DtWin &w, void *scratch, int64_t *
   if (P == 0) return DT_OK;
   FaScratch f = fa_layout(w, scratch);
   hipLaunchKernelGGL(k_fa_rank_summary, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, w, f.tiles_x,
-                     f.rec, f.state, f.jump, P, A, xr, code);
+                     f.rec, f.state, f.nxt, f.nnodes, P, A, xr, code);
   return DT_OK;
 }
 
@@ -1309,6 +1285,17 @@ __global__ __launch_bounds__(256, 6) void k_fh_tile3(const uint8_t *__restrict__
       unsigned long long ns = nodes[node];
       uint32_t nptr = (uint32_t)(ns >> 32), nnd = (uint32_t)((ns >> 16) & 0xFFFFu);
       uint32_t nncf = (uint32_t)(ns & 0xFFFFu);
+      if (!(nncf & FHT_DONE) && nptr >= nnodes && (size_t)nptr != node) {
+        // parked on the ghost of a rank exit (the local doubling left it pointing straight at it): one more
+        // hop picks up what the rank-level solve wrote there
+        unsigned long long gs = nodes[nptr];
+        uint32_t gncf = (uint32_t)(gs & 0xFFFFu);
+        nnd += (uint32_t)((gs >> 16) & 0xFFFFu);
+        nncf += gncf & 0x7FFFu;
+        nptr = (uint32_t)(gs >> 32);
+        if ((gncf & FHT_DONE) && nptr != FHT_DEAD && (nncf & 0x7FFFu) + nnd <= FHT_CAP) nncf |= FHT_DONE;
+        else nptr = FHT_DEAD;
+      }
       bool diag = dy != 0 && dx != 0;
       // not done after all rounds == longer than the cap (or an unresolved rank exit)
       if ((nncf & FHT_DONE) && nptr != FHT_DEAD) {
@@ -1539,10 +1526,7 @@ int dt_launch_fh_finish(hipStream_t s, const DtWin &w, const float *dem, const u
   if (res_ok) {
     hipLaunchKernelGGL(k_fh_ghost_set, dim3((unsigned)((f.P + 255) / 256)), b, 0, s, f.nodes, (uint32_t)f.nnodes,
                        f.P, res_ok, res_nc, res_nd);
-    // nodes parked on a ghost pick up its result (they point at it directly: one hop; two for safety)
-    dim3 gj(gn.x < 4096u ? gn.x : 4096u);
-    for (int r = 0; r < 2; r++)
-      hipLaunchKernelGGL(k_fh_node_jump, gj, b, 0, s, f.nodes, f.nnodes + f.P, (int *)nullptr, r);
+    // nodes parked on a ghost point at it directly: pass 3 takes that one hop itself
   }
   FhRemote rem{rem_gidx, rem_zr, rem_ar};
   FhGfi G{nullptr, nullptr, 0.0, 0.0, nullptr};
