@@ -131,18 +131,16 @@ void *dt_scratch_take(dt_ctx *c, size_t bytes) {
   DT_HIP(hipSetDevice((c)->device))
 
 // DT_FLOW_IMPL=v1 selects the first-generation global kernels for flow accumulation / HAND
-// DT_FLOW_IMPL=kahn: tile-hierarchical with the in-LDS countdown for flow-accumulation pass 1
 static int g_flow_impl = -1;
 int dt_flow_impl() {
   if (g_flow_impl < 0) {
     const char *e = getenv("DT_FLOW_IMPL");
-    g_flow_impl = (e && strcmp(e, "v1") == 0) ? 1 : ((e && strcmp(e, "kahn") == 0) ? 3 : 2);
+    g_flow_impl = (e && strcmp(e, "v1") == 0) ? 1 : 2;
   }
   return g_flow_impl;
 }
 extern "C" int dt_set_flow_impl(int impl) {
-  DT_REQUIRE(impl >= 1 && impl <= 3,
-             "impl must be 1 (global kernels), 2 (tile-hierarchical) or 3 (2 with the LDS countdown in pass 1)");
+  DT_REQUIRE(impl == 1 || impl == 2, "impl must be 1 (global kernels) or 2 (tile-hierarchical)");
   g_flow_impl = impl;
   return DT_OK;
 }

@@ -71,4 +71,4 @@ int dt_launch_rank_solve_flowhand(hipStream_t s, int ty, int tx, const int64_t *
                                   int64_t P_rank, void *scratch, uint8_t *res_ok, int32_t *res_nc,
                                   int32_t *res_nd, long long *gidx, float *zr, int32_t *ar);
 
-int dt_flow_impl();  // 1 global kernels, 2 tile-hierarchical (default), 3 = 2 with the LDS countdown in FA pass 1
+int dt_flow_impl();  // 1 global kernels, 2 tile-hierarchical (default)

@@ -179,6 +179,10 @@ __device__ __forceinline__ void dt_tile_sums(uint32_t *s_pv, uint32_t *s_recv, u
   __syncthreads();
 }
 
+// countdown word of an exit node in the perimeter graph: pending feeders << 54 | sum of what arrived so far
+#define FA_NONE 0xFFFFFFFFu
+#define FA2_SH 54 /* pending count in bits 54-63: a tile exit has at most 260 feeders (the cells around the tile) */
+#define FA2_MASK ((1ull << FA2_SH) - 1ull)
 // perimeter record (8 bytes):  W:32 | xslot:16 | code:8 | flags:8
 //   code  = the cell's D8 code when its successor is in another tile or rank (an "exit" cell)
 //   flags = bit 0: rank exit (the successor is outside the core window)
@@ -197,7 +201,8 @@ __device__ __forceinline__ unsigned long long fa_rec(uint32_t W_, uint32_t xslot
 
 __global__ __launch_bounds__(256, 6) void k_fa_tile1(const uint8_t *__restrict__ fdr, DtWin w, int tiles_x,
                                                     unsigned long long *__restrict__ rec,
-                                                    uint16_t *__restrict__ loc16) {
+                                                    uint16_t *__restrict__ loc16,
+                                                    unsigned long long *__restrict__ state) {
   // 24 KiB of LDS: six tiles per CU.  The direction codes are staged through the receive array (free until
   // the rounds start), which is all zero again when the rounds end and then serves as the cycle mask.
   __shared__ __attribute__((aligned(16))) uint32_t s_pv[NT];  // val:16 | idx:12 | PT_EXIT | PT_ALIVE
@@ -222,6 +227,7 @@ __global__ __launch_bounds__(256, 6) void k_fa_tile1(const uint8_t *__restrict__
     }
   }
   uint32_t my_code = 0, my_flags = 0;  // D8 code of my perimeter cell when it is an exit cell
+  uint32_t feeders = 0;                // exits of neighbouring tiles (inside the core) that step onto my cell
   if (threadIdx.x < PS) {
     int ly, lx;
     dt_cell_of_slot(threadIdx.x, ly, lx);
@@ -229,9 +235,29 @@ __global__ __launch_bounds__(256, 6) void k_fa_tile1(const uint8_t *__restrict__
     uint32_t n = dt_tile_next(code, ly, lx, y0, x0, w);
     if (n == NX_EXIT || n == NX_REXIT) my_code = code;
     if (n == NX_REXIT) my_flags = (uint32_t)REC_RANK_EXIT;
+    // The in-degree of the perimeter graph, without the global atomics of a link pass: every exit that feeds
+    // this tile enters at a perimeter cell, from one of its <= 5 neighbours outside the tile.
+    const int y = y0 + ly, x = x0 + lx;
+    if (y < w.H && x < w.W) {
+#pragma unroll
+      for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+        for (int dx = -1; dx <= 1; dx++) {
+          int ny = ly + dy, nx = lx + dx;
+          if ((dy == 0 && dx == 0) || (ny >= 0 && ny < TH && nx >= 0 && nx < TW)) continue;  // inside my tile
+          if (!dt_in_core(w, y + dy, x + dx)) continue;  // other ranks' cells arrive as injected inflow
+          uint32_t c2 = fdr[(long long)(y + dy) * w.ld + x + dx];
+          if (dt_d8_valid(c2)) {
+            int ey, ex;
+            dt_d8_delta(c2, ey, ex);
+            feeders += (ey == -dy && ex == -dx) ? 1u : 0u;
+          }
+        }
+    }
   }
   __syncthreads();
   uint8_t *s_cyc = reinterpret_cast<uint8_t *>(s_recv);
+  uint32_t *s_pend = s_recv + NT / 4;  // 252 words above the cycle mask (the array is all zero after the rounds)
   for (int j = 0; j < CPT; j++) {
     int c = threadIdx.x + 256 * j;
     uint32_t n = nx[j];
@@ -254,7 +280,12 @@ __global__ __launch_bounds__(256, 6) void k_fa_tile1(const uint8_t *__restrict__
       xs = (uint32_t)dt_slot_of((int)f / TW, (int)f % TW);
     }
     rec[(size_t)tile * PS + threadIdx.x] = fa_rec(my_code ? (p >> 16) : 0u, xs, my_code, my_flags);
+    // what enters at my cell waits at the exit its in-tile path leads to
+    if (xs != X_NONE && feeders) atomicAdd(&s_pend[xs], feeders);
   }
+  __syncthreads();
+  if (threadIdx.x < PS)  // pending count of my exit (0 for the rest): k_fa_reduce's countdown word
+    state[(size_t)tile * PS + threadIdx.x] = (unsigned long long)s_pend[threadIdx.x] << FA2_SH;
   // in-tile accumulation (upstream cells of this tile only, <= 4095: 2 bytes per cell, tile-major; 0xFFFF =
   // on an in-tile cycle); pass 3 adds what enters from outside
   // (4 cells per lane: one 16-byte LDS read, one 4-byte mask read, one 8-byte store)
@@ -271,131 +302,15 @@ __global__ __launch_bounds__(256, 6) void k_fa_tile1(const uint8_t *__restrict__
   }
 }
 
-// ---- pass 1 as an in-degree countdown inside LDS (alternative to the doubling, dt_set_flow_impl(3)) ----
-// One 32-bit LDS word per cell: sum:13 | nxt:13 | pending:4.  A lane that owns a source cell (nothing flows
-// into it) carries its running sum downstream: ONE returning LDS atomic per move adds the sum, drops the
-// target's pending count and hands back the target's own sum and successor; the walker carries on only if it
-// was the last tributary to arrive.  Every cell is fired exactly once (~4096 LDS atomics per tile instead of
-// ~6 LDS instructions per cell per doubling round) but the work is a chain of LDS round trips as long as the
-// longest in-tile path: it lives on occupancy -- 16 KiB of LDS, eight tiles per CU.  Cells whose count never
-// reaches 0 are exactly the cells on in-tile D8 cycles.
-#define KW_TERM 0x1000u /* nxt13: bit 12 = no in-tile successor; bits 0-1 = kind */
-#define KW_SINK 0u
-#define KW_EXIT 1u
-#define KW_REXIT 2u
-#define K1_SUM 0x1FFFu
-#define K1_NXT_SH 13
-#define K1_CNT_SH 26
-__global__ __launch_bounds__(256, 8) void k_fa_tile1k(const uint8_t *__restrict__ fdr, DtWin w, int tiles_x,
-                                                     unsigned long long *__restrict__ rec,
-                                                     uint16_t *__restrict__ loc16) {
-  __shared__ __attribute__((aligned(16))) uint32_t s_w[NT];
-  uint8_t *s_fdr = reinterpret_cast<uint8_t *>(s_w);  // staged through the word array
-  const int tile = blockIdx.x;
-  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-  const int y0 = ty * TH, x0 = tx * TW;
-  dt_tile_load_fdr(fdr, w, y0, x0, s_fdr);
-  __syncthreads();
-  uint32_t nx[CPT];
-  if (dt_tile_interior(w, y0, x0)) {
-#pragma unroll
-    for (int j = 0; j < CPT; j++) {
-      int c = threadIdx.x + 256 * j;
-      nx[j] = dt_tile_next_interior(s_fdr[c], c / TW, c % TW);
-    }
-  } else {
-    for (int j = 0; j < CPT; j++) {
-      int c = threadIdx.x + 256 * j;
-      nx[j] = dt_tile_next(s_fdr[c], c / TW, c % TW, y0, x0, w);
-    }
-  }
-  uint32_t my_code = 0, my_flags = 0, my_cell = 0;  // D8 code of my perimeter cell when it is an exit cell
-  if (threadIdx.x < PS) {
-    int ly, lx;
-    dt_cell_of_slot(threadIdx.x, ly, lx);
-    my_cell = (uint32_t)(ly * TW + lx);
-    uint32_t code = s_fdr[my_cell];
-    uint32_t n = dt_tile_next(code, ly, lx, y0, x0, w);
-    if (n == NX_EXIT || n == NX_REXIT) my_code = code;
-    if (n == NX_REXIT) my_flags = (uint32_t)REC_RANK_EXIT;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < CPT; j++) {
-    uint32_t n = nx[j];
-    uint32_t n13 = n < NT ? n : (KW_TERM | (n == NX_EXIT ? KW_EXIT : (n == NX_REXIT ? KW_REXIT : KW_SINK)));
-    s_w[threadIdx.x + 256 * j] = 1u | (n13 << K1_NXT_SH);
-  }
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < CPT; j++)
-    if (nx[j] < NT) atomicAdd(&s_w[nx[j]], 1u << K1_CNT_SH);
-  __syncthreads();
-  uint32_t src = 0;  // my cells nothing flows into (decided before anything fires)
-#pragma unroll
-  for (int j = 0; j < CPT; j++)
-    if (nx[j] < NT && (s_w[threadIdx.x + 256 * j] >> K1_CNT_SH) == 0u) src |= 1u << j;
-  __syncthreads();
-  {
-    uint32_t t = NT, A = 0;
-    for (;;) {
-      if (t >= NT) {  // chain finished: start from my next source cell
-        if (src == 0u) break;
-        int j = __ffs(src) - 1;
-        src &= src - 1u;
-        t = (s_w[threadIdx.x + 256 * j] >> K1_NXT_SH) & 0x1FFFu;  // < NT by construction of src
-        A = 1u;
-      }
-      uint32_t old = atomicAdd(&s_w[t], A - (1u << K1_CNT_SH));
-      if ((old >> K1_CNT_SH) != 1u) {
-        t = NT;
-      } else {
-        A += old & K1_SUM;
-        t = (old >> K1_NXT_SH) & 0x1FFFu;
-      }
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < PS) {
-    // where does a path entering at my perimeter cell leave the tile?
-    uint32_t c = my_cell, xs = X_NONE;
-    for (int it = 0; it < NT; it++) {
-      uint32_t wd = s_w[c];
-      if ((wd >> K1_CNT_SH) != 0u) break;  // ran into an in-tile cycle
-      uint32_t n = (wd >> K1_NXT_SH) & 0x1FFFu;
-      if (n & KW_TERM) {
-        if ((n & 3u) != KW_SINK) xs = (uint32_t)dt_slot_of((int)c / TW, (int)c % TW);
-        break;
-      }
-      c = n;
-    }
-    rec[(size_t)tile * PS + threadIdx.x] = fa_rec(my_code ? (s_w[my_cell] & K1_SUM) : 0u, xs, my_code, my_flags);
-  }
-#pragma unroll
-  for (int u = 0; u < NT / 4 / 256; u++) {
-    int c = 4 * (threadIdx.x + 256 * u);
-    uint4 v = *reinterpret_cast<const uint4 *>(&s_w[c]);
-    uint32_t a = (v.x >> K1_CNT_SH) ? 0xFFFFu : ((v.x & K1_SUM) - 1u) & 0xFFFFu;
-    uint32_t b = (v.y >> K1_CNT_SH) ? 0xFFFFu : ((v.y & K1_SUM) - 1u) & 0xFFFFu;
-    uint32_t d = (v.z >> K1_CNT_SH) ? 0xFFFFu : ((v.z & K1_SUM) - 1u) & 0xFFFFu;
-    uint32_t e = (v.w >> K1_CNT_SH) ? 0xFFFFu : ((v.w & K1_SUM) - 1u) & 0xFFFFu;
-    *reinterpret_cast<uint2 *>(loc16 + (size_t)tile * NT + c) = make_uint2(a | (b << 16), d | (e << 16));
-  }
-}
-
 // perimeter graph: node id = tile * PS + slot.  For every in-core exit node find the entry node it
 // feeds (the neighbouring tile's perimeter cell its D8 step lands on) and the exit node that entry's
 // in-tile path leads to (its parent in the reduced forest).  Rank exits have neither.
-#define FA_NONE 0xFFFFFFFFu
-#define FA2_SH 54 /* pending count in bits 54-63: a tile exit has at most 260 feeders (the cells around the tile) */
-#define FA2_MASK ((1ull << FA2_SH) - 1ull)
 #define FA_CYCLE (1ull << 63) /* ext flag: this entry cell is fed by a cross-tile D8 cycle */
 #define FA_VALUE(e) ((e) & ~FA_CYCLE)
 
 __global__ __launch_bounds__(256) void k_fa_link(const unsigned long long *__restrict__ rec, int64_t nnodes,
                                                 int tiles_x, uint32_t *__restrict__ entry_of,
-                                                uint32_t *__restrict__ parent,
-                                                unsigned long long *__restrict__ state) {
+                                                uint32_t *__restrict__ parent) {
   int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (n >= nnodes) return;
   unsigned long long r = rec[n];
@@ -410,10 +325,7 @@ __global__ __launch_bounds__(256) void k_fa_link(const unsigned long long *__res
     int y = ty * TH + ly + dy, x = tx * TW + lx + dx;  // inside the core by construction
     ent = dt_node_of(y, x, tiles_x);
     uint32_t xs = REC_XSLOT(rec[ent]);
-    if (xs != X_NONE) {
-      par = (ent / PS) * PS + xs;
-      atomicAdd(&state[par], 1ull << FA2_SH);
-    }
+    if (xs != X_NONE) par = (ent / PS) * PS + xs;  // (its pending count was set by pass 1)
   }
   entry_of[n] = ent;
   parent[n] = par;
@@ -711,12 +623,11 @@ int dt_launch_fa_local(hipStream_t s, const DtWin &w, const uint8_t *fdr, void *
   DT_REQUIRE(scratch_bytes >= dt_flowacc_tiled_scratch(w.H, w.W), "scratch too small");
   FaScratch f = fa_layout(w, scratch);
   DT_REQUIRE(f.nnodes < 0x7FFFFFF0ll, "raster too large for one device tile");
-  DT_HIP(hipMemsetAsync(f.state, 0, dt_align256((size_t)f.nnodes * 8) * 2, s));
+  DT_HIP(hipMemsetAsync(f.ext, 0, dt_align256((size_t)f.nnodes * 8), s));  // (state is written by pass 1)
   dim3 gt((unsigned)f.ntiles), b(256), gn((unsigned)((f.nnodes + 255) / 256));
   (void)acc32;  // written by pass 3 only
-  if (dt_flow_impl() == 3) hipLaunchKernelGGL(k_fa_tile1k, gt, b, 0, s, fdr, w, f.tiles_x, f.rec, f.loc16);
-  else hipLaunchKernelGGL(k_fa_tile1, gt, b, 0, s, fdr, w, f.tiles_x, f.rec, f.loc16);
-  hipLaunchKernelGGL(k_fa_link, gn, b, 0, s, f.rec, f.nnodes, f.tiles_x, f.entry_of, f.parent, f.state);
+  hipLaunchKernelGGL(k_fa_tile1, gt, b, 0, s, fdr, w, f.tiles_x, f.rec, f.loc16, f.state);
+  hipLaunchKernelGGL(k_fa_link, gn, b, 0, s, f.rec, f.nnodes, f.tiles_x, f.entry_of, f.parent);
   hipLaunchKernelGGL(k_fa_reduce, gn, b, 0, s, f.rec, f.nnodes, f.entry_of, f.parent, f.state, f.ext);
   if (rank_level) {
     hipLaunchKernelGGL(k_fa_nxt_init, gn, b, 0, s, f.rec, f.nnodes, f.entry_of, f.state, f.nxt);
