@@ -42,8 +42,7 @@ OPS = [("d8", 5), ("downslope", 9), ("flowacc_river", 5 + 1), ("flowhand_local",
 # traffic (profiles/r1/v2_pmc_traffic.json, collected in separate --pmc runs of this script) to an op
 OP_KERNELS = {
     "d8": ["k_stencil<false, true, false, false>"],
-    "flowacc_river": ["k_fa_tile1", "k_fa_link", "k_fa_reduce", "k_fa_poison", "k_fa_tile3<true, true>",
-                      "__amd_rocclr_fillBufferAligned"],
+    "flowacc_river": ["k_fa_tile1", "k_fa_reduce", "k_fa_poison", "k_fa_tile3<true, true>"],
     "flowhand_local": ["k_fh_tile1n", "k_fh_tile1", "k_fh_ghost_init", "k_fh_node_jump", "k_fh_rank_summary"],
     "flowhand_gfi_finish": ["k_fh_tile3"],
     "slope_twi": ["k_stencil<true, false, false, true>"],

@@ -183,6 +183,8 @@ __device__ __forceinline__ void dt_tile_sums(uint32_t *s_pv, uint32_t *s_recv, u
 #define FA_NONE 0xFFFFFFFFu
 #define FA2_SH 54 /* pending count in bits 54-63: a tile exit has at most 260 feeders (the cells around the tile) */
 #define FA2_MASK ((1ull << FA2_SH) - 1ull)
+#define FA_CYCLE (1ull << 63) /* ext flag: this entry cell is fed by a cross-tile D8 cycle */
+#define FA_VALUE(e) ((e) & ~FA_CYCLE)
 // perimeter record (8 bytes):  W:32 | xslot:16 | code:8 | flags:8
 //   code  = the cell's D8 code when its successor is in another tile or rank (an "exit" cell)
 //   flags = bit 0: rank exit (the successor is outside the core window)
@@ -202,7 +204,10 @@ __device__ __forceinline__ unsigned long long fa_rec(uint32_t W_, uint32_t xslot
 __global__ __launch_bounds__(256, 6) void k_fa_tile1(const uint8_t *__restrict__ fdr, DtWin w, int tiles_x,
                                                     unsigned long long *__restrict__ rec,
                                                     uint16_t *__restrict__ loc16,
-                                                    unsigned long long *__restrict__ state) {
+                                                    unsigned long long *__restrict__ state,
+                                                    unsigned long long *__restrict__ ext,
+                                                    uint32_t *__restrict__ entry_of,
+                                                    uint32_t *__restrict__ parent) {
   // 24 KiB of LDS: six tiles per CU.  The direction codes are staged through the receive array (free until
   // the rounds start), which is all zero again when the rounds end and then serves as the cycle mask.
   __shared__ __attribute__((aligned(16))) uint32_t s_pv[NT];  // val:16 | idx:12 | PT_EXIT | PT_ALIVE
@@ -228,6 +233,7 @@ __global__ __launch_bounds__(256, 6) void k_fa_tile1(const uint8_t *__restrict__
   }
   uint32_t my_code = 0, my_flags = 0;  // D8 code of my perimeter cell when it is an exit cell
   uint32_t feeders = 0;                // exits of neighbouring tiles (inside the core) that step onto my cell
+  uint32_t fnode[5];                   // their node ids (a perimeter cell has <= 5 neighbours outside the tile)
   if (threadIdx.x < PS) {
     int ly, lx;
     dt_cell_of_slot(threadIdx.x, ly, lx);
@@ -235,10 +241,15 @@ __global__ __launch_bounds__(256, 6) void k_fa_tile1(const uint8_t *__restrict__
     uint32_t n = dt_tile_next(code, ly, lx, y0, x0, w);
     if (n == NX_EXIT || n == NX_REXIT) my_code = code;
     if (n == NX_REXIT) my_flags = (uint32_t)REC_RANK_EXIT;
-    // The in-degree of the perimeter graph, without the global atomics of a link pass: every exit that feeds
-    // this tile enters at a perimeter cell, from one of its <= 5 neighbours outside the tile.
+    // The links of the perimeter graph, without a link pass and its global atomics: every exit that feeds this
+    // tile enters at a perimeter cell, from one of its <= 5 neighbours outside the tile.  The tile that is
+    // ENTERED writes the feeder's entry and parent (each exit has one successor: no two writers) and counts
+    // its own exits' pending feeders in LDS.
     const int y = y0 + ly, x = x0 + lx;
+#pragma unroll
+    for (int k = 0; k < 5; k++) fnode[k] = FA_NONE;
     if (y < w.H && x < w.W) {
+      int k = 0;
 #pragma unroll
       for (int dy = -1; dy <= 1; dy++)
 #pragma unroll
@@ -250,7 +261,10 @@ __global__ __launch_bounds__(256, 6) void k_fa_tile1(const uint8_t *__restrict__
           if (dt_d8_valid(c2)) {
             int ey, ex;
             dt_d8_delta(c2, ey, ex);
-            feeders += (ey == -dy && ex == -dx) ? 1u : 0u;
+            if (ey == -dy && ex == -dx && k < 5) {
+              fnode[k++] = dt_node_of(y + dy, x + dx, tiles_x);
+              feeders++;
+            }
           }
         }
     }
@@ -282,10 +296,23 @@ __global__ __launch_bounds__(256, 6) void k_fa_tile1(const uint8_t *__restrict__
     rec[(size_t)tile * PS + threadIdx.x] = fa_rec(my_code ? (p >> 16) : 0u, xs, my_code, my_flags);
     // what enters at my cell waits at the exit its in-tile path leads to
     if (xs != X_NONE && feeders) atomicAdd(&s_pend[xs], feeders);
+    const uint32_t me = (uint32_t)tile * PS + threadIdx.x, par = xs != X_NONE ? (uint32_t)tile * PS + xs : FA_NONE;
+#pragma unroll
+    for (int k = 0; k < 5; k++)
+      if (fnode[k] != FA_NONE) {
+        entry_of[fnode[k]] = me;
+        parent[fnode[k]] = par;
+      }
+    if (my_flags & (uint32_t)REC_RANK_EXIT) {  // my exit leaves the rank: nobody else writes its links
+      entry_of[me] = FA_NONE;
+      parent[me] = FA_NONE;
+    }
   }
   __syncthreads();
-  if (threadIdx.x < PS)  // pending count of my exit (0 for the rest): k_fa_reduce's countdown word
+  if (threadIdx.x < PS) {  // pending count of my exit (0 for the rest): k_fa_reduce's countdown word
     state[(size_t)tile * PS + threadIdx.x] = (unsigned long long)s_pend[threadIdx.x] << FA2_SH;
+    ext[(size_t)tile * PS + threadIdx.x] = 0ull;  // inflow accumulator of my entry
+  }
   // in-tile accumulation (upstream cells of this tile only, <= 4095: 2 bytes per cell, tile-major; 0xFFFF =
   // on an in-tile cycle); pass 3 adds what enters from outside
   // (4 cells per lane: one 16-byte LDS read, one 4-byte mask read, one 8-byte store)
@@ -302,35 +329,9 @@ __global__ __launch_bounds__(256, 6) void k_fa_tile1(const uint8_t *__restrict__
   }
 }
 
-// perimeter graph: node id = tile * PS + slot.  For every in-core exit node find the entry node it
-// feeds (the neighbouring tile's perimeter cell its D8 step lands on) and the exit node that entry's
-// in-tile path leads to (its parent in the reduced forest).  Rank exits have neither.
-#define FA_CYCLE (1ull << 63) /* ext flag: this entry cell is fed by a cross-tile D8 cycle */
-#define FA_VALUE(e) ((e) & ~FA_CYCLE)
-
-__global__ __launch_bounds__(256) void k_fa_link(const unsigned long long *__restrict__ rec, int64_t nnodes,
-                                                int tiles_x, uint32_t *__restrict__ entry_of,
-                                                uint32_t *__restrict__ parent) {
-  int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (n >= nnodes) return;
-  unsigned long long r = rec[n];
-  uint32_t code = REC_CODE(r);
-  uint32_t ent = FA_NONE, par = FA_NONE;
-  if (code && !(r & REC_RANK_EXIT)) {
-    int tile = (int)(n / PS), slot = (int)(n - (int64_t)tile * PS);
-    int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    int ly, lx, dy, dx;
-    dt_cell_of_slot(slot, ly, lx);
-    dt_d8_delta(code, dy, dx);
-    int y = ty * TH + ly + dy, x = tx * TW + lx + dx;  // inside the core by construction
-    ent = dt_node_of(y, x, tiles_x);
-    uint32_t xs = REC_XSLOT(rec[ent]);
-    if (xs != X_NONE) par = (ent / PS) * PS + xs;  // (its pending count was set by pass 1)
-  }
-  entry_of[n] = ent;
-  parent[n] = par;
-}
-
+// perimeter graph: node id = tile * PS + slot.  entry_of[q] = the entry node exit q feeds (the neighbouring
+// tile's perimeter cell its D8 step lands on), parent[q] = the exit node that entry's in-tile path leads to;
+// rank exits have neither.  Both are written by pass 1 of the tile that is entered.
 // countdown over the reduced forest; A(q) = W(q) + sum of A over the exit nodes feeding
 // q's tile through entry cells whose in-tile path leads to q.  ext[entry] accumulates the inflow
 // arriving at an entry cell from other tiles.
@@ -623,11 +624,10 @@ int dt_launch_fa_local(hipStream_t s, const DtWin &w, const uint8_t *fdr, void *
   DT_REQUIRE(scratch_bytes >= dt_flowacc_tiled_scratch(w.H, w.W), "scratch too small");
   FaScratch f = fa_layout(w, scratch);
   DT_REQUIRE(f.nnodes < 0x7FFFFFF0ll, "raster too large for one device tile");
-  DT_HIP(hipMemsetAsync(f.ext, 0, dt_align256((size_t)f.nnodes * 8), s));  // (state is written by pass 1)
   dim3 gt((unsigned)f.ntiles), b(256), gn((unsigned)((f.nnodes + 255) / 256));
   (void)acc32;  // written by pass 3 only
-  hipLaunchKernelGGL(k_fa_tile1, gt, b, 0, s, fdr, w, f.tiles_x, f.rec, f.loc16, f.state);
-  hipLaunchKernelGGL(k_fa_link, gn, b, 0, s, f.rec, f.nnodes, f.tiles_x, f.entry_of, f.parent);
+  hipLaunchKernelGGL(k_fa_tile1, gt, b, 0, s, fdr, w, f.tiles_x, f.rec, f.loc16, f.state, f.ext, f.entry_of,
+                     f.parent);
   hipLaunchKernelGGL(k_fa_reduce, gn, b, 0, s, f.rec, f.nnodes, f.entry_of, f.parent, f.state, f.ext);
   if (rank_level) {
     hipLaunchKernelGGL(k_fa_nxt_init, gn, b, 0, s, f.rec, f.nnodes, f.entry_of, f.state, f.nxt);
