@@ -135,12 +135,13 @@ __device__ __forceinline__ void dt_tile_sums(uint32_t *s_pv, uint32_t *s_recv, u
   // disjoint subtrees (<= 4096 cells in total) plus, on an in-tile D8 cycle, the one cycle cell 2^k moves
   // behind it, whose sum is garbage and may be huge: a cell whose sum exceeds the tile size is on such a
   // cycle and no longer scatters, so a half never carries into its neighbour (<= 8192 per round)
+  // a lane's own words change only by its own hand: they live in registers, LDS gets the copies others gather
+#pragma unroll
+  for (int j = 0; j < CPT / 2; j++) pv[j] = s_pv2[threadIdx.x + 256 * j];
   for (int round = 0; round < 12; round++) {
     int any = 0;
 #pragma unroll
     for (int j = 0; j < CPT / 2; j++) {
-      int c2 = threadIdx.x + 256 * j;
-      pv[j] = s_pv2[c2];
       np[j].x = pv[j].x & 0xFFFFu;
       np[j].y = pv[j].y & 0xFFFFu;
       if (pv[j].x & PT_ALIVE) {
@@ -163,9 +164,11 @@ __device__ __forceinline__ void dt_tile_sums(uint32_t *s_pv, uint32_t *s_recv, u
       uint32_t r = s_recv[c2];
       if (r) s_recv[c2] = 0u;
       // a finished pair that received nothing keeps its words
-      if (r || ((pv[j].x | pv[j].y) & PT_ALIVE))
-        s_pv2[c2] = make_uint2((((pv[j].x >> 16) + (r & 0xFFFFu)) << 16) | np[j].x,
-                               (((pv[j].y >> 16) + (r >> 16)) << 16) | np[j].y);
+      if (r || ((pv[j].x | pv[j].y) & PT_ALIVE)) {
+        pv[j] = make_uint2((((pv[j].x >> 16) + (r & 0xFFFFu)) << 16) | np[j].x,
+                           (((pv[j].y >> 16) + (r >> 16)) << 16) | np[j].y);
+        s_pv2[c2] = pv[j];
+      }
     }
     if (!__syncthreads_or(any)) return;
   }
@@ -978,13 +981,17 @@ __global__ __launch_bounds__(256, 6) void k_fh_tile1n(const uint8_t *__restrict_
   __syncthreads();
   // pointer doubling in place; ONE addition of the low 19 bits adds both counts and inherits the done bit
   uint2 *s_w2 = reinterpret_cast<uint2 *>(s_w);  // lane owns adjacent cell pairs
+  // a lane's own words change only by its own hand: they live in registers, LDS gets the copies others gather
+  uint2 own[CPT / 2];
+#pragma unroll
+  for (int j = 0; j < CPT / 2; j++) own[j] = s_w2[threadIdx.x + 256 * j];
   for (int round = 0; round < 13; round++) {
     int changed = 0;
     uint32_t ovf = 0;
 #pragma unroll
     for (int j = 0; j < CPT / 2; j++) {
       int c2 = threadIdx.x + 256 * j;
-      uint2 v = s_w2[c2];
+      uint2 v = own[j];
       bool dx = (v.x & FN_DONE) != 0u, dy = (v.y & FN_DONE) != 0u;
       if (dx && dy) continue;
       if (!dx) {
@@ -999,6 +1006,7 @@ __global__ __launch_bounds__(256, 6) void k_fh_tile1n(const uint8_t *__restrict_
         ovf |= sum & FN_OVF;
         v.y = (t & ~FN_LOW) | sum;
       }
+      own[j] = v;
       s_w2[c2] = v;
       changed = 1;
     }
