@@ -161,8 +161,7 @@ __device__ __forceinline__ void dt_tile_sums(uint32_t *s_pv, uint32_t *s_recv, u
 #pragma unroll
     for (int j = 0; j < CPT / 2; j++) {
       int c2 = threadIdx.x + 256 * j;
-      uint32_t r = s_recv[c2];
-      if (r) s_recv[c2] = 0u;
+      uint32_t r = atomicExch(&s_recv[c2], 0u);  // read and clear in one LDS instruction
       // a finished pair that received nothing keeps its words
       if (r || ((pv[j].x | pv[j].y) & PT_ALIVE)) {
         pv[j] = make_uint2((((pv[j].x >> 16) + (r & 0xFFFFu)) << 16) | np[j].x,
