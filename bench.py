@@ -48,7 +48,7 @@ OP_KERNELS = {
     "slope_twi": ["k_stencil<true, false, false, true>"],
     "downslope": ["k_downslope_win"],
 }
-PMC_FILE = os.path.join(ROOT, "profiles", "r1", "v9_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r1", "v10_pmc_traffic.json")
 
 
 def pmc_traffic(op, size):
