@@ -26,6 +26,7 @@ _SIGS = {
     "dt_version": (C.c_char_p, []),
     "dt_device_count": (ci, []),
     "dt_set_flow_impl": (ci, [ci]),
+    "dt_debug_set": (ci, [ci, ci]),
     "dt_ctx_create": (ci, [ci, vp, C.POINTER(vp)]),
     "dt_ctx_destroy": (ci, [vp]),
     "dt_ctx_set_stream": (ci, [vp, vp]),

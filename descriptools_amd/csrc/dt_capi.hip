@@ -18,6 +18,14 @@ void dt_set_error(const char *fmt, ...) {
 extern "C" const char *dt_last_error(void) { return g_err; }
 extern "C" const char *dt_version(void) { return "descriptools_hip 0.1 (gfx950)"; }
 
+static int g_debug[DT_DBG_COUNT] = {0};
+int dt_debug_get(int key) { return (key >= 0 && key < DT_DBG_COUNT) ? g_debug[key] : 0; }
+extern "C" int dt_debug_set(int key, int value) {
+  DT_REQUIRE(key >= 0 && key < DT_DBG_COUNT, "unknown debug key");
+  g_debug[key] = value;
+  return DT_OK;
+}
+
 extern "C" int dt_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -42,6 +50,8 @@ extern "C" int dt_ctx_create(int device, void *stream, dt_ctx **out) {
   c->scratch2 = nullptr;
   c->scratch2_bytes = 0;
   c->ev = nullptr;
+  c->aux = nullptr;
+  c->aux_bytes = 0;
   if (stream) {
     c->stream = (hipStream_t)stream;
     c->own_stream = false;
@@ -64,6 +74,7 @@ extern "C" int dt_ctx_destroy(dt_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   if (c->scratch) (void)hipFree(c->scratch);
   if (c->scratch2) (void)hipFree(c->scratch2);
+  if (c->aux) (void)hipFree(c->aux);
   if (c->ev) (void)hipEventDestroy(c->ev);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -124,6 +135,19 @@ void *dt_scratch_take(dt_ctx *c, size_t bytes) {
   c->scratch_used += dt_align256(bytes);
   if (c->scratch_used > c->scratch_bytes) return nullptr;
   return c->scratch + off;
+}
+
+// grow-only side buffers (scratch2: rank-level solves; aux: stencil marks)
+static int dt_side_reserve(dt_ctx *c, char **buf, size_t *have, size_t bytes) {
+  if (bytes > *have) {
+    DT_HIP(hipStreamSynchronize(c->stream));
+    if (*buf) DT_HIP(hipFree(*buf));
+    *buf = nullptr;
+    *have = 0;
+    DT_HIP(hipMalloc((void **)buf, bytes));
+    *have = bytes;
+  }
+  return DT_OK;
 }
 
 #define DT_CTX(c)                            \
@@ -208,8 +232,9 @@ extern "C" int dt_dev_slope_twi(dt_ctx *c, const float *dem, const int32_t *acc3
   DT_CTX(c);
   DT_TRY(dt_check_hw(H, W));
   DT_REQUIRE((dem && acc32 && ti && mti) || H * W == 0, "NULL raster");
+  DT_TRY(dt_side_reserve(c, &c->aux, &c->aux_bytes, dt_stencil_aux_bytes(H, W)));
   DT_TRY(dt_launch_stencil(c->stream, dt_full_window(H, W), dem, px, slope, nullptr, slope_rad, acc32, n_top, ti,
-                           mti));
+                           mti, c->aux));
   DT_HIP(hipGetLastError());
   return DT_OK;
 }
@@ -459,7 +484,8 @@ extern "C" int dt_dev_slope_twi_w(dt_ctx *c, const dt_window *win, const float *
   DtWin w;
   DT_TRY(dt_convert_window(win, &w));
   DT_REQUIRE(dem && acc32 && ti && mti, "NULL raster");
-  DT_TRY(dt_launch_stencil(c->stream, w, dem, px, slope, nullptr, slope_rad, acc32, n_top, ti, mti));
+  DT_TRY(dt_side_reserve(c, &c->aux, &c->aux_bytes, dt_stencil_aux_bytes(w.H, w.W)));
+  DT_TRY(dt_launch_stencil(c->stream, w, dem, px, slope, nullptr, slope_rad, acc32, n_top, ti, mti, c->aux));
   DT_HIP(hipGetLastError());
   return DT_OK;
 }
@@ -565,15 +591,7 @@ extern "C" int dt_dev_flowhand_gfi_finish_w(dt_ctx *c, const dt_window *win, con
 }
 
 static int dt_scratch2_reserve(dt_ctx *c, size_t bytes) {
-  if (bytes > c->scratch2_bytes) {
-    DT_HIP(hipStreamSynchronize(c->stream));
-    if (c->scratch2) DT_HIP(hipFree(c->scratch2));
-    c->scratch2 = nullptr;
-    c->scratch2_bytes = 0;
-    DT_HIP(hipMalloc((void **)&c->scratch2, bytes));
-    c->scratch2_bytes = bytes;
-  }
-  return DT_OK;
+  return dt_side_reserve(c, &c->scratch2, &c->scratch2_bytes, bytes);
 }
 
 extern "C" int dt_dev_rank_solve_flowacc(dt_ctx *c, int ty, int tx, const int64_t *heights, const int64_t *widths,

@@ -36,6 +36,10 @@ void dt_set_error(const char *fmt, ...);
     if (rc__ != DT_OK) return rc__; \
   } while (0)
 
+// ---- test / experiment knobs (dt_debug_set in the C ABI; all 0 by default) -------------------------
+enum { DT_DBG_TWI_FLAG_ALL = 0, DT_DBG_TWI_PLAIN = 1, DT_DBG_COUNT = 8 };
+int dt_debug_get(int key);
+
 // ---- context ------------------------------------------------------------------------------
 struct dt_ctx {
   int device;
@@ -47,6 +51,8 @@ struct dt_ctx {
   char *scratch2;       // rank-level solves (must not disturb the two-phase tile scratch)
   size_t scratch2_bytes;
   hipEvent_t ev;        // fork / join with another context's stream (created on first use)
+  char *aux;            // workspace of the fused slope + TI + MTI stencil (it runs between the two phases of
+  size_t aux_bytes;     // the tile kernels in a multi-GPU step, so it must not touch `scratch`)
 };
 
 // grow-only scratch, bump-allocated per entry point (256-B aligned)

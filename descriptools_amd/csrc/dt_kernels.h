@@ -6,7 +6,9 @@ int dt_launch_synth_dem(hipStream_t s, uint32_t seed, int O, int64_t Hg, int64_t
                         int64_t h, int64_t w, int nodata_pct, float *out);
 int dt_launch_stencil(hipStream_t s, const DtWin &w, const float *dem, double px, float *slope,
                       uint8_t *fdr, float *slope_rad, const int32_t *acc32, double n_top, float *ti,
-                      float *mti);
+                      float *mti, void *aux = nullptr);
+// workspace (tile marks + lane masks) of the fused slope + TI + MTI launch; see dt_stencil.hip
+size_t dt_stencil_aux_bytes(int64_t H, int64_t W);
 int dt_launch_flowacc(hipStream_t s, const uint8_t *fdr, const float *dem, int64_t H, int64_t W,
                       unsigned long long *state, int32_t *acc32);
 int dt_launch_river_mask(hipStream_t s, const int32_t *acc32, int64_t n, int64_t thr, int8_t *river);

@@ -99,357 +99,6 @@ int dt_launch_synth_dem(hipStream_t s, uint32_t seed, int O, int64_t Hg, int64_t
   return DT_OK;
 }
 
-// ===========================================================================================
-// 3x3 stencil: slope (S3, slope.py:210-259) + D8 (N1) + radians + optional fused TI/MTI.
-//
-// Tile = 256 columns x 16 rows per 256-thread workgroup, staged (with a 1-cell halo) through
-// LDS by coalesced 16-byte row loads; thread (tx, ty) then owns a 4-wide x 4-tall patch and
-// reads its 6 x 6 neighbourhood as one ds_read_b128 + two ds_read_b32 per row.  Stores are
-// float4 / uchar4 per row (1 KiB / 256 B contiguous per wave).  Workgroup ids are remapped so
-// that each XCD (ids congruent mod 8 share one) sweeps its own horizontal band of the raster
-// top to bottom: the halo rows shared by vertically adjacent tiles are then re-read from that
-// XCD's L2 instead of HBM.
-//
-// Exactness: the reference compares float64 quotients (z_c - z_nb)/d in scan order
-// NW,N,NE,W,E,SW,S,SE with strict '<'.  Division by a positive constant is monotone and
-// injective on float32 differences, so the maximum over the 4 cardinal (4 diagonal)
-// neighbours is taken on the float32 differences and only the two class maxima are divided
-// in float64 -- bit-identical results with 2 instead of 8 float64 divisions per cell.
-// ===========================================================================================
-#define SD_TX 256
-#define SD_TY 16
-#define SD_LDW (SD_TX + 8)  // LDS row stride in floats; interior starts at column 4
-
-struct SlopeCell {
-  float slope;
-  uint8_t code;
-};
-
-// scan positions: NW0 N1 NE2 W3 E4 SW5 S6 SE7.  NEED_CODE = false (slope only): the D8 bookkeeping
-// (which neighbour, scan position for ties) is skipped -- the slope value does not depend on it.
-// scan position (NW 0, N 1, NE 2, W 3, E 4, SW 5, S 6, SE 7; 8 = none) of a D8 code
-__device__ __forceinline__ int dt_scan_pos(uint32_t code) {
-  if (code == 0u) return 8;
-  // bit index of the code 0..7 = E SE S SW W NW N NE -> position 4 7 6 5 3 0 1 2
-  return (int)((0x21035674u >> (4 * (__ffs((int)code) - 1))) & 0xFu);
-}
-
-// Neighbour heights arrive with nodata (== -100) replaced by +inf (done once per cell when the tile is
-// staged): c - inf = -inf never beats a candidate, which is the reference's "neighbour == -100 skipped"
-// (slope.py:247) without a test per neighbour.  `c` is the centre's original value.
-template <bool NEED_CODE, bool NEED_SLOPE>
-__device__ __forceinline__ SlopeCell dt_slope_cell(float c, float nw, float n, float ne, float w,
-                                                  float e, float sw, float s, float se,
-                                                  double inv_card, double inv_diag, double dcard,
-                                                  double ddiag) {
-  SlopeCell r;
-  if (c <= DT_NODATA) {  // slope.py:231
-    r.slope = DT_NODATA;
-    r.code = 0;
-    return r;
-  }
-  // cardinals in scan order N, W, E, S, then the diagonals NW, NE, SW, SE; strict > keeps the first maximum
-  float cb = 0.0f, db = 0.0f;
-  uint32_t ccode = 0, dcode = 0;
-  if (NEED_CODE) {
-#define DT_CAND(nb, best, bcode, code_) \
-  {                                     \
-    float d_ = c - (nb);                \
-    if (d_ > best) {                    \
-      best = d_;                        \
-      bcode = code_;                    \
-    }                                   \
-  }
-    DT_CAND(n, cb, ccode, 64u)
-    DT_CAND(w, cb, ccode, 16u)
-    DT_CAND(e, cb, ccode, 1u)
-    DT_CAND(s, cb, ccode, 4u)
-    DT_CAND(nw, db, dcode, 32u)
-    DT_CAND(ne, db, dcode, 128u)
-    DT_CAND(sw, db, dcode, 8u)
-    DT_CAND(se, db, dcode, 2u)
-#undef DT_CAND
-  } else {
-    cb = fmaxf(fmaxf(fmaxf(c - n, c - w), fmaxf(c - e, c - s)), 0.0f);
-    db = fmaxf(fmaxf(fmaxf(c - nw, c - ne), fmaxf(c - sw, c - se)), 0.0f);
-  }
-  // Exact float64 divisions are ~15 instructions each.  Fast path: multiply by the (correctly rounded)
-  // reciprocals -- within 3 float64 ulp of the reference's quotient -- and accept the result only if
-  // neither the cardinal / diagonal comparison nor (when the slope is wanted) the final float32 rounding
-  // can be affected by those ulps; otherwise divide.  Results are bit-identical either way.
-  double vc = (double)cb * inv_card, vd = (double)db * inv_diag;
-  const double EPS = 8.9e-16;  // 4 ulp, relative
-  double vmax = vc > vd ? vc : vd;
-  bool ambiguous = (vc != vd) && fabs(vc - vd) <= EPS * vmax;
-  if (NEED_SLOPE) {
-    float f_lo = (float)(vmax * (100.0 * (1.0 - EPS))), f_hi = (float)(vmax * (100.0 * (1.0 + EPS)));
-    ambiguous = ambiguous || (f_lo != f_hi);
-  }
-  if (ambiguous) {
-    vc = cb > 0.0f ? (double)cb / dcard : 0.0;
-    vd = db > 0.0f ? (double)db / ddiag : 0.0;
-  }
-  double v;
-  uint32_t code;
-  // equal quotients: the candidate met first in scan order wins (positions looked up only then)
-  if (vc > vd || (vc == vd && dt_scan_pos(ccode) < dt_scan_pos(dcode))) {
-    v = vc;
-    code = ccode;
-  } else {
-    v = vd;
-    code = dcode;
-  }
-  r.slope = (float)(v * 100.0);  // slope.py:259
-  r.code = (uint8_t)code;
-  return r;
-}
-
-// TI / MTI of one cell (topoindexes.py:234-295); float64 inside, float32 out.
-//   TI  = ln(A / t)   = ln A - ln t,      A = a * px^2 (a = fac, 0 -> 1), t = tan(slope + 0.01)
-//   MTI = ln(A^n / t) = n ln A - ln t
-// evaluated from two logarithms and one tangent instead of pow + 2 log + 2 divisions (the float64
-// difference to the reference's literal expression is ~1e-16 relative, invisible after the float32
-// rounding except at rounding ties; NaN / inf cases propagate identically: ln of a negative A or t
-// is NaN like pow / log of it).  lnpx2 = ln(px^2) is computed once on the host.
-__device__ __forceinline__ void dt_twi_cell(int64_t fac, float srad, double lnpx2, double n, float &ti,
-                                            float &mti, const DtLogEntry *s_tab) {
-  if (fac <= -100) {
-    ti = DT_NODATA;
-    mti = DT_NODATA;
-    return;
-  }
-  // float32 fast path (dt_math.h): valid arguments and results away from zero
-  if (fac >= 0 && fac < (1ll << 40) && srad >= 0.0f && srad <= 1.2f) {
-    double la = (fac == 0 ? 0.0 : dt_lnf((float)fac)) + lnpx2;
-    double lt = dt_lntanf((double)srad + 0.01);
-    double a = la - lt, b = n * la - lt;
-    if (fabs(a) >= DT_FAST_MIN && fabs(b) >= DT_FAST_MIN) {
-      ti = (float)a;
-      mti = (float)b;
-      return;
-    }
-  }
-  double la = (fac == 0 ? 0.0 : dt_fast_log((double)fac, s_tab)) + lnpx2;
-  double lt = dt_fast_lntan((double)srad + 0.01, s_tab);
-  ti = (float)(la - lt);
-  mti = (float)(n * la - lt);
-}
-
-// slope % -> radians as Example/example.py:63-64 does on the host: float32 quotient, arctan,
-// float32 result; -100 where dem == -100.
-__device__ __forceinline__ float dt_slope_rad(float slope_pct, float dem) {
-  if (dem == DT_NODATA) return DT_NODATA;
-  float q = slope_pct / 100.0f;
-  if (q >= 0.0f && q < 1e30f) return (float)dt_atanf_pos(q);
-  return (float)dt_fast_atan((double)q);
-}
-
-template <bool W_SLOPE, bool W_FDR, bool W_RAD, bool W_TWI>
-__global__ __launch_bounds__(256, 6) void k_stencil(const float *__restrict__ dem, DtWin w,
-                                                double px, float *__restrict__ slope,
-                                                uint8_t *__restrict__ fdr,
-                                                float *__restrict__ slope_rad,
-                                                const int32_t *__restrict__ acc32, double n_top,
-                                                double lnpx2, float *__restrict__ ti,
-                                                float *__restrict__ mti, int tiles_x, int tiles_y,
-                                                int vec_ok, const DtLogEntry *__restrict__ g_tab) {
-  __shared__ __attribute__((aligned(16))) float t[(SD_TY + 2) * SD_LDW];
-  __shared__ DtLogEntry s_tab[W_TWI ? DT_LOGTAB_N : 1];
-  if (W_TWI) dt_math_stage(g_tab, s_tab);
-
-  // XCD-aware tile mapping: workgroup id b runs on XCD group (b % 8); give each group a band
-  // of tile rows and walk it row-major.
-  int b = blockIdx.x;
-  int ntiles = tiles_x * tiles_y;
-  int tile;
-  {
-    int xcd = b & 7, j = b >> 3;
-    int q = ntiles >> 3, rem = ntiles & 7;
-    int base = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
-    tile = base + j;
-  }
-  int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
-  int x0 = txi * SD_TX, y0 = tyi * SD_TY;
-
-  const int H = w.H, W = w.W;
-  // ---- stage (SD_TY + 2) x (SD_TX + 2) cells; outside the GLOBAL raster = -100 ring (slope.py:175);
-  // cells outside the core but inside the global raster come from the halo of the window ----
-  const int ylo = -(w.gy0 > 0 ? 1 : 0), yhi = H + (w.gy0 + H < w.Hg ? 1 : 0);  // readable rows [ylo, yhi)
-  const int xlo = -(w.gx0 > 0 ? 1 : 0), xhi = W + (w.gx0 + W < w.Wg ? 1 : 0);
-  const float pinf = __builtin_inff();
-  for (int i = threadIdx.x; i < (SD_TY + 2) * (SD_TX / 4); i += 256) {
-    int r = i / (SD_TX / 4), c4 = i - r * (SD_TX / 4);
-    int gy = y0 - 1 + r, gx = x0 + c4 * 4;
-    float4 v = make_float4(DT_NODATA, DT_NODATA, DT_NODATA, DT_NODATA);
-    if (gy >= ylo && gy < yhi) {
-      const float *p = dem + (long long)gy * w.ld + gx;
-      if (vec_ok && gx + 3 < xhi) {
-        v = *reinterpret_cast<const float4 *>(p);
-      } else {
-        if (gx < xhi) v.x = p[0];
-        if (gx + 1 < xhi) v.y = p[1];
-        if (gx + 2 < xhi) v.z = p[2];
-        if (gx + 3 < xhi) v.w = p[3];
-      }
-    }
-    // nodata (and everything outside the raster) as +inf: see dt_slope_cell
-    v.x = v.x == DT_NODATA ? pinf : v.x;
-    v.y = v.y == DT_NODATA ? pinf : v.y;
-    v.z = v.z == DT_NODATA ? pinf : v.z;
-    v.w = v.w == DT_NODATA ? pinf : v.w;
-    *reinterpret_cast<float4 *>(&t[r * SD_LDW + 4 + c4 * 4]) = v;
-  }
-  for (int i = threadIdx.x; i < (SD_TY + 2) * 2; i += 256) {
-    int r = i >> 1, side = i & 1;
-    int gy = y0 - 1 + r, gx = side ? x0 + SD_TX : x0 - 1;
-    float v = DT_NODATA;
-    if (gy >= ylo && gy < yhi && gx >= xlo && gx < xhi) v = dem[(long long)gy * w.ld + gx];
-    t[r * SD_LDW + (side ? 4 + SD_TX : 3)] = v == DT_NODATA ? pinf : v;
-  }
-  __syncthreads();
-
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int cx = tx * 4;  // tile column of the patch
-  const int ry = ty * 4;  // tile row of the patch
-  const int gx = x0 + cx;
-  if (gx >= W) return;
-  const double dcard = px, ddiag = px * sqrt(2.0);
-  const double inv_card = 1.0 / dcard, inv_diag = 1.0 / ddiag;
-
-  // rolling 3-row window of 6 values (cols cx-1 .. cx+4)
-  float a[6], bb[6], cc[6];
-  auto load_row = [&](int lr, float *dst) {
-    const float *p = &t[lr * SD_LDW + 4 + cx];
-    float4 m = *reinterpret_cast<const float4 *>(p);
-    dst[0] = p[-1];
-    dst[1] = m.x;
-    dst[2] = m.y;
-    dst[3] = m.z;
-    dst[4] = m.w;
-    dst[5] = p[4];
-  };
-  // flow accumulation of my 4 x 4 patch: four 16-byte loads issued up front (latency hidden behind the
-  // stencil arithmetic) instead of sixteen 4-byte loads inside the loop
-  int4 facv[4];
-  if (W_TWI) {
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      int gy = y0 + ry + j;
-      facv[j] = make_int4(-100, -100, -100, -100);
-      if (gy < H) {
-        const int32_t *pf = acc32 + (long long)gy * w.ld + gx;
-        if (vec_ok && gx + 3 < W) {
-          facv[j] = *reinterpret_cast<const int4 *>(pf);
-        } else {
-          if (gx < W) facv[j].x = pf[0];
-          if (gx + 1 < W) facv[j].y = pf[1];
-          if (gx + 2 < W) facv[j].z = pf[2];
-          if (gx + 3 < W) facv[j].w = pf[3];
-        }
-      }
-    }
-  }
-  load_row(ry, a);       // row above the first output row (tile row ry == raster row y0-1+ry)
-  load_row(ry + 1, bb);  // first output row
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    int gy = y0 + ry + j;
-    load_row(ry + 2 + j, cc);
-    if (gy < H) {
-      float so[4], ro[4], tio[4], mtio[4];
-      uint32_t codes = 0;
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const float cz = bb[k + 1] == pinf ? DT_NODATA : bb[k + 1];  // the centre's own value
-        SlopeCell sc = dt_slope_cell<W_FDR, (W_SLOPE || W_RAD || W_TWI)>(cz, a[k], a[k + 1], a[k + 2], bb[k],
-                                                                       bb[k + 2], cc[k], cc[k + 1], cc[k + 2],
-                                                                       inv_card, inv_diag, dcard, ddiag);
-        so[k] = sc.slope;
-        uint32_t code = sc.code;
-        if (W_FDR) {
-          // N1 border rule: a border cell with no lower neighbour drains out of the raster
-          int gyy = w.gy0 + gy, gxx = w.gx0 + gx + k;  // global position
-          if (code == 0u && cz > DT_NODATA) {
-            if (gyy == w.Hg - 1) code = 4u;
-            else if (gyy == 0) code = 64u;
-            else if (gxx == 0) code = 16u;
-            else if (gxx == w.Wg - 1) code = 1u;
-          }
-          codes |= code << (8 * k);
-        }
-        if (W_RAD || W_TWI) ro[k] = dt_slope_rad(sc.slope, cz);
-        if (W_TWI) {
-          int32_t f32v = k == 0 ? facv[j].x : (k == 1 ? facv[j].y : (k == 2 ? facv[j].z : facv[j].w));
-          dt_twi_cell((int64_t)f32v, ro[k], lnpx2, n_top, tio[k], mtio[k], s_tab);
-        }
-      }
-      long long o = (long long)gy * w.ld + gx;
-      bool full = vec_ok && gx + 3 < W;
-      if (full) {
-        if (W_SLOPE) *reinterpret_cast<float4 *>(slope + o) = make_float4(so[0], so[1], so[2], so[3]);
-        if (W_RAD) *reinterpret_cast<float4 *>(slope_rad + o) = make_float4(ro[0], ro[1], ro[2], ro[3]);
-        if (W_TWI) {
-          *reinterpret_cast<float4 *>(ti + o) = make_float4(tio[0], tio[1], tio[2], tio[3]);
-          *reinterpret_cast<float4 *>(mti + o) = make_float4(mtio[0], mtio[1], mtio[2], mtio[3]);
-        }
-        if (W_FDR) *reinterpret_cast<uint32_t *>(fdr + o) = codes;
-      } else {
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          if (gx + k < W) {
-            if (W_SLOPE) slope[o + k] = so[k];
-            if (W_RAD) slope_rad[o + k] = ro[k];
-            if (W_TWI) {
-              ti[o + k] = tio[k];
-              mti[o + k] = mtio[k];
-            }
-            if (W_FDR) fdr[o + k] = (uint8_t)(codes >> (8 * k));
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < 6; q++) {
-      a[q] = bb[q];
-      bb[q] = cc[q];
-    }
-  }
-}
-
-int dt_launch_stencil(hipStream_t s, const DtWin &w, const float *dem, double px, float *slope,
-                      uint8_t *fdr, float *slope_rad, const int32_t *acc32, double n_top, float *ti,
-                      float *mti) {
-  const int64_t H = w.H, W = w.W;
-  if (H == 0 || W == 0) return DT_OK;
-  int tiles_x = (int)((W + SD_TX - 1) / SD_TX), tiles_y = (int)((H + SD_TY - 1) / SD_TY);
-  int64_t ntiles = (int64_t)tiles_x * tiles_y;
-  DT_REQUIRE(ntiles < (1ll << 31), "raster too large for one launch");
-  // 16-byte vector path needs W % 4 == 0 and 16-byte aligned bases
-  int vec_ok = (W % 4 == 0) && (w.ld % 4 == 0) && (((uintptr_t)dem & 15) == 0) && (!slope || ((uintptr_t)slope & 15) == 0) &&
-               (!slope_rad || ((uintptr_t)slope_rad & 15) == 0) && (!ti || ((uintptr_t)ti & 15) == 0) &&
-               (!mti || ((uintptr_t)mti & 15) == 0) && (!fdr || ((uintptr_t)fdr & 3) == 0);
-  dim3 g((unsigned)ntiles), b(256);
-  bool ws = slope != nullptr, wf = fdr != nullptr, wr = slope_rad != nullptr, wt = ti != nullptr;
-  const DtLogEntry *g_tab = wt ? dt_math_device_table(s) : nullptr;
-#define DT_GO(S, F, R, T)                                                                          \
-  hipLaunchKernelGGL((k_stencil<S, F, R, T>), g, b, 0, s, dem, w, px, slope, fdr,                  \
-                     slope_rad, acc32, n_top, log(px * px), ti, mti, tiles_x, tiles_y, vec_ok, g_tab)
-  if (wt) {
-    DT_REQUIRE(acc32 && mti, "fused TWI needs acc32, ti and mti");
-    if (ws && wr) DT_GO(true, false, true, true);
-    else if (ws) DT_GO(true, false, false, true);
-    else if (wr) DT_GO(false, false, true, true);
-    else DT_GO(false, false, false, true);
-  } else if (ws && wf && wr) DT_GO(true, true, true, false);
-  else if (ws && wf) DT_GO(true, true, false, false);
-  else if (ws && wr) DT_GO(true, false, true, false);
-  else if (wf && wr) DT_GO(false, true, true, false);
-  else if (ws) DT_GO(true, false, false, false);
-  else if (wf) DT_GO(false, true, false, false);
-  else if (wr) DT_GO(false, false, true, false);
-#undef DT_GO
-  return DT_OK;
-}
 
 // ===========================================================================================
 // Flow accumulation (N2), v1: in-degree countdown with ONE packed 64-bit word per cell,
@@ -1412,3 +1061,4 @@ int dt_launch_i64_to_i32(hipStream_t s, const int64_t *a, int64_t n, int32_t *b)
   if (n) hipLaunchKernelGGL(k_i64_to_i32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, n, b);
   return DT_OK;
 }
+

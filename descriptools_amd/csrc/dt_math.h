@@ -124,28 +124,32 @@ __device__ __forceinline__ double dt_lntanf(double y) {
   return lo ? r : -r;
 }
 
-// atan(q), q >= 0 float32: reduction as dt_fast_atan with float32 division, degree-5 polynomial; the
-// last multiply-add is float64 so that the result rounds to float32 within ~1 ulp
+// atan(q), q >= 0 float32, without branches: reduction as dt_fast_atan (q, (q - 1) / (q + 1) or 1 / q into
+// [-tan(pi/8), tan(pi/8)]) with the quotient from the hardware reciprocal and one Newton step (<= 0.51 ulp),
+// degree-5 polynomial; the last multiply-add is float64 so that the result rounds to float32 within ~1 ulp
 __device__ __forceinline__ double dt_atanf_pos(float q) {
   const float T8 = 0.41421356f, T38 = 2.41421356f;
-  float x;
-  double base, sgn = 1.0;
-  if (q <= T8) {
-    x = q;
-    base = 0.0;
-  } else if (q < T38) {
-    x = (q - 1.0f) / (q + 1.0f);
-    base = 0.7853981633974483;
-  } else {
-    x = 1.0f / q;
-    base = 1.5707963267948966;
-    sgn = -1.0;
-  }
+  const bool lowr = q <= T8, high = !(q < T38);
+  const float num = lowr ? q : (high ? 1.0f : q - 1.0f);
+  const float den = lowr ? 1.0f : (high ? q : q + 1.0f);
+  const float r0 = __builtin_amdgcn_rcpf(den);
+  float x = num * r0;
+  x = fmaf(fmaf(-den, x, num), r0, x);
+  x = lowr ? q : x;
+  const double base = lowr ? 0.0 : (high ? 1.5707963267948966 : 0.7853981633974483);
   float t = fmaf(x * x, (float)DT_ATAN_SCALE, -1.0f);
   float h = dt_atan_c32[5];
 #pragma unroll
   for (int k = 4; k >= 0; k--) h = fmaf(h, t, dt_atan_c32[k]);
-  return fma(sgn * (double)x, (double)h, base);
+  const double xs = high ? -(double)x : (double)x;
+  return fma(xs, (double)h, base);
+}
+
+// slope % / 100 in float32 (Example/example.py:63 divides in float32): product with the rounded reciprocal
+// and one residual correction, <= 0.51 ulp from the quotient, 3 instructions instead of an IEEE division
+__device__ __forceinline__ float dt_pct_to_tan(float slope_pct) {
+  const float q0 = slope_pct * 0.01f;
+  return fmaf(fmaf(-q0, 100.0f, slope_pct), 0.01f, q0);
 }
 
 // GFI and ln(hl/H) in one pass: hand is read once and ln(h + 0.01) evaluated once (3 logs / cell
@@ -172,3 +176,46 @@ __device__ __forceinline__ void dt_gfi_both_cell(float h, int32_t ar, int32_t f,
   l_out = (float)(lh + (f == 0 ? 0.0 : expo * dt_fast_log((double)f, s_tab)));
 }
 
+#ifndef DT_NODATA
+#define DT_NODATA (-100.0f)
+#endif
+
+// TI / MTI of one cell (topoindexes.py:234-295); float64 inside, float32 out.
+//   TI  = ln(A / t)   = ln A - ln t,      A = a * px^2 (a = fac, 0 -> 1), t = tan(slope + 0.01)
+//   MTI = ln(A^n / t) = n ln A - ln t
+// evaluated from two logarithms and one tangent instead of pow + 2 log + 2 divisions (the float64
+// difference to the reference's literal expression is ~1e-16 relative, invisible after the float32
+// rounding except at rounding ties; NaN / inf cases propagate identically: ln of a negative A or t
+// is NaN like pow / log of it).  lnpx2 = ln(px^2) is computed once on the host.
+__device__ __forceinline__ void dt_twi_cell(int64_t fac, float srad, double lnpx2, double n, float &ti,
+                                            float &mti, const DtLogEntry *s_tab) {
+  if (fac <= -100) {
+    ti = DT_NODATA;
+    mti = DT_NODATA;
+    return;
+  }
+  // float32 fast path (dt_math.h): valid arguments and results away from zero
+  if (fac >= 0 && fac < (1ll << 40) && srad >= 0.0f && srad <= 1.2f) {
+    double la = (fac == 0 ? 0.0 : dt_lnf((float)fac)) + lnpx2;
+    double lt = dt_lntanf((double)srad + 0.01);
+    double a = la - lt, b = n * la - lt;
+    if (fabs(a) >= DT_FAST_MIN && fabs(b) >= DT_FAST_MIN) {
+      ti = (float)a;
+      mti = (float)b;
+      return;
+    }
+  }
+  double la = (fac == 0 ? 0.0 : dt_fast_log((double)fac, s_tab)) + lnpx2;
+  double lt = dt_fast_lntan((double)srad + 0.01, s_tab);
+  ti = (float)(la - lt);
+  mti = (float)(n * la - lt);
+}
+
+// slope % -> radians as Example/example.py:63-64 does on the host: float32 quotient, arctan,
+// float32 result (within ~1 float32 ulp of numpy's float32 arctan); -100 where dem == -100.
+__device__ __forceinline__ float dt_slope_rad(float slope_pct, float dem) {
+  if (dem == DT_NODATA) return DT_NODATA;
+  float q = dt_pct_to_tan(slope_pct);
+  if (q >= 0.0f && q < 1e30f) return (float)dt_atanf_pos(q);
+  return (float)dt_fast_atan((double)q);
+}

@@ -50,6 +50,10 @@ const char *dt_version(void);
 /* A/B knob: 1 = first-generation global kernels for flow accumulation / HAND, 2 = tile-hierarchical
  * (default; also selectable with the environment variable DT_FLOW_IMPL=v1).  Same results. */
 int dt_set_flow_impl(int impl);
+/* Test knobs, all 0 by default.  key 0 (DT_DBG_TWI_FLAG_ALL): the fused slope + TI + MTI stencil sends every
+ * cell through its exact (cold) path as well as the fast one; key 1 (DT_DBG_TWI_PLAIN): default cache policy
+ * instead of non-temporal loads / stores in that stencil (A/B timing). */
+int dt_debug_set(int key, int value);
 
 /* Context = one device + one stream + grow-only scratch.  `stream` may be NULL (the context
  * creates its own non-blocking stream) or an existing hipStream_t (e.g. torch's). */

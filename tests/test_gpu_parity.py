@@ -429,3 +429,33 @@ def test_flowhand_long_in_tile_paths(dt):
     assert np.array_equal(idx, idx_o) and np.array_equal(hand, hand_o)
     assert (idx_o >= 0).sum() > 8000 and fd_o.max() > 40000
     assert_float_close(fd, fd_o, rtol=1e-6, what="flow distance")
+
+
+def test_slope_twi_cold_path_equals_hot_path(dt):
+    """The fused slope + TI + MTI stencil is a branch-free fast kernel plus an exact fix-up kernel for the cells
+    it flags (dt_stencil.hip).  With every cell flagged (test knob) the exact path writes all of them: slope and
+    radians must not change at all, TI / MTI only inside the fast path's error bound, and both agree with the
+    oracle; ragged shapes, nodata blobs, negative / zero / huge accumulations."""
+    from descriptools_amd import _lib, chain
+    L = _lib.lib()
+    rng = np.random.default_rng(7)
+    for (H, W, nod) in ((300, 777, 3), (64, 1024, 0), (17, 5, 0)):
+        dem = oracle.synth_dem(5, 2048, 2048, 10, 20, H, W, nod)
+        dem[rng.random((H, W)) < 0.01] = -250.0          # below the nodata sentinel: slope -100, finite radians
+        outs = []
+        for flag_all in (0, 1):
+            _lib.check(L.dt_debug_set(0, flag_all))
+            try:
+                outs.append(chain.run_host(dem, 10.0, river_threshold=max(8, H * W // 512)))
+            finally:
+                _lib.check(L.dt_debug_set(0, 0))
+        a, b = outs
+        assert np.array_equal(a["slope"], b["slope"]) and np.array_equal(a["slope_rad"], b["slope_rad"])
+        sl_o, _ = oracle.slope_d8(dem, 10.0)
+        assert np.array_equal(a["slope"], sl_o)
+        for k in ("ti", "mti"):
+            assert_float_close(a[k], b[k], rtol=4e-6, atol=1e-6, what=k + " hot vs cold")
+        ti_o, mti_o = oracle.twi(a["fac"], a["slope_rad"], 10.0, 0.1)
+        for got in (a, b):
+            assert_float_close(got["ti"], ti_o, rtol=1e-5, what="ti")
+            assert_float_close(got["mti"], mti_o, rtol=1e-5, atol=1e-6, what="mti")

@@ -27,6 +27,18 @@ for blocks in (1024, 2048, 4096, 8192, 65536):
 t("slope only (8 B)", lambda: L.dt_dev_slope_d8(ctx.h, dem.data_ptr(), S, S, 10.0, slope.data_ptr(), None, None), 8)
 t("d8 only (5 B)", lambda: L.dt_dev_slope_d8(ctx.h, dem.data_ptr(), S, S, 10.0, None, fdr.data_ptr(), None), 5)
 t("slope + rad (12 B)", lambda: L.dt_dev_slope_d8(ctx.h, dem.data_ptr(), S, S, 10.0, slope.data_ptr(), None, rad.data_ptr()), 12)
+t("slope+rad+ti+mti (24 B)", lambda: L.dt_dev_slope_twi(ctx.h, dem.data_ptr(), fac.data_ptr(), S, S, 10.0, 0.1, slope.data_ptr(), rad.data_ptr(), ti.data_ptr(), mti.data_ptr()), 24)
 t("slope+ti+mti (20 B)", lambda: L.dt_dev_slope_twi(ctx.h, dem.data_ptr(), fac.data_ptr(), S, S, 10.0, 0.1, slope.data_ptr(), None, ti.data_ptr(), mti.data_ptr()), 20)
 t("ti+mti only (16 B)", lambda: L.dt_dev_slope_twi(ctx.h, dem.data_ptr(), fac.data_ptr(), S, S, 10.0, 0.1, None, None, ti.data_ptr(), mti.data_ptr()), 16)
 t("twi pointwise (16 B)", lambda: L.dt_dev_twi(ctx.h, fac.data_ptr(), rad.data_ptr(), S * S, 10.0, 0.1, ti.data_ptr(), mti.data_ptr()), 16)
+
+# ---- the fused kernel on the chain's own accumulation raster, store-policy A/B (interleaved) ----
+river = torch.empty((S, S), dtype=torch.int8, device="cuda")
+_lib.check(L.dt_dev_slope_d8(ctx.h, dem.data_ptr(), S, S, 10.0, None, fdr.data_ptr(), None))
+_lib.check(L.dt_dev_flowacc_river(ctx.h, fdr.data_ptr(), dem.data_ptr(), S, S, S * S // 512, fac.data_ptr(), river.data_ptr()))
+torch.cuda.synchronize()
+for rep in range(3):
+    for nt in (0, 1):
+        _lib.check(L.dt_debug_set(1, nt))
+        t("real fac, plain=%d slope+ti+mti" % nt, lambda: L.dt_dev_slope_twi(ctx.h, dem.data_ptr(), fac.data_ptr(), S, S, 10.0, 0.1, slope.data_ptr(), None, ti.data_ptr(), mti.data_ptr()), 20)
+_lib.check(L.dt_debug_set(1, 0))
