@@ -1154,45 +1154,16 @@ __global__ __launch_bounds__(256) void k_fh_ghost_set(unsigned long long *__rest
 // optional fused epilogue: GFI and ln(hl/H) (gfi.py:268-294, :404-440) from the HAND and river accumulation
 // this kernel has in registers and the cell's own accumulation -- saves the separate pass over hand,
 // A_river and fac (and, when a_river is not asked for, that raster altogether)
-// dt_gfi_both_cell's fast path alone (three hardware log2 of mantissas; dt_math.h): true when the cell is outside
-// it and must be redone with the float64 logarithms (k_fh_gfi_fix)
-__device__ __forceinline__ bool fh_gfi_fast(float h, int32_t ar, int32_t f, double expo, double c0, float &g_out,
-                                            float &l_out) {
-  const double lh = c0 - dt_lnf((float)((double)h + 0.01));
-  const double g = lh + expo * dt_lnf((float)ar);
-  const double l = lh + (f == 0 ? 0.0 : expo * dt_lnf((float)f));
-  const bool nod = h <= DT_NODATA;
-  g_out = nod ? DT_NODATA : (float)g;
-  l_out = nod ? DT_NODATA : (float)l;
-  return !nod && !(h > -0.005f && ar > 0 && f >= 0 && fabs(g) >= DT_FAST_MIN && fabs(l) >= DT_FAST_MIN);
-}
-
 struct FhGfi {
   float *gfi, *lnhlh;  // NULL: not fused
   double expo, c0;     // n, ln b + n ln(size^2)
   const DtLogEntry *tab;
-  // cells the fast logarithms cannot settle (result within DT_FAST_MIN of zero, odd arguments: a few per cent
-  // near the zero crossings of the indices) are queued per tile, {local cell, river accumulation}, and redone
-  // in float64 by k_fh_gfi_fix: the streaming kernel keeps no slow-path code
-  unsigned long long *fix_rec;  // [ntiles * NT]
-  uint32_t *fix_cnt;            // [ntiles]
 };
 struct FhRemote {  // payload of rank exits (multi-GPU), all indexed by core-ring index; NULL when unused
   const long long *gidx;
   const float *zr;
   const int32_t *ar;
 };
-
-typedef float fh_v4f __attribute__((ext_vector_type(4)));
-typedef int fh_v4i __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void fh_store4(float *p, float a, float b, float c, float d) {
-  fh_v4f v = {a, b, c, d};
-  __builtin_nontemporal_store(v, reinterpret_cast<fh_v4f *>(p));
-}
-__device__ __forceinline__ void fh_store4(int32_t *p, int32_t a, int32_t b, int32_t c, int32_t d) {
-  fh_v4i v = {a, b, c, d};
-  __builtin_nontemporal_store(v, reinterpret_cast<fh_v4i *>(p));
-}
 
 __global__ __launch_bounds__(256, 6) void k_fh_tile3(const uint8_t *__restrict__ fdr,
                                                  const float *__restrict__ dem,
@@ -1209,12 +1180,10 @@ __global__ __launch_bounds__(256, 6) void k_fh_tile3(const uint8_t *__restrict__
   // 28 B/cell and needs the occupancy, not a 32 KiB per-cell table.
   __shared__ unsigned long long s_x[PS];
   __shared__ unsigned long long s_pay[PS];
-  __shared__ uint32_t s_nfix;
   const int tile = blockIdx.x;
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int y0 = ty * TH, x0 = tx * TW;
   const bool wide = cache_wide[tile] != 0;  // block-uniform
-  if (threadIdx.x == 0) s_nfix = 0u;
   if (threadIdx.x < PS) {
     int ly, lx;
     dt_cell_of_slot(threadIdx.x, ly, lx);
@@ -1361,42 +1330,29 @@ __global__ __launch_bounds__(256, 6) void k_fh_tile3(const uint8_t *__restrict__
         CellOut r1 = solve(((unsigned long long)wa[u].w << 32) | wa[u].z, z4[u].y);
         CellOut r2 = solve(((unsigned long long)wb[u].y << 32) | wb[u].x, z4[u].z);
         CellOut r3 = solve(((unsigned long long)wb[u].w << 32) | wb[u].z, z4[u].w);
-        // every output byte is written once and not read again by this kernel: non-temporal stores
-        if (fdist) fh_store4(fdist + o, r0.fd, r1.fd, r2.fd, r3.fd);
-        if (idx32) fh_store4(idx32 + o, r0.i32, r1.i32, r2.i32, r3.i32);
+        if (fdist) *reinterpret_cast<float4 *>(fdist + o) = make_float4(r0.fd, r1.fd, r2.fd, r3.fd);
+        if (idx32) *reinterpret_cast<int4 *>(idx32 + o) = make_int4(r0.i32, r1.i32, r2.i32, r3.i32);
         if (idx64) {
           *reinterpret_cast<longlong2 *>(idx64 + o) = make_longlong2(r0.i64, r1.i64);
           *reinterpret_cast<longlong2 *>(idx64 + o + 2) = make_longlong2(r2.i64, r3.i64);
         }
-        if (hand) fh_store4(hand + o, r0.h, r1.h, r2.h, r3.h);
-        if (a_river) fh_store4(a_river + o, r0.ar, r1.ar, r2.ar, r3.ar);
+        if (hand) *reinterpret_cast<float4 *>(hand + o) = make_float4(r0.h, r1.h, r2.h, r3.h);
+        if (a_river) *reinterpret_cast<int4 *>(a_river + o) = make_int4(r0.ar, r1.ar, r2.ar, r3.ar);
         if (G.gfi) {
           int4 f = *reinterpret_cast<const int4 *>(acc32 + o);  // own accumulation (aligned like the outputs)
           float4 g, l;
-          const bool q0 = fh_gfi_fast(r0.h, r0.ar, f.x, G.expo, G.c0, g.x, l.x);
-          const bool q1 = fh_gfi_fast(r1.h, r1.ar, f.y, G.expo, G.c0, g.y, l.y);
-          const bool q2 = fh_gfi_fast(r2.h, r2.ar, f.z, G.expo, G.c0, g.z, l.z);
-          const bool q3 = fh_gfi_fast(r3.h, r3.ar, f.w, G.expo, G.c0, g.w, l.w);
-          fh_store4(G.gfi + o, g.x, g.y, g.z, g.w);
-          fh_store4(G.lnhlh + o, l.x, l.y, l.z, l.w);
-          if (q0 | q1 | q2 | q3) {  // queue the unsettled cells of this group (LDS counter: a few per cent of the lanes)
-            unsigned long long *rec = G.fix_rec + (size_t)tile * NT;
-            if (q0) rec[atomicAdd(&s_nfix, 1u)] = ((unsigned long long)(uint32_t)r0.ar << 32) | (uint32_t)c;
-            if (q1) rec[atomicAdd(&s_nfix, 1u)] = ((unsigned long long)(uint32_t)r1.ar << 32) | (uint32_t)(c + 1);
-            if (q2) rec[atomicAdd(&s_nfix, 1u)] = ((unsigned long long)(uint32_t)r2.ar << 32) | (uint32_t)(c + 2);
-            if (q3) rec[atomicAdd(&s_nfix, 1u)] = ((unsigned long long)(uint32_t)r3.ar << 32) | (uint32_t)(c + 3);
-          }
+          dt_gfi_both_cell(r0.h, r0.ar, f.x, G.expo, G.c0, G.tab, g.x, l.x);
+          dt_gfi_both_cell(r1.h, r1.ar, f.y, G.expo, G.c0, G.tab, g.y, l.y);
+          dt_gfi_both_cell(r2.h, r2.ar, f.z, G.expo, G.c0, G.tab, g.z, l.z);
+          dt_gfi_both_cell(r3.h, r3.ar, f.w, G.expo, G.c0, G.tab, g.w, l.w);
+          *reinterpret_cast<float4 *>(G.gfi + o) = g;
+          *reinterpret_cast<float4 *>(G.lnhlh + o) = l;
         }
       }
-    }
-    if (G.gfi) {
-      __syncthreads();
-      if (threadIdx.x == 0) G.fix_cnt[tile] = s_nfix;
     }
     return;
   }
   // ragged tiles and unaligned rasters: one cell at a time (rare: keep it small, not fast)
-  if (G.gfi && threadIdx.x == 0) G.fix_cnt[tile] = 0u;
   __syncthreads();
 #pragma unroll 1
   for (int j = 0; j < CPT; j++) {
@@ -1419,42 +1375,9 @@ __global__ __launch_bounds__(256, 6) void k_fh_tile3(const uint8_t *__restrict__
   }
 }
 
-// the cold half of the fused GFI / ln(hl/H) epilogue: float64 logarithms for the queued cells
-__global__ __launch_bounds__(256) void k_fh_gfi_fix(const float *__restrict__ hand, const int32_t *__restrict__ acc32,
-                                                   DtWin w, int tiles_x, int ntiles, FhGfi G) {
-  __shared__ DtLogEntry s_tab[DT_LOGTAB_N];
-  __shared__ uint32_t s_cnt[256];
-  dt_math_stage(G.tab, s_tab);
-  for (int chunk = blockIdx.x; chunk * 256 < ntiles; chunk += gridDim.x) {
-    const int mine = chunk * 256 + (int)threadIdx.x;
-    const uint32_t n = mine < ntiles ? G.fix_cnt[mine] : 0u;
-    __syncthreads();  // s_tab staged; the previous chunk's readers are done with s_cnt
-    s_cnt[threadIdx.x] = n;
-    if (!__syncthreads_or(n != 0u)) continue;
-    for (int i = 0; i < 256; i++) {
-      const uint32_t cnt = s_cnt[i];  // block-uniform
-      if (cnt == 0u) continue;
-      const int tile = chunk * 256 + i;
-      const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-      const unsigned long long *rec = G.fix_rec + (size_t)tile * NT;
-      for (uint32_t k = threadIdx.x; k < cnt; k += 256) {
-        const unsigned long long r = rec[k];
-        const uint32_t c = (uint32_t)r & 0xFFFu;
-        const long long o = (long long)(ty * TH + (int)(c / TW)) * w.ld + tx * TW + (int)(c % TW);
-        float g, l;
-        dt_gfi_both_cell(hand[o], (int32_t)(uint32_t)(r >> 32), acc32[o], G.expo, G.c0, s_tab, g, l);
-        G.gfi[o] = g;
-        G.lnhlh[o] = l;
-      }
-    }
-  }
-}
-
 struct FhScratch {
   unsigned long long *nodes, *cache;
   uint8_t *cache_wide;  // one flag per tile
-  unsigned long long *fix_rec;  // GFI fix-up queue, NT records per tile
-  uint32_t *fix_cnt;            // records queued per tile
   int64_t nnodes, ntiles, P;
   int tiles_x;
 };
@@ -1467,15 +1390,12 @@ static FhScratch fh_layout(const DtWin &w, void *scratch) {
   f.nodes = (unsigned long long *)scratch;
   f.cache = (unsigned long long *)((char *)scratch + dt_align256(((size_t)f.nnodes + (size_t)f.P) * 8));
   f.cache_wide = (uint8_t *)f.cache + dt_align256((size_t)f.ntiles * NT * 8) + 256;  // after the round flags
-  f.fix_cnt = (uint32_t *)(f.cache_wide + dt_align256((size_t)f.ntiles));
-  f.fix_rec = (unsigned long long *)((char *)f.fix_cnt + dt_align256((size_t)f.ntiles * 4));
   return f;
 }
 size_t dt_flowhand_tiled_scratch(int64_t H, int64_t W) {
   int64_t ntiles = ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
   return dt_align256(((size_t)ntiles * PS + (size_t)dt_perim_count((int)H, (int)W)) * 8) +
-         dt_align256((size_t)ntiles * NT * 8) + 256 + dt_align256((size_t)ntiles) +
-         dt_align256((size_t)ntiles * 4) + dt_align256((size_t)ntiles * NT * 8);
+         dt_align256((size_t)ntiles * NT * 8) + 256 + dt_align256((size_t)ntiles);
 }
 
 // phase 1: tile pass + perimeter node doubling (rank exits park on their ghosts)
@@ -1527,18 +1447,14 @@ int dt_launch_fh_finish(hipStream_t s, const DtWin &w, const float *dem, const u
     // nodes parked on a ghost point at it directly: pass 3 takes that one hop itself
   }
   FhRemote rem{rem_gidx, rem_zr, rem_ar};
-  FhGfi G{nullptr, nullptr, 0.0, 0.0, nullptr, nullptr, nullptr};
+  FhGfi G{nullptr, nullptr, 0.0, 0.0, nullptr};
   if (gfi && lnhlh) {
-    DT_REQUIRE(dem && acc32 && hand, "fused GFI needs dem, the accumulation raster and the HAND raster");
-    G = FhGfi{gfi, lnhlh, n_gfi, log(b_gfi) + n_gfi * log(size * size), dt_math_device_table(s), f.fix_rec, f.fix_cnt};
+    DT_REQUIRE(dem && acc32, "fused GFI needs dem and the accumulation raster");
+    G = FhGfi{gfi, lnhlh, n_gfi, log(b_gfi) + n_gfi * log(size * size), dt_math_device_table(s)};
   }
   (void)river;
   hipLaunchKernelGGL(k_fh_tile3, gt, b, 0, s, fdr, dem, acc32, w, f.tiles_x, (uint32_t)f.nnodes, f.nodes, f.cache,
                      f.cache_wide, rem, px, fdist, idx32, idx64, hand, a_river, G);
-  if (G.gfi) {
-    unsigned fb = (unsigned)((f.ntiles + 255) / 256 < 2048 ? (f.ntiles + 255) / 256 : 2048);
-    hipLaunchKernelGGL(k_fh_gfi_fix, dim3(fb), b, 0, s, hand, acc32, w, f.tiles_x, (int)f.ntiles, G);
-  }
   return DT_OK;
 }
 

@@ -165,8 +165,7 @@ int dt_dev_flowhand(dt_ctx *ctx, const float *dem, const uint8_t *fdr, const int
                     int32_t *idx32, float *hand, int32_t *a_river);
 /* the same plus GFI and ln(hl/H) (gfi.py:268-294, :404-440; size = px as in example.py:81-91) evaluated in the
  * last tile pass from the HAND / river accumulation it holds in registers: one pass over the rasters less than
- * dt_dev_flowhand + dt_dev_gfi_lnhlh.  a_river, fdist and idx32 may be NULL; hand is required (the few cells whose
- * logarithms need float64 are redone from it by a small second kernel). */
+ * dt_dev_flowhand + dt_dev_gfi_lnhlh.  a_river may be NULL. */
 int dt_dev_flowhand_gfi(dt_ctx *ctx, const float *dem, const uint8_t *fdr, const int8_t *river,
                         const int32_t *acc32, int64_t H, int64_t W, double px, double n_gfi, double b,
                         float *fdist, int32_t *idx32, float *hand, int32_t *a_river, float *gfi, float *lnhlh);
