@@ -1165,7 +1165,21 @@ struct FhRemote {  // payload of rank exits (multi-GPU), all indexed by core-rin
   const int32_t *ar;
 };
 
-__global__ __launch_bounds__(256, 6) void k_fh_tile3(const uint8_t *__restrict__ fdr,
+typedef float fh_v4f __attribute__((ext_vector_type(4)));
+typedef int fh_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void fh_store4(float *p, float a, float b, float c, float d) {
+  fh_v4f v = {a, b, c, d};
+  __builtin_nontemporal_store(v, reinterpret_cast<fh_v4f *>(p));
+}
+__device__ __forceinline__ void fh_store4(int32_t *p, int32_t a, int32_t b, int32_t c, int32_t d) {
+  fh_v4i v = {a, b, c, d};
+  __builtin_nontemporal_store(v, reinterpret_cast<fh_v4i *>(p));
+}
+
+// RANKED: the multi-GPU form (rank-exit payloads `rem`, ghost nodes, global int64 river indices); the
+// single-raster form leaves all of that out of the register budget
+template <bool RANKED, int VH, int MINW>
+__global__ __launch_bounds__(256, MINW) void k_fh_tile3(const uint8_t *__restrict__ fdr,
                                                  const float *__restrict__ dem,
                                                  const int32_t *__restrict__ acc32, DtWin w, int tiles_x,
                                                  uint32_t nnodes, const unsigned long long *__restrict__ nodes,
@@ -1180,6 +1194,8 @@ __global__ __launch_bounds__(256, 6) void k_fh_tile3(const uint8_t *__restrict__
   // 28 B/cell and needs the occupancy, not a 32 KiB per-cell table.
   __shared__ unsigned long long s_x[PS];
   __shared__ unsigned long long s_pay[PS];
+  __shared__ DtLogEntry s_tab[DT_LOGTAB_N];  // 2 KiB: the GFI epilogue's logarithm table
+  if (G.gfi) dt_math_stage(G.tab, s_tab);  // before the barrier every path below passes
   const int tile = blockIdx.x;
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int y0 = ty * TH, x0 = tx * TW;
@@ -1203,7 +1219,7 @@ __global__ __launch_bounds__(256, 6) void k_fh_tile3(const uint8_t *__restrict__
       unsigned long long ns = nodes[node];
       uint32_t nptr = (uint32_t)(ns >> 32), nnd = (uint32_t)((ns >> 16) & 0xFFFFu);
       uint32_t nncf = (uint32_t)(ns & 0xFFFFu);
-      if (!(nncf & FHT_DONE) && nptr >= nnodes && (size_t)nptr != node) {
+      if (RANKED && !(nncf & FHT_DONE) && nptr >= nnodes && (size_t)nptr != node) {
         // parked on the ghost of a rank exit (the local doubling left it pointing straight at it): one more
         // hop picks up what the rank-level solve wrote there
         unsigned long long gs = nodes[nptr];
@@ -1218,7 +1234,7 @@ __global__ __launch_bounds__(256, 6) void k_fh_tile3(const uint8_t *__restrict__
       // not done after all rounds == longer than the cap (or an unresolved rank exit)
       if ((nncf & FHT_DONE) && nptr != FHT_DEAD) {
         o = fht_pack(nptr, nnd + (diag ? 1u : 0u), ((nncf & 0x7FFFu) + (diag ? 0u : 1u)) | FHT_DONE);
-        if (nptr & FHT_REMOTE) {
+        if (RANKED && (nptr & FHT_REMOTE)) {
           zr = rem.zr[nptr & ~FHT_REMOTE];
           ar = rem.ar[nptr & ~FHT_REMOTE];
         } else {
@@ -1275,12 +1291,12 @@ __global__ __launch_bounds__(256, 6) void k_fh_tile3(const uint8_t *__restrict__
         }
       }
     }
-    const bool remote = ok && (ridx & FHT_REMOTE) != 0u;
+    const bool remote = RANKED && ok && (ridx & FHT_REMOTE) != 0u;
     CellOut o;
     o.fd = ok ? (float)(dcard * (double)nc + ddiag * (double)nd) : DT_NODATA;
     o.i32 = (ok && !remote) ? (int32_t)ridx : -100;
     o.i64 = -100;
-    if (idx64 && ok)
+    if (RANKED && idx64 && ok)
       o.i64 = remote ? rem.gidx[ridx & ~FHT_REMOTE]
                      : (long long)(w.gy0 + (int)(ridx / (uint32_t)w.W)) * w.Wg + w.gx0 + (int)(ridx % (uint32_t)w.W);
     o.h = DT_NODATA;
@@ -1296,7 +1312,7 @@ __global__ __launch_bounds__(256, 6) void k_fh_tile3(const uint8_t *__restrict__
   if (vec) {
     // 4 groups of 4 cells per lane, two at a time: 24 registers of loads in flight per lane and twice the
     // waves per SIMD instead of 48 and half of them
-    constexpr int VPT = NT / 4 / 256, VH = 2;
+    constexpr int VPT = NT / 4 / 256;
 #pragma unroll 1
     for (int h = 0; h < VPT / VH; h++) {
       uint4 wa[VH], wb[VH];
@@ -1330,24 +1346,30 @@ __global__ __launch_bounds__(256, 6) void k_fh_tile3(const uint8_t *__restrict__
         CellOut r1 = solve(((unsigned long long)wa[u].w << 32) | wa[u].z, z4[u].y);
         CellOut r2 = solve(((unsigned long long)wb[u].y << 32) | wb[u].x, z4[u].z);
         CellOut r3 = solve(((unsigned long long)wb[u].w << 32) | wb[u].z, z4[u].w);
-        if (fdist) *reinterpret_cast<float4 *>(fdist + o) = make_float4(r0.fd, r1.fd, r2.fd, r3.fd);
-        if (idx32) *reinterpret_cast<int4 *>(idx32 + o) = make_int4(r0.i32, r1.i32, r2.i32, r3.i32);
-        if (idx64) {
+        // every output byte is written once and not read again by this kernel: non-temporal stores
+        if (fdist) fh_store4(fdist + o, r0.fd, r1.fd, r2.fd, r3.fd);
+        if (idx32) fh_store4(idx32 + o, r0.i32, r1.i32, r2.i32, r3.i32);
+        if (RANKED && idx64) {
           *reinterpret_cast<longlong2 *>(idx64 + o) = make_longlong2(r0.i64, r1.i64);
           *reinterpret_cast<longlong2 *>(idx64 + o + 2) = make_longlong2(r2.i64, r3.i64);
         }
-        if (hand) *reinterpret_cast<float4 *>(hand + o) = make_float4(r0.h, r1.h, r2.h, r3.h);
-        if (a_river) *reinterpret_cast<int4 *>(a_river + o) = make_int4(r0.ar, r1.ar, r2.ar, r3.ar);
+        if (hand) fh_store4(hand + o, r0.h, r1.h, r2.h, r3.h);
+        if (a_river) fh_store4(a_river + o, r0.ar, r1.ar, r2.ar, r3.ar);
         if (G.gfi) {
           int4 f = *reinterpret_cast<const int4 *>(acc32 + o);  // own accumulation (aligned like the outputs)
           float4 g, l;
-          dt_gfi_both_cell(r0.h, r0.ar, f.x, G.expo, G.c0, G.tab, g.x, l.x);
-          dt_gfi_both_cell(r1.h, r1.ar, f.y, G.expo, G.c0, G.tab, g.y, l.y);
-          dt_gfi_both_cell(r2.h, r2.ar, f.z, G.expo, G.c0, G.tab, g.z, l.z);
-          dt_gfi_both_cell(r3.h, r3.ar, f.w, G.expo, G.c0, G.tab, g.w, l.w);
-          *reinterpret_cast<float4 *>(G.gfi + o) = g;
-          *reinterpret_cast<float4 *>(G.lnhlh + o) = l;
+          // one cell after the other (the scheduler would interleave the four float64 chains: 105 VGPRs)
+          dt_gfi_both_cell(r0.h, r0.ar, f.x, G.expo, G.c0, s_tab, g.x, l.x);
+          __builtin_amdgcn_sched_barrier(0);
+          dt_gfi_both_cell(r1.h, r1.ar, f.y, G.expo, G.c0, s_tab, g.y, l.y);
+          __builtin_amdgcn_sched_barrier(0);
+          dt_gfi_both_cell(r2.h, r2.ar, f.z, G.expo, G.c0, s_tab, g.z, l.z);
+          __builtin_amdgcn_sched_barrier(0);
+          dt_gfi_both_cell(r3.h, r3.ar, f.w, G.expo, G.c0, s_tab, g.w, l.w);
+          fh_store4(G.gfi + o, g.x, g.y, g.z, g.w);
+          fh_store4(G.lnhlh + o, l.x, l.y, l.z, l.w);
         }
+        __builtin_amdgcn_sched_barrier(0);  // finish this group of 4 cells before the next one starts
       }
     }
     return;
@@ -1363,12 +1385,12 @@ __global__ __launch_bounds__(256, 6) void k_fh_tile3(const uint8_t *__restrict__
     CellOut r = solve(fh_cache_get(cache, wide, tile, c), dem ? dem[o] : DT_NODATA);
     if (fdist) fdist[o] = r.fd;
     if (idx32) idx32[o] = r.i32;
-    if (idx64) idx64[o] = r.i64;
+    if (RANKED && idx64) idx64[o] = r.i64;
     if (hand) hand[o] = r.h;
     if (a_river) a_river[o] = r.ar;
     if (G.gfi) {
       float g, l;
-      dt_gfi_both_cell(r.h, r.ar, acc32[o], G.expo, G.c0, G.tab, g, l);
+      dt_gfi_both_cell(r.h, r.ar, acc32[o], G.expo, G.c0, s_tab, g, l);
       G.gfi[o] = g;
       G.lnhlh[o] = l;
     }
@@ -1453,8 +1475,12 @@ int dt_launch_fh_finish(hipStream_t s, const DtWin &w, const float *dem, const u
     G = FhGfi{gfi, lnhlh, n_gfi, log(b_gfi) + n_gfi * log(size * size), dt_math_device_table(s)};
   }
   (void)river;
-  hipLaunchKernelGGL(k_fh_tile3, gt, b, 0, s, fdr, dem, acc32, w, f.tiles_x, (uint32_t)f.nnodes, f.nodes, f.cache,
-                     f.cache_wide, rem, px, fdist, idx32, idx64, hand, a_river, G);
+  if (res_ok || idx64)
+    hipLaunchKernelGGL((k_fh_tile3<true, 1, 5>), gt, b, 0, s, fdr, dem, acc32, w, f.tiles_x, (uint32_t)f.nnodes, f.nodes,
+                       f.cache, f.cache_wide, rem, px, fdist, idx32, idx64, hand, a_river, G);
+  else
+    hipLaunchKernelGGL((k_fh_tile3<false, 1, 5>), gt, b, 0, s, fdr, dem, acc32, w, f.tiles_x, (uint32_t)f.nnodes, f.nodes,
+                       f.cache, f.cache_wide, rem, px, fdist, idx32, idx64, hand, a_river, G);
   return DT_OK;
 }
 
