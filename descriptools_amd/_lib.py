@@ -76,6 +76,11 @@ _SIGS = {
     "dt_dev_unique_extremes_f32": (ci, [vp, vp, i64, vp]),
     "dt_dev_minmax_scale_f32": (ci, [vp, vp, i64, C.c_float, C.c_float, C.c_float, vp]),
     "dt_dev_membench_copy": (ci, [vp, vp, vp, i64, ci]),
+    "dt_dev_minmax_scale_f32_f64": (ci, [vp, vp, i64, f64, f64, f64, vp]),
+    "dt_dev_classify": (ci, [vp, vp, vp, i64, f64, f64, ci, ci, vp, vp, vp]),
+    "dt_minmax_scale": (ci, [vp, ci, i64, f64, f64, f64, vp]),
+    "dt_binary_map": (ci, [vp, ci, i64, f64, f64, ci, c_u8p]),
+    "dt_avaliacao": (ci, [c_i32p, c_i8p, i64, c_i32p, c_i64p]),
     "dt_dev_flowhand_gfi": (ci, [vp, vp, vp, vp, vp, i64, i64, f64, f64, f64, vp, vp, vp, vp, vp, vp]),
     "dt_dev_flowhand_gfi_finish_w": (ci, [vp, vp, vp, vp, vp, vp, f64, f64, f64, vp, vp, vp, vp, vp,
                                           vp, vp, vp, vp, vp, vp, vp, vp]),

@@ -442,6 +442,27 @@ extern "C" int dt_dev_minmax_scale_f32(dt_ctx *c, const float *x, int64_t N, flo
   return DT_OK;
 }
 
+extern "C" int dt_dev_minmax_scale_f32_f64(dt_ctx *c, const float *x, int64_t N, double mn, double mx, double nodata,
+                                           double *desc) {
+  DT_CTX(c);
+  DT_REQUIRE((x && desc) || N == 0, "NULL raster");
+  DT_TRY(dt_launch_minmax_scale_f32f64(c->stream, x, N, mn, mx, nodata, desc));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+
+extern "C" int dt_dev_classify(dt_ctx *c, const double *desc, int8_t *flood, int64_t N, double nodata_value,
+                               double threshold, int under, int remap_flood, uint8_t *binary, int32_t *klass,
+                               int64_t *counts4_dev) {
+  DT_CTX(c);
+  DT_REQUIRE(counts4_dev != nullptr, "counts4 is NULL");
+  DT_REQUIRE((desc && flood) || N == 0, "NULL raster");
+  DT_TRY(dt_launch_classify_f64(c->stream, desc, nullptr, flood, N, nodata_value, threshold, under, remap_flood,
+                                binary, klass, (unsigned long long *)counts4_dev));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+
 extern "C" int dt_dev_membench_copy(dt_ctx *c, const float *a, float *b, int64_t N, int blocks) {
   DT_CTX(c);
   DT_REQUIRE(a && b && N >= 0 && blocks != 0, "bad arguments");
@@ -911,4 +932,78 @@ extern "C" int dt_confusion_multi(const double *desc, const int8_t *flood, int64
     DT_HIP(hipStreamSynchronize(c->stream));
   }
   return DT_OK;
+}
+
+// ---- evaluation.minMaxScale / binary_map / avaliacao, host tier --------------------------------------
+extern "C" int dt_minmax_scale(const void *x, int is_f32, int64_t N, double mn, double mx, double nodata, void *out) {
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  dt_ctx *c;
+  DT_TRY(host_ctx(&c));
+  DT_REQUIRE(N >= 0, "negative size");
+  if (N == 0) return DT_OK;
+  DT_REQUIRE(x && out, "NULL raster");
+  const size_t es = is_f32 ? 4 : 8, n = (size_t)N;
+  DevBuf d_x, d_o;
+  DT_TRY(d_x.alloc(n * es));
+  DT_TRY(d_o.alloc(n * es));
+  H2D(d_x, x, n * es, c);
+  if (is_f32) DT_TRY(dt_launch_minmax_scale_f32f32(c->stream, d_x.as<float>(), N, (float)mn, (float)mx, (float)nodata,
+                                                   d_o.as<float>()));
+  else DT_TRY(dt_launch_minmax_scale_f64(c->stream, d_x.as<double>(), N, mn, mx, nodata, d_o.as<double>()));
+  DT_HIP(hipGetLastError());
+  D2H(out, d_o, n * es, c);
+  return dt_ctx_sync(c);
+}
+
+extern "C" int dt_binary_map(const void *desc, int is_f32, int64_t N, double nodata_value, double threshold, int under,
+                             uint8_t *binary) {
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  dt_ctx *c;
+  DT_TRY(host_ctx(&c));
+  DT_REQUIRE(N >= 0, "negative size");
+  if (N == 0) return DT_OK;
+  DT_REQUIRE(desc && binary, "NULL raster");
+  const size_t es = is_f32 ? 4 : 8, n = (size_t)N;
+  DevBuf d_d, d_f, d_b, d_c;
+  DT_TRY(d_d.alloc(n * es));
+  DT_TRY(d_f.alloc(n));
+  DT_TRY(d_b.alloc(n));
+  DT_TRY(d_c.alloc(4 * sizeof(int64_t)));
+  H2D(d_d, desc, n * es, c);
+  DT_HIP(hipMemsetAsync(d_f.p, 0, n, c->stream));
+  if (is_f32) DT_TRY(dt_launch_classify_f32(c->stream, d_d.as<float>(), nullptr, d_f.as<int8_t>(), N, (float)nodata_value,
+                                            (float)threshold, under, 0, d_b.as<uint8_t>(), nullptr,
+                                            d_c.as<unsigned long long>()));
+  else DT_TRY(dt_launch_classify_f64(c->stream, d_d.as<double>(), nullptr, d_f.as<int8_t>(), N, nodata_value, threshold,
+                                     under, 0, d_b.as<uint8_t>(), nullptr, d_c.as<unsigned long long>()));
+  DT_HIP(hipGetLastError());
+  D2H(binary, d_b, n, c);
+  return dt_ctx_sync(c);
+}
+
+extern "C" int dt_avaliacao(const int32_t *binary, int8_t *flood, int64_t N, int32_t *klass, int64_t *counts4) {
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  dt_ctx *c;
+  DT_TRY(host_ctx(&c));
+  DT_REQUIRE(N >= 0 && counts4, "bad arguments");
+  const size_t n = (size_t)N;
+  DevBuf d_b, d_f, d_k, d_c;
+  DT_TRY(d_b.alloc(n * 4));
+  DT_TRY(d_f.alloc(n));
+  DT_TRY(d_k.alloc(n * 4));
+  DT_TRY(d_c.alloc(4 * sizeof(int64_t)));
+  if (n) {
+    DT_REQUIRE(binary && flood, "NULL raster");
+    H2D(d_b, binary, n * 4, c);
+    H2D(d_f, flood, n, c);
+  }
+  DT_TRY(dt_launch_classify_f64(c->stream, nullptr, d_b.as<int32_t>(), d_f.as<int8_t>(), N, 0.0, 0.0, 0, 1, nullptr,
+                                klass ? d_k.as<int32_t>() : nullptr, d_c.as<unsigned long long>()));
+  DT_HIP(hipGetLastError());
+  if (n) {
+    D2H(flood, d_f, n, c);  // the benchmark map comes back remapped (evaluation.py:149-150 mutates it)
+    if (klass) D2H(klass, d_k, n * 4, c);
+  }
+  D2H(counts4, d_c, 4 * sizeof(int64_t), c);
+  return dt_ctx_sync(c);
 }

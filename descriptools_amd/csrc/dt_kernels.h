@@ -62,6 +62,18 @@ int dt_launch_gfi_both(hipStream_t s, const float *hand, const int32_t *a_river,
 int dt_launch_unique_extremes(hipStream_t s, const float *x, int64_t n, uint32_t *work4, float *out3);
 int dt_launch_minmax_scale(hipStream_t s, const float *x, int64_t n, float mn, float mx, float nodata,
                            double *out);
+int dt_launch_minmax_scale_f32f32(hipStream_t s, const float *x, int64_t n, float mn, float mx, float nodata,
+                                  float *out);
+int dt_launch_minmax_scale_f64(hipStream_t s, const double *x, int64_t n, double mn, double mx, double nodata,
+                               double *out);
+int dt_launch_minmax_scale_f32f64(hipStream_t s, const float *x, int64_t n, double mn, double mx, double nodata,
+                                  double *out);
+int dt_launch_classify_f64(hipStream_t s, const double *desc, const int32_t *bin_in, int8_t *flood, int64_t n,
+                           double nodata, double th, int under, int remap, uint8_t *binary, int32_t *klass,
+                           unsigned long long *counts4);
+int dt_launch_classify_f32(hipStream_t s, const float *desc, const int32_t *bin_in, int8_t *flood, int64_t n,
+                           float nodata, float th, int under, int remap, uint8_t *binary, int32_t *klass,
+                           unsigned long long *counts4);
 int dt_launch_membench_copy(hipStream_t s, const float *a, float *b, int64_t n, int blocks);
 // rank-level solves on all-gathered summary rows (multi-GPU)
 size_t dt_rank_solve_scratch(int nranks, int64_t Pmax);

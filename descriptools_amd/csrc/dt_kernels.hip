@@ -996,6 +996,104 @@ int dt_launch_minmax_scale(hipStream_t s, const float *x, int64_t n, float mn, f
   return DT_OK;
 }
 
+// ===========================================================================================
+// evaluation.minMaxScale / binary_map / avaliacao as kernels (E1-E3, evaluation.py:5-9, 90-123, 126-171)
+// ===========================================================================================
+// minMaxScale in the arithmetic numpy would use for the raster's dtype (T = float for a float32 raster,
+// double for integer / float64 rasters): NaN where x == nodata or x is NaN, else (x - mn) / (mx - mn)
+template <typename TI, typename T>
+__global__ __launch_bounds__(256) void k_minmax_scale_t(const TI *__restrict__ x, int64_t n, T mn, T mx, T nodata,
+                                                       T *__restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  T v = (T)x[i];
+  out[i] = (v == nodata || v != v) ? (T)NAN : (v - mn) / (mx - mn);
+}
+int dt_launch_minmax_scale_f32f32(hipStream_t s, const float *x, int64_t n, float mn, float mx, float nodata,
+                                  float *out) {
+  if (n) hipLaunchKernelGGL((k_minmax_scale_t<float, float>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n,
+                            mn, mx, nodata, out);
+  return DT_OK;
+}
+int dt_launch_minmax_scale_f64(hipStream_t s, const double *x, int64_t n, double mn, double mx, double nodata,
+                               double *out) {
+  if (n) hipLaunchKernelGGL((k_minmax_scale_t<double, double>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x,
+                            n, mn, mx, nodata, out);
+  return DT_OK;
+}
+// float32 raster scaled in float64 (an integer-valued HAND kept as float32 on the device: numpy scales the
+// example's int16 HAND in float64)
+int dt_launch_minmax_scale_f32f64(hipStream_t s, const float *x, int64_t n, double mn, double mx, double nodata,
+                                  double *out) {
+  if (n) hipLaunchKernelGGL((k_minmax_scale_t<float, double>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x,
+                            n, mn, mx, nodata, out);
+  return DT_OK;
+}
+
+// One pass over a descriptor and a benchmark flood map at ONE threshold (what Example/example.py:139-147 does
+// with binary_map + avaliacao): optional outputs
+//   binary[i]  = 1 where the descriptor is on the flooded side of the threshold, 0 where it is not, is NaN or
+//                equals `nodata` (the caller passes desc[0, 0], evaluation.py:111)
+//   flood[i]   remapped in place 1 -> 2, -100 -> 0 (evaluation.py:149-150) when `remap` is set
+//   klass[i]   = binary + remapped flood (evaluation.py:151)
+//   counts4[v] = number of cells of class v = 0..3
+// With bin_in the binary map is an input (avaliacao on its own), desc is not read.
+template <typename T>
+__global__ __launch_bounds__(256) void k_classify(const T *__restrict__ desc, const int32_t *__restrict__ bin_in,
+                                                 int8_t *__restrict__ flood, int64_t n, T nodata, T th, int under,
+                                                 int remap, uint8_t *__restrict__ binary,
+                                                 int32_t *__restrict__ klass,
+                                                 unsigned long long *__restrict__ counts4) {
+  unsigned int cnt[4] = {0u, 0u, 0u, 0u};
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    int b;
+    if (bin_in) {
+      b = bin_in[i];
+    } else {
+      const T v = desc[i];
+      const bool on = under ? (v <= th) : (v >= th);  // false for NaN
+      b = (on && !(v == nodata)) ? 1 : 0;
+    }
+    int g = flood[i];
+    if (g == 1) g = 2;
+    else if (g == -100) g = 0;
+    if (remap) flood[i] = (int8_t)g;
+    const int r = b + g;
+    if (binary) binary[i] = (uint8_t)b;
+    if (klass) klass[i] = r;
+    if (r >= 0 && r <= 3) cnt[r]++;
+  }
+#pragma unroll
+  for (int v = 0; v < 4; v++) {
+    unsigned int c = cnt[v];
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&counts4[v], (unsigned long long)c);
+  }
+}
+template <typename T>
+static int dt_launch_classify_t(hipStream_t s, const T *desc, const int32_t *bin_in, int8_t *flood, int64_t n,
+                                T nodata, T th, int under, int remap, uint8_t *binary, int32_t *klass,
+                                unsigned long long *counts4) {
+  DT_HIP(hipMemsetAsync(counts4, 0, 4 * sizeof(unsigned long long), s));
+  if (n == 0) return DT_OK;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_classify<T>, dim3((unsigned)blocks), dim3(256), 0, s, desc, bin_in, flood, n, nodata, th, under,
+                     remap, binary, klass, counts4);
+  return DT_OK;
+}
+int dt_launch_classify_f64(hipStream_t s, const double *desc, const int32_t *bin_in, int8_t *flood, int64_t n,
+                           double nodata, double th, int under, int remap, uint8_t *binary, int32_t *klass,
+                           unsigned long long *counts4) {
+  return dt_launch_classify_t<double>(s, desc, bin_in, flood, n, nodata, th, under, remap, binary, klass, counts4);
+}
+int dt_launch_classify_f32(hipStream_t s, const float *desc, const int32_t *bin_in, int8_t *flood, int64_t n,
+                           float nodata, float th, int under, int remap, uint8_t *binary, int32_t *klass,
+                           unsigned long long *counts4) {
+  return dt_launch_classify_t<float>(s, desc, bin_in, flood, n, nodata, th, under, remap, binary, klass, counts4);
+}
+
 // ---- HBM copy micro-benchmark (the practical bandwidth ceiling the roofline fractions compare with) ----
 template <int UNROLL>
 __global__ __launch_bounds__(256) void k_membench_copy(const float4 *__restrict__ a, float4 *__restrict__ b,

@@ -127,6 +127,17 @@ int dt_downslope(const float *dem, const uint8_t *fdr, int64_t H, int64_t W, dou
 int dt_confusion_multi(const double *desc, const int8_t *flood, int64_t N, double nodata_value,
                        const double *th, int nth, int under, int64_t *counts4);
 
+/* evaluation.minMaxScale (evaluation.py:5-9): out = NaN where x == nodata or x is NaN, else (x - mn) / (mx - mn),
+ * in float32 for a float32 raster (is_f32) and float64 otherwise -- numpy's arithmetic for those dtypes. */
+int dt_minmax_scale(const void *x, int is_f32, int64_t N, double mn, double mx, double nodata, void *out);
+/* evaluation.binary_map (evaluation.py:90-123): binary = 1 where desc <= threshold ('under') or >= threshold,
+ * 0 elsewhere, where desc is NaN and where desc == nodata_value (the caller passes desc[0, 0], :111). */
+int dt_binary_map(const void *desc, int is_f32, int64_t N, double nodata_value, double threshold, int under,
+                  uint8_t *binary);
+/* evaluation.avaliacao (evaluation.py:126-171): flood is remapped IN PLACE (1 -> 2, -100 -> 0, :149-150),
+ * klass (may be NULL) = binary + flood, counts4[v] = cells of class v = 0..3. */
+int dt_avaliacao(const int32_t *binary, int8_t *flood, int64_t N, int32_t *klass, int64_t *counts4);
+
 /* Synthetic "tilted integer fBm" DEM window, bit-identical to the oracle's. */
 int dt_synth_dem(uint32_t seed, int64_t Hg, int64_t Wg, int64_t y0, int64_t x0, int64_t h,
                  int64_t w, int nodata_pct, float *out);
@@ -235,6 +246,16 @@ int dt_dev_unique_extremes_f32(dt_ctx *ctx, const float *x, int64_t N, float *ou
  * NaN where x == nodata, written as the float64 raster dt_dev_confusion_multi reads. */
 int dt_dev_minmax_scale_f32(dt_ctx *ctx, const float *x, int64_t N, float mn, float mx, float nodata,
                             double *desc);
+
+/* the same for an integer-valued raster kept as float32 on the device (the example's int16 HAND): float64
+ * arithmetic, as numpy scales integer rasters */
+int dt_dev_minmax_scale_f32_f64(dt_ctx *ctx, const float *x, int64_t N, double mn, double mx, double nodata,
+                                double *desc);
+/* binary_map + avaliacao at one threshold on resident rasters (Example/example.py:139-147): binary (may be NULL),
+ * klass = binary + remapped flood (may be NULL), counts4_dev[v] = cells of class v; remap_flood != 0 rewrites the
+ * benchmark map in place (1 -> 2, -100 -> 0) as avaliacao does. */
+int dt_dev_classify(dt_ctx *ctx, const double *desc, int8_t *flood, int64_t N, double nodata_value, double threshold,
+                    int under, int remap_flood, uint8_t *binary, int32_t *klass, int64_t *counts4_dev);
 
 /* Device-to-device copy of N floats, the practical HBM ceiling the roofline fractions are put beside:
  * blocks > 0: float4 grid-stride copy with that many workgroups; blocks < 0: the buffer walked as rows of 16384

@@ -73,22 +73,20 @@ def test_helpers_divisor_matches_golden():
     assert r.size == 0 and c.size == 0
 
 
-def test_evaluation_host_functions_match_golden():
-    """minMaxScale / binary_map / avaliacao keep the reference's numpy semantics (no GPU needed)."""
-    from conftest import golden
-    from descriptools_amd import evaluation
-    g = golden("eval")
-    for k in range(3):
-        under = str(g["e%d_under" % k])
-        desc = evaluation.minMaxScale(g["e%d_hand" % k], g["e%d_mn" % k], g["e%d_mx" % k], -100)
-        assert np.array_equal(desc, g["e%d_desc" % k], equal_nan=True)
-        binary = evaluation.binary_map(desc, float(g["e%d_th" % k]), under)
-        assert np.array_equal(binary, g["e%d_binary" % k])
-        flood = g["e%d_flood" % k].copy()
-        c, f, cm = evaluation.avaliacao(binary, flood)
-        assert c == float(g["e%d_c" % k]) and f == float(g["e%d_f" % k])
-        assert np.array_equal(cm, g["e%d_class" % k])
-        assert np.array_equal(flood, g["e%d_flood_after" % k])
+def test_evaluation_has_no_cpu_path_either():
+    """minMaxScale / binary_map / avaliacao are kernels behind the C ABI like every other descriptor (their
+    goldens are checked on the GPU, tests/test_gpu_parity.py::test_golden_eval); the pure index formulas are not."""
+    from descriptools_amd import _lib, evaluation
+    assert evaluation.correctness(np.array([5, 1, 2, 6])) == 6 / 8
+    assert evaluation.fit(np.array([5, 1, 2, 6])) == 6 / 9
+    if _lib.lib().dt_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(RuntimeError):
+        evaluation.minMaxScale(np.ones((4, 4), np.float32), 0, 1, -100)
+    with pytest.raises(RuntimeError):
+        evaluation.binary_map(np.ones((4, 4)), 0.5, 'under')
+    with pytest.raises(RuntimeError):
+        evaluation.avaliacao(np.ones((4, 4), np.int64), np.ones((4, 4), np.int8))
 
 
 def test_python_api_mirrors_reference_names():

@@ -141,6 +141,18 @@ def test_golden_eval(dt):
         c, f, cm = dt.evaluation.avaliacao(binary, flood)
         assert c == float(g["e%d_c" % k]) and f == float(g["e%d_f" % k])
         assert np.array_equal(cm, g["e%d_class" % k])
+        # numpy's dtypes for these expressions: an int16 raster scales in float64, np.where(..., 1, 0) is int64
+        assert desc.dtype == np.float64 and binary.dtype == np.int64 and cm.dtype == np.int64
+        d32 = dt.evaluation.minMaxScale(g["e%d_hand" % k].astype(np.float32), np.float32(g["e%d_mn" % k]),
+                                        np.float32(g["e%d_mx" % k]), -100)
+        h32 = g["e%d_hand" % k].astype(np.float32)
+        want = np.where(h32 == -100, np.nan, (h32 - np.float32(g["e%d_mn" % k])) /
+                        (np.float32(g["e%d_mx" % k]) - np.float32(g["e%d_mn" % k]))).astype(np.float32)
+        assert d32.dtype == np.float32 and np.array_equal(d32, want, equal_nan=True), "float32 rasters scale in float32"
+        # avaliacao on a fresh copy of the benchmark map remaps that copy in place (evaluation.py:149-150)
+        fresh = g["e%d_flood" % k].copy()
+        c2, f2, cm2 = dt.evaluation.avaliacao(binary, fresh)
+        assert (c2, f2) == (c, f) and np.array_equal(cm2, cm) and np.array_equal(fresh, g["e%d_flood_after" % k])
 
 
 @pytest.mark.parametrize("seed,H,W,nod", [(1, 257, 300, 0), (2, 512, 512, 4), (3, 1000, 1536, 0),
