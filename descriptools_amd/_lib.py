@@ -32,6 +32,7 @@ _SIGS = {
     "dt_ctx_set_stream": (ci, [vp, vp]),
     "dt_ctx_stream": (vp, [vp]),
     "dt_ctx_sync": (ci, [vp]),
+    "dt_ctx_status": (ci, [vp, c_i32p]),
     "dt_ctx_scratch_bytes": (i64, [vp]),
     # host tier
     "dt_slope_f32": (ci, [c_f32p, i64, i64, f64, c_f32p]),

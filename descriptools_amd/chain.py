@@ -2,6 +2,8 @@
 mask -> flow distance / river index / HAND -> TI / MTI -> GFI -> ln(hl/H) -> downslope, every raster
 staying in HBM between steps (the reference round-trips each descriptor through the host,
 Example/example.py:59-91).  Parameters default to the example's (n_top 0.1, n_gfi 0.4, b 0.1, dz 5)."""
+import ctypes as C
+
 import numpy as np
 
 from . import _lib
@@ -17,6 +19,21 @@ OUTPUTS = (("slope", F32), ("fdr", U8), ("fac", I32), ("river", I8), ("fdist", F
 # Unfused algorithmic bytes per cell of the chain: slope 8, D8 5, flow-acc 5, river
 # mask 5, HAND 18, TI+MTI 16, GFI 12, ln(hl/H) 12, downslope 9.
 ALGO_BYTES_PER_CELL = 90
+
+# The ops of one step in launch order: (name, compulsory bytes per cell of the op AS FUSED HERE, kernels behind it
+# as rocprofv3 names them).  HAND + GFI + ln(hl/H) is one fused op issued as its two phases (the windowed entry
+# points with the whole raster as the window -- the same kernels as dt_dev_flowhand_gfi plus a 5 us ring summary)
+# so that its last pass, one kernel, has a duration of its own: phase 1 reads fdr 1 + river 1, the last pass reads
+# dem 4 + fac 4 and writes fdist, idx, hand, gfi, lnhlh (20).  "d8" writes fdr only: slope comes out of the fused
+# slope+TI+MTI stencil (dem 4 + fac 4 read, slope 4 + TI 4 + MTI 4 written = the north_star's 20 B/cell).
+OPS = (
+    ("d8", 5, ["k_stencil<false, true, false>"]),
+    ("downslope", 9, ["k_downslope_win"]),
+    ("flowacc_river", 5 + 1, ["k_fa_tile1", "k_fa_reduce", "k_fa_poison", "k_fa_tile3<true, true>"]),
+    ("flowhand_local", 2, ["k_fh_tile1n", "k_fh_tile1", "k_fh_ghost_init", "k_fh_node_jump", "k_fh_rank_summary"]),
+    ("flowhand_gfi_finish", 28, ["k_fh_tile3<false, 1, 5>"]),
+    ("slope_twi", 20, ["k_slope_twi<true, false, true>", "k_slope_twi_fix"]),
+)
 
 
 class Chain:
@@ -45,35 +62,53 @@ class Chain:
         b = self.buf[name]
         return b.ptr if hasattr(b, "ptr") else b
 
-    def run(self, dem_ptr):
-        """Enqueue the whole chain (asynchronous).  Downslope needs only the DEM and the D8 codes, and the
-        flow-accumulation / HAND kernels are latency chains that leave most of the GPU idle, so it runs as a
-        second branch on the side context's stream between the D8 kernel and the end of the chain."""
-        L, c, H, W, N = _lib.lib(), self.ctx.h, self.H, self.W, self.N
+    def ops(self, dem_ptr, want_a_river=False):
+        """The step as a list of (name, context, call) in launch order -- THE definition of the chain: run()
+        executes it, bench.py times it op by op.  With `overlap` the downslope op belongs to the side context
+        (forked after D8, joined at the end by run())."""
+        L, c, H, W = _lib.lib(), self.ctx, self.H, self.W
         p = self.p
-        check(L.dt_dev_slope_d8(c, dem_ptr, H, W, self.px, None, p("fdr"), None))
-        if self.side is not None:
-            self.ctx.fork(self.side)
-            check(L.dt_dev_downslope(self.side.h, dem_ptr, p("fdr"), H, W, self.px, self.dz, 0, p("down")))
-        check(L.dt_dev_flowacc_river(c, p("fdr"), dem_ptr, H, W, self.river_threshold, p("fac"), p("river")))
-        # HAND with GFI and ln(hl/H) evaluated in its last tile pass (one pass over the rasters less)
-        check(L.dt_dev_flowhand_gfi(c, dem_ptr, p("fdr"), p("river"), p("fac"), H, W, self.px, self.n_gfi, self.b,
-                                    p("fdist"), p("idx"), p("hand"), p("a_river"), p("gfi"), p("lnhlh")))
-        check(L.dt_dev_slope_twi(c, dem_ptr, p("fac"), H, W, self.px, self.n_top, p("slope"),
-                                 p("slope_rad") if self.want_slope_rad else None, p("ti"), p("mti")))
+        side = self.side if self.side is not None else c
+        if getattr(self, "_ring", None) is None:
+            P = max(int(L.dt_perim_cells(H, W)), 1)
+            self._full = _lib.Window(H, W, W, 0, 0, H, W, 0)
+            self._ring = [c.empty(P, dt) for dt in (np.uint8, np.int32, np.int32, np.int32, np.float32, np.int32)]
+        full, ring = self._full, [r.ptr for r in self._ring]
+        rad = p("slope_rad") if self.want_slope_rad else None
+        return [
+            ("d8", c, lambda: L.dt_dev_slope_d8(c.h, dem_ptr, H, W, self.px, None, p("fdr"), None)),
+            ("downslope", side, lambda: L.dt_dev_downslope(side.h, dem_ptr, p("fdr"), H, W, self.px, self.dz, 0,
+                                                           p("down"))),
+            ("flowacc_river", c, lambda: L.dt_dev_flowacc_river(c.h, p("fdr"), dem_ptr, H, W, self.river_threshold,
+                                                                p("fac"), p("river"))),
+            ("flowhand_local", c, lambda: L.dt_dev_flowhand_local_w(c.h, C.byref(full), dem_ptr, p("fdr"), p("river"),
+                                                                    p("fac"), *ring)),
+            ("flowhand_gfi_finish", c, lambda: L.dt_dev_flowhand_gfi_finish_w(
+                c.h, C.byref(full), dem_ptr, p("fdr"), p("river"), p("fac"), self.px, self.n_gfi, self.b, None, None,
+                None, None, None, None, p("fdist"), p("idx"), None, p("hand"),
+                p("a_river") if want_a_river else None, p("gfi"), p("lnhlh"))),
+            ("slope_twi", c, lambda: L.dt_dev_slope_twi(c.h, dem_ptr, p("fac"), H, W, self.px, self.n_top, p("slope"),
+                                                        rad, p("ti"), p("mti"))),
+        ]
+
+    def run(self, dem_ptr, want_a_river=True):
+        """Enqueue the whole chain (asynchronous).  Downslope needs only the DEM and the D8 codes: with `overlap` it
+        runs as a second branch on the side context's stream between the D8 kernel and the end of the chain."""
+        for name, ctx, call in self.ops(dem_ptr, want_a_river):
+            if name == "downslope" and self.side is not None:
+                self.ctx.fork(self.side)
+            check(call())
         if self.side is not None:
             self.ctx.join(self.side)
-        else:
-            check(L.dt_dev_downslope(c, dem_ptr, p("fdr"), H, W, self.px, self.dz, 0, p("down")))
 
     def free(self):
         if self._own_side:
             self.side.close()
             self.side, self._own_side = None, False
-        for b in self.buf.values():
+        for b in list(self.buf.values()) + list(getattr(self, "_ring", None) or []):
             if hasattr(b, "free"):
                 b.free()
-        self.buf = {}
+        self.buf, self._ring = {}, None
 
 
 def run_host(dem, px, **kw):

@@ -52,6 +52,12 @@ extern "C" int dt_ctx_create(int device, void *stream, dt_ctx **out) {
   c->ev = nullptr;
   c->aux = nullptr;
   c->aux_bytes = 0;
+  c->status = nullptr;
+  if (hipMalloc((void **)&c->status, 64) != hipSuccess || hipMemset(c->status, 0, 64) != hipSuccess) {
+    dt_set_error("cannot allocate the context's status word");
+    delete c;
+    return DT_ENOMEM;
+  }
   if (stream) {
     c->stream = (hipStream_t)stream;
     c->own_stream = false;
@@ -75,6 +81,7 @@ extern "C" int dt_ctx_destroy(dt_ctx *c) {
   if (c->scratch) (void)hipFree(c->scratch);
   if (c->scratch2) (void)hipFree(c->scratch2);
   if (c->aux) (void)hipFree(c->aux);
+  if (c->status) (void)hipFree(c->status);
   if (c->ev) (void)hipEventDestroy(c->ev);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -111,6 +118,16 @@ extern "C" int dt_ctx_fork(dt_ctx *parent, dt_ctx *child) { return dt_ctx_order(
 extern "C" int dt_ctx_join(dt_ctx *parent, dt_ctx *child) { return dt_ctx_order(child, parent); }
 extern "C" int dt_ctx_sync(dt_ctx *c) {
   DT_REQUIRE(c != nullptr, "ctx is NULL");
+  DT_HIP(hipStreamSynchronize(c->stream));
+  return DT_OK;
+}
+// sticky status bits raised by kernels since the last call (synchronises the stream); bit 0: a flow accumulation
+// value of a multi-rank raster may have reached 2^31 and does not fit the int32 accumulation rasters
+extern "C" int dt_ctx_status(dt_ctx *c, int32_t *out) {
+  DT_REQUIRE(c != nullptr && out != nullptr, "NULL argument");
+  DT_HIP(hipSetDevice(c->device));
+  DT_HIP(hipMemcpyAsync(out, c->status, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  DT_HIP(hipMemsetAsync(c->status, 0, sizeof(int32_t), c->stream));
   DT_HIP(hipStreamSynchronize(c->stream));
   return DT_OK;
 }
@@ -548,7 +565,7 @@ extern "C" int dt_dev_flowacc_finish_w(dt_ctx *c, const dt_window *win, const ui
   DT_REQUIRE(fdr && acc32, "NULL raster");
   DT_REQUIRE(c->scratch && c->scratch_bytes >= dt_flowacc_tiled_scratch(w.H, w.W), "no local phase before finish");
   DT_TRY(dt_launch_fa_finish(c->stream, w, fdr, dem, c->scratch, (const unsigned long long *)ext_perim, threshold,
-                             acc32, river));
+                             acc32, river, c->status));
   DT_HIP(hipGetLastError());
   return DT_OK;
 }

@@ -51,6 +51,7 @@ struct dt_ctx {
   char *scratch2;       // rank-level solves (must not disturb the two-phase tile scratch)
   size_t scratch2_bytes;
   hipEvent_t ev;        // fork / join with another context's stream (created on first use)
+  int *status;          // device word of sticky DT_STATUS_* bits raised by kernels (dt_ctx_status reads and clears)
   char *aux;            // workspace of the fused slope + TI + MTI stencil (it runs between the two phases of
   size_t aux_bytes;     // the tile kernels in a multi-GPU step, so it must not touch `scratch`)
 };

@@ -45,7 +45,7 @@ int dt_launch_fa_local(hipStream_t s, const DtWin &w, const uint8_t *fdr, void *
 int dt_launch_fa_summary(hipStream_t s, const DtWin &w, void *scratch, int64_t *A, int32_t *xr, uint8_t *code);
 int dt_launch_fa_finish(hipStream_t s, const DtWin &w, const uint8_t *fdr, const float *dem, void *scratch,
                         const unsigned long long *ext_perim, int64_t river_thr, int32_t *acc32,
-                        int8_t *river);
+                        int8_t *river, int *status = nullptr);
 size_t dt_flowhand_tiled_scratch(int64_t H, int64_t W);
 int dt_launch_fh_local(hipStream_t s, const DtWin &w, const uint8_t *fdr, const int8_t *river, void *scratch,
                        size_t scratch_bytes);

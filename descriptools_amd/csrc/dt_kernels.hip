@@ -362,16 +362,10 @@ __global__ __launch_bounds__(256) void k_gfi(const float *__restrict__ hand,
     return;
   }
   IT ar = area[i];
-  if (h > -0.005f && ar >= 0 && (ar > 0 || OWN_CELL)) {  // float32 fast path (dt_math.h)
-    double la = ar == 0 ? 0.0 : dt_lnf((float)ar);
-    double r = c0 + expo * la - dt_lnf((float)((double)h + 0.01));
-    if (fabs(r) >= DT_FAST_MIN) {
-      out[i] = (float)r;
-      return;
-    }
-  }
-  double la = (OWN_CELL && ar == 0) ? 0.0 : dt_fast_log((double)ar, s_tab);
-  out[i] = (float)(c0 + expo * la - dt_fast_log((double)h + 0.01, s_tab));
+  // float64 table logarithms on the exactly converted integer area (dt_math.h): the index crosses zero inside
+  // ordinary terrain, where a relative tolerance leaves no room for a float32 fast path
+  double la = (OWN_CELL && ar == 0) ? 0.0 : dt_log_sel((double)ar, s_tab);
+  out[i] = (float)(c0 + expo * la - dt_log_sel((double)h + 0.01, s_tab));
 }
 // 4 cells per thread with 16-byte loads / stores, grid-stride (the table is staged once per workgroup)
 __global__ __launch_bounds__(256) void k_gfi_both(const float *__restrict__ hand,

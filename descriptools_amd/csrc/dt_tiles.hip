@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256, 6) void k_fa_tile3(const uint8_t *__restrict__
                                                     const unsigned long long *__restrict__ ext,
                                                     const uint16_t *__restrict__ loc16,
                                                     int32_t *__restrict__ acc32, int32_t river_thr,
-                                                    int8_t *__restrict__ river) {
+                                                    int8_t *__restrict__ river, int *__restrict__ status) {
   // 24 KiB of LDS: six tiles per CU (the kernel is a latency chain of LDS walks).  The direction codes are
   // staged through the delta array; bit 31 of a delta (real inflow < 2^31) marks the cells of a cycle
   // spanning tiles.
@@ -398,7 +398,18 @@ __global__ __launch_bounds__(256, 6) void k_fa_tile3(const uint8_t *__restrict__
   dt_tile_load_fdr(fdr, w, y0, x0, s_fdr);
   unsigned long long e = 0ull;
   if (threadIdx.x < PS) e = ext[(size_t)tile * PS + threadIdx.x];
-  __syncthreads();
+  // The accumulation raster is int32 (a device tile has < 2^31 cells), but across ranks a basin can reach 2^31
+  // cells.  No value of this tile can exceed the inflow entering it plus its own 4096 cells: a tile whose entries
+  // bring in >= 2^31 - 4096 in total raises the context's overflow status (dt_ctx_status) instead of wrapping
+  // silently.  Only such a tile pays for the 64-bit sum.
+  if (__syncthreads_or(!(e & FA_CYCLE) && FA_VALUE(e) >= (1ull << 22))) {
+    __shared__ unsigned long long s_in;
+    if (threadIdx.x == 0) s_in = 0ull;
+    __syncthreads();
+    if (e != 0ull && !(e & FA_CYCLE)) atomicAdd(&s_in, FA_VALUE(e));
+    __syncthreads();
+    if (threadIdx.x == 0 && s_in >= (1ull << 31) - (unsigned long long)NT && status) atomicOr(status, DT_STATUS_ACC_OVERFLOW);
+  }
   uint32_t nx[CPT];
   if (dt_tile_interior(w, y0, x0)) {
 #pragma unroll
@@ -651,7 +662,7 @@ int dt_launch_fa_summary(hipStream_t s, const DtWin &w, void *scratch, int64_t *
 // (dt_launch_fa_local with rank_level), then the final tile pass.
 int dt_launch_fa_finish(hipStream_t s, const DtWin &w, const uint8_t *fdr, const float *dem, void *scratch,
                         const unsigned long long *ext_perim, int64_t river_thr, int32_t *acc32,
-                        int8_t *river) {
+                        int8_t *river, int *status) {
   if (w.H == 0 || w.W == 0) return DT_OK;
   FaScratch f = fa_layout(w, scratch);
   dim3 gt((unsigned)f.ntiles), b(256), gn((unsigned)((f.nnodes + 255) / 256));
@@ -662,10 +673,10 @@ int dt_launch_fa_finish(hipStream_t s, const DtWin &w, const uint8_t *fdr, const
   }
   hipLaunchKernelGGL(k_fa_poison, gn, b, 0, s, f.rec, f.nnodes, f.entry_of, f.state, f.ext);
   int32_t thr = river_thr > 2147483647ll ? 2147483647 : (river_thr < -2147483647ll ? -2147483647 : (int32_t)river_thr);
-  if (dem && river) hipLaunchKernelGGL((k_fa_tile3<true, true>), gt, b, 0, s, fdr, dem, w, f.tiles_x, f.ext, f.loc16, acc32, thr, river);
-  else if (dem) hipLaunchKernelGGL((k_fa_tile3<true, false>), gt, b, 0, s, fdr, dem, w, f.tiles_x, f.ext, f.loc16, acc32, thr, river);
-  else if (river) hipLaunchKernelGGL((k_fa_tile3<false, true>), gt, b, 0, s, fdr, dem, w, f.tiles_x, f.ext, f.loc16, acc32, thr, river);
-  else hipLaunchKernelGGL((k_fa_tile3<false, false>), gt, b, 0, s, fdr, dem, w, f.tiles_x, f.ext, f.loc16, acc32, thr, river);
+  if (dem && river) hipLaunchKernelGGL((k_fa_tile3<true, true>), gt, b, 0, s, fdr, dem, w, f.tiles_x, f.ext, f.loc16, acc32, thr, river, status);
+  else if (dem) hipLaunchKernelGGL((k_fa_tile3<true, false>), gt, b, 0, s, fdr, dem, w, f.tiles_x, f.ext, f.loc16, acc32, thr, river, status);
+  else if (river) hipLaunchKernelGGL((k_fa_tile3<false, true>), gt, b, 0, s, fdr, dem, w, f.tiles_x, f.ext, f.loc16, acc32, thr, river, status);
+  else hipLaunchKernelGGL((k_fa_tile3<false, false>), gt, b, 0, s, fdr, dem, w, f.tiles_x, f.ext, f.loc16, acc32, thr, river, status);
   return DT_OK;
 }
 

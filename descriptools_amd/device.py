@@ -57,6 +57,18 @@ class Context:
     def sync(self):
         check(_lib.lib().dt_ctx_sync(self.h))
 
+    def status(self):
+        """sticky DT_STATUS_* bits raised by kernels since the last call (synchronises, clears)"""
+        out = C.c_int32(0)
+        check(_lib.lib().dt_ctx_status(self.h, C.byref(out)))
+        return int(out.value)
+
+    def raise_on_status(self):
+        st = self.status()
+        if st & 1:
+            raise OverflowError("flow accumulation reached 2^31 cells: the int32 accumulation rasters of this "
+                                "step are not valid (DT_STATUS_ACC_OVERFLOW)")
+
     def fork(self, child):
         """`child`'s stream waits (on the device) for everything enqueued so far on this context's stream."""
         check(_lib.lib().dt_ctx_fork(self.h, child.h))

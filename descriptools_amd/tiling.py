@@ -55,15 +55,16 @@ class Layout:
         # at the core origin); only the last row / column of ranks may be ragged
         assert all(h % 64 == 0 for h in self.heights[:-1]) and all(w % 64 == 0 for w in self.widths[:-1]), \
             "rank tile heights / widths must be multiples of 64 (except the last row / column)"
+        # accumulation rasters are int32 on the device: a rank tile must stay below 2^31 cells; a GLOBAL raster of
+        # >= 2^31 cells is allowed, and a basin that reaches 2^31 cells is detected at run time
+        # (DT_STATUS_ACC_OVERFLOW, RankTile.check_status)
+        assert all(h * w < 2 ** 31 for h in self.heights for w in self.widths), "a rank tile must have < 2^31 cells"
 
     @staticmethod
     def uniform(world, H, W):
-        tx = 1
-        while tx * tx < world:
-            tx *= 2
-        ty = (world + tx - 1) // tx
-        assert ty * tx == world, "world size must be a power of two (or fill a ty x tx grid)"
-        return Layout([H] * ty, [W] * tx)
+        """the most nearly square ty x tx grid with ty * tx == world and ty <= tx (1 x 2, 2 x 2, 2 x 3, 2 x 4, ...)"""
+        ty = max(d for d in range(1, int(world ** 0.5) + 1) if world % d == 0)
+        return Layout([H] * ty, [W] * (world // ty))
 
     def origin(self, r):
         return int(self.ys[r // self.tx]), int(self.xs[r % self.tx])
@@ -271,13 +272,16 @@ class RankTile:
         self.dev = torch.device("cuda", device)
         self.ctx = Context(device=device, stream=stream)
         self.side_ctx = Context(device=device)  # the downslope branch (own stream), see run_rank
-        # torch ops below (fills, copies, the ring gather) run on torch's current stream: when that is not
-        # the context's stream the two are ordered by hand (_torch_begin / _torch_end)
-        self._foreign = stream is None or int(stream) != int(torch.cuda.current_stream(self.dev).cuda_stream)
+        # every torch op of this tile (fills, copies, the ring gather, the all-gathers' events) is issued on the
+        # CONTEXT's stream, wrapped as a torch stream: library kernels and torch ops are ordered by the stream
+        # itself, whatever torch's current stream is
+        self.ts = torch.cuda.ExternalStream(int(self.ctx.stream), device=self.dev)
         self.px, self.n_top, self.n_gfi, self.b, self.dz = px, n_top, n_gfi, b, dz
         self.river_threshold = (layout.Hg * layout.Wg) // 512 if river_threshold is None else int(river_threshold)
         self.P = perim_count(self.H, self.W)
         t = {}
+        self._on_ts = torch.cuda.stream(self.ts)
+        self._on_ts.__enter__()
         for name, dt in (("dem", torch.float32), ("fdr", torch.uint8), ("fac", torch.int32),
                          ("river", torch.int8), ("fdist", torch.float32), ("idx", torch.int64),
                          ("hand", torch.float32), ("a_river", torch.int32), ("slope", torch.float32),
@@ -308,16 +312,12 @@ class RankTile:
                      torch.zeros(max(self.P, 1), dtype=torch.int64, device=self.dev),
                      torch.zeros(max(self.P, 1), dtype=torch.float32, device=self.dev),
                      torch.zeros(max(self.P, 1), dtype=torch.int32, device=self.dev))
+        self._on_ts.__exit__(None, None, None)
+        self.ctx.sync()  # the buffers exist and are zero before anybody (any stream) touches them
 
-        self._torch_end()
-
-    def _torch_begin(self):
-        if self._foreign:
-            self.ctx.sync()
-
-    def _torch_end(self):
-        if self._foreign:
-            self.torch.cuda.current_stream(self.dev).synchronize()
+    def on_stream(self):
+        """context manager: torch ops inside run on this tile's context stream"""
+        return self.torch.cuda.stream(self.ts)
 
     def _row_views(self, row, fields):
         tc, pm = self.torch, self.pmax
@@ -346,19 +346,19 @@ class RankTile:
         h = self.halo
         y0, x0 = max(self.gy0 - h, 0), max(self.gx0 - h, 0)
         y1, x1 = min(self.gy0 + self.H + h, self.layout.Hg), min(self.gx0 + self.W + h, self.layout.Wg)
-        tmp = self.torch.empty((y1 - y0, x1 - x0), dtype=self.torch.float32, device=self.dev)
-        self._chk(self.L.dt_dev_synth_dem(self.ctx.h, seed, self.layout.Hg, self.layout.Wg, y0, x0, y1 - y0,
-                                          x1 - x0, nodata_pct, tmp.data_ptr()))
+        with self.on_stream():
+            tmp = self.torch.empty((y1 - y0, x1 - x0), dtype=self.torch.float32, device=self.dev)
+            self._chk(self.L.dt_dev_synth_dem(self.ctx.h, seed, self.layout.Hg, self.layout.Wg, y0, x0, y1 - y0,
+                                              x1 - x0, nodata_pct, tmp.data_ptr()))
+            oy, ox = y0 - (self.gy0 - h), x0 - (self.gx0 - h)
+            self.t["dem"][oy:oy + (y1 - y0), ox:ox + (x1 - x0)] = tmp
         self.ctx.sync()
-        oy, ox = y0 - (self.gy0 - h), x0 - (self.gx0 - h)
-        self.t["dem"][oy:oy + (y1 - y0), ox:ox + (x1 - x0)] = tmp
-        self._torch_end()
 
     def set_dem_ext(self, dem_ext):
         """host array of the extended window (He x We); cells outside the global raster are ignored."""
-        self._torch_begin()
-        self.t["dem"].copy_(self.torch.as_tensor(np.ascontiguousarray(dem_ext, np.float32)))
-        self._torch_end()
+        with self.on_stream():
+            self.t["dem"].copy_(self.torch.as_tensor(np.ascontiguousarray(dem_ext, np.float32)))
+        self.ctx.sync()
 
     # ---- local stages ------------------------------------------------------------------------------
     def d8(self):
@@ -379,8 +379,10 @@ class RankTile:
         return self.t["fdr"].reshape(-1)[self._ring_lin]
 
     def ring_codes(self):
+        with self.on_stream():
+            rc = self.ring_codes_dev()
         self.ctx.sync()
-        return self.ring_codes_dev().cpu().numpy()
+        return rc.cpu().numpy()
 
     def fa_local(self, sync=True):
         v = self._fa_v
@@ -393,7 +395,8 @@ class RankTile:
 
     def fa_finish(self, ext):
         tc = self.torch
-        e = tc.as_tensor(ext.view(np.int64), device=self.dev) if ext is not None else None
+        with self.on_stream():
+            e = tc.as_tensor(ext.view(np.int64), device=self.dev) if ext is not None else None
         self._keep = e
         self._chk(self.L.dt_dev_flowacc_finish_w(self.ctx.h, C.byref(self.win), self.p("fdr"), self.p("dem"),
                                                  e.data_ptr() if e is not None else None,
@@ -401,11 +404,10 @@ class RankTile:
 
     def fill_ring_codes(self):
         """D8 codes of the ring cells into both summary rows (the rank-level solves step across ranks with them)."""
-        self._torch_begin()
-        rc = self.ring_codes_dev()
-        self._fa_v["ring"].copy_(rc)
-        self._fh_v["ring"].copy_(rc)
-        self._torch_end()
+        with self.on_stream():
+            rc = self.ring_codes_dev()
+            self._fa_v["ring"].copy_(rc)
+            self._fh_v["ring"].copy_(rc)
 
     def fa_solve_finish(self, rows):
         """rank-level inflow solve on the GPU from the all-gathered rows (size x FA_ROW_BYTES*pmax bytes,
@@ -454,7 +456,8 @@ class RankTile:
         tc = self.torch
         ptrs = [None] * 6
         if res is not None:
-            self._keep2 = [tc.as_tensor(np.ascontiguousarray(a), device=self.dev) for a in res]
+            with self.on_stream():
+                self._keep2 = [tc.as_tensor(np.ascontiguousarray(a), device=self.dev) for a in res]
             ptrs = [a.data_ptr() for a in self._keep2]
         self._chk(self.L.dt_dev_flowhand_finish_w(self.ctx.h, C.byref(self.win), self.p("dem"), self.p("fdr"),
                                                   self.p("river"), self.p("fac"), self.px, ptrs[0], ptrs[1],
@@ -491,12 +494,18 @@ class RankTile:
         self.gfi()
         self.downslope()
 
+    def check_status(self):
+        """raise if a kernel of this tile's steps flagged a condition that invalidates its rasters (a flow
+        accumulation of >= 2^31 cells); synchronises"""
+        self.ctx.raise_on_status()
+
     def unresolved_downslope(self):
         self.side_ctx.sync()
         self.ctx.sync()
         return int(self.n_unres.item())
 
     def host(self, name):
+        self.side_ctx.sync()
         self.ctx.sync()
         return self.core(name).cpu().numpy()
 
@@ -543,20 +552,10 @@ def all_gather_summaries(arrs, layout, rank, group=None):
 _DIRS = [(-1, -1), (-1, 0), (-1, 1), (0, -1), (0, 1), (1, -1), (1, 0), (1, 1)]
 
 
-def exchange_halo(ext, layout, rank, halo=HALO, group=None):
-    """Point-to-point halo exchange of an extended raster `ext` ((H + 2*halo) x (W + 2*halo) torch
-    tensor, CPU for gloo / GPU for RCCL) with the <= 8 neighbouring ranks: each rank sends the border
-    strips of its core and receives its halo.  xGMI is point-to-point, the strips are KBs: eight small
-    sends per rank, no collective.  Halo cells outside the global raster are left untouched."""
-    import torch
-    import torch.distributed as dist
-    H, W = layout.shape(rank)
-    ry, rx = rank // layout.tx, rank % layout.tx
-    h = halo
-    assert all(hh >= h for hh in layout.heights) and all(ww >= h for ww in layout.widths), \
-        "rank tiles must be at least `halo` cells in both directions"
-
-    def rows(d, send):  # slice of ext rows for direction component d
+def _halo_slices(H, W, h):
+    """(rows, cols)(d, send): slices of an extended raster for direction component d in {-1, 0, 1}: the strip of
+    the core that is SENT towards d, or the part of the halo that is RECEIVED from d."""
+    def rows(d, send):
         if d == 0:
             return slice(h, h + H)
         if send:
@@ -569,13 +568,35 @@ def exchange_halo(ext, layout, rank, halo=HALO, group=None):
         if send:
             return slice(h, 2 * h) if d < 0 else slice(W, W + h)
         return slice(0, h) if d < 0 else slice(h + W, 2 * h + W)
+    return rows, cols
 
-    ops, recvs = [], []
+
+def halo_plan(layout, rank):
+    """[(k, dy, dx, peer)] for the <= 8 neighbouring ranks of `rank` (k = index into _DIRS; the peer's strip that
+    lands in our (dy, dx) halo is the one it sends in direction 7 - k)."""
+    ry, rx = rank // layout.tx, rank % layout.tx
+    plan = []
     for k, (dy, dx) in enumerate(_DIRS):
         py, px = ry + dy, rx + dx
-        if not (0 <= py < layout.ty and 0 <= px < layout.tx):
-            continue
-        peer = py * layout.tx + px
+        if 0 <= py < layout.ty and 0 <= px < layout.tx:
+            plan.append((k, dy, dx, py * layout.tx + px))
+    return plan
+
+
+def exchange_halo(ext, layout, rank, halo=HALO, group=None):
+    """Point-to-point halo exchange of an extended raster `ext` ((H + 2*halo) x (W + 2*halo) torch
+    tensor, CPU for gloo / GPU for RCCL) with the <= 8 neighbouring ranks: each rank sends the border
+    strips of its core and receives its halo.  xGMI is point-to-point, the strips are KBs: eight small
+    sends per rank, no collective.  Halo cells outside the global raster are left untouched."""
+    import torch
+    import torch.distributed as dist
+    H, W = layout.shape(rank)
+    h = halo
+    assert all(hh >= h for hh in layout.heights) and all(ww >= h for ww in layout.widths), \
+        "rank tiles must be at least `halo` cells in both directions"
+    rows, cols = _halo_slices(H, W, h)
+    ops, recvs = [], []
+    for k, dy, dx, peer in halo_plan(layout, rank):
         sbuf = ext[rows(dy, True), cols(dx, True)].contiguous()
         rbuf = torch.empty_like(ext[rows(dy, False), cols(dx, False)]).contiguous()
         # the peer sends towards us in the opposite direction: its tag is 7 - k
@@ -590,35 +611,56 @@ def exchange_halo(ext, layout, rank, halo=HALO, group=None):
     return ext
 
 
+def exchange_halo_local(exts, layout, halo=HALO):
+    """The same exchange between N LOGICAL ranks living in one process (one device): exts[r] is rank r's extended
+    raster; every send / receive pair of exchange_halo becomes one device-to-device copy of the same strips
+    (what simulate() is to the all-gathers: the slicing, packing and placement are the product's, only the
+    transport differs)."""
+    h = halo
+    for r in range(layout.size):
+        H, W = layout.shape(r)
+        rows, cols = _halo_slices(H, W, h)
+        for k, dy, dx, peer in halo_plan(layout, r):
+            pH, pW = layout.shape(peer)
+            prow, pcol = _halo_slices(pH, pW, h)
+            # what the peer sends in direction (-dy, -dx) is what we receive from (dy, dx)
+            exts[r][rows(dy, False), cols(dx, False)] = exts[peer][prow(-dy, True), pcol(-dx, True)]
+    return exts
+
+
 class Exchange:
-    """The two all-gathers of a step, issued on a SIDE stream behind an event, so that kernels queued
-    on the main stream after the summaries keep the GPU busy while the ring rows travel (RCCL).  The
-    gathered rows stay on the device: the rank-level graphs are solved there (dt_dev_rank_solve_*), the
-    main stream only waits on an event, the host never blocks."""
+    """The two all-gathers of a step, issued on a SIDE stream behind an event recorded on the tile's context
+    stream, so that kernels queued on that stream after the summaries keep the GPU busy while the ring rows travel
+    (RCCL).  The gathered rows stay on the device: the rank-level graphs are solved there (dt_dev_rank_solve_*), the
+    context stream only waits on an event, the host never blocks."""
 
     def __init__(self, tile, layout, world, group=None):
         self.tile, self.layout, self.world, self.group = tile, layout, world, group
         tc = self.torch = tile.torch
         self.side = tc.cuda.Stream(device=tile.dev)
         n = layout.size
-        self.fa_all = tc.zeros(n * tile.fa_row.numel(), dtype=tc.uint8, device=tile.dev)
-        self.fh_all = tc.zeros(n * tile.fh_row.numel(), dtype=tc.uint8, device=tile.dev)
+        with tile.on_stream():
+            self.fa_all = tc.zeros(n * tile.fa_row.numel(), dtype=tc.uint8, device=tile.dev)
+            self.fh_all = tc.zeros(n * tile.fh_row.numel(), dtype=tc.uint8, device=tile.dev)
+        tile.ctx.sync()
+        self._done = None
 
     def gather(self, row, out):
-        """all-gather `row` into `out` behind the main stream's current work; the main stream resumes
-        after the gather.  Work queued on the main stream BEFORE the returned wait overlaps it."""
+        """all-gather `row` into `out` behind the work queued so far on the tile's context stream (the kernels that
+        write the row); the returned tensor is valid on that stream after wait().  Work queued on the context
+        stream between gather() and wait() overlaps the transfer."""
         tc = self.torch
-        main = tc.cuda.current_stream(self.tile.dev)
         if self.world == 1:
             return row
         import torch.distributed as dist
         ev = tc.cuda.Event()
-        ev.record(main)
+        ev.record(self.tile.ts)
         if dist.get_backend(self.group) == "gloo":  # CPU rehearsal of the RCCL path
             ev.synchronize()
             h = tc.empty(out.numel(), dtype=tc.uint8)
             dist.all_gather_into_tensor(h, row.cpu(), group=self.group)
-            out.copy_(h)
+            with self.tile.on_stream():
+                out.copy_(h)
             return out
         with tc.cuda.stream(self.side):
             self.side.wait_event(ev)
@@ -629,9 +671,8 @@ class Exchange:
         return out
 
     def wait(self):
-        d = getattr(self, "_done", None)
-        if d is not None:
-            self.torch.cuda.current_stream(self.tile.dev).wait_event(d)
+        if self._done is not None:
+            self.tile.ts.wait_event(self._done)
             self._done = None
 
 

@@ -11,12 +11,14 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-import descriptools_amd.topoindexes as topoindexes  # noqa: E402
-import descriptools_amd.downslope as downslope  # noqa: E402
-import descriptools_amd.slope as slope  # noqa: E402
-import descriptools_amd.flowhand as flowhand  # noqa: E402
-import descriptools_amd.gfi as gfi  # noqa: E402
-import descriptools_amd.evaluation as evaluation  # noqa: E402
+# the reference example's own import block (Example/example.py:11-16), unchanged: `descriptools` is the alias
+# package of descriptools_amd at the repository root
+import descriptools.topoindexes as topoindexes  # noqa: E402
+import descriptools.downslope as downslope  # noqa: E402
+import descriptools.slope as slope  # noqa: E402
+import descriptools.flowhand as flowhand  # noqa: E402
+import descriptools.gfi as gfi  # noqa: E402
+import descriptools.evaluation as evaluation  # noqa: E402
 
 
 import descriptools_amd.rasterio_lite as rio  # noqa: E402

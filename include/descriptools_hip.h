@@ -68,6 +68,11 @@ void *dt_ctx_stream(dt_ctx *ctx);
 int dt_ctx_fork(dt_ctx *parent, dt_ctx *child);
 int dt_ctx_join(dt_ctx *parent, dt_ctx *child);
 int dt_ctx_sync(dt_ctx *ctx);
+/* Sticky status bits raised by kernels since the last call (synchronises the context's stream, clears them).
+ * DT_STATUS_ACC_OVERFLOW: a flow accumulation value of a multi-rank raster may have reached 2^31 cells; the device
+ * accumulation rasters are int32 (a device tile is < 2^31 cells), so the results of that step are not valid. */
+#define DT_STATUS_ACC_OVERFLOW 1
+int dt_ctx_status(dt_ctx *ctx, int32_t *out);
 int64_t dt_ctx_scratch_bytes(dt_ctx *ctx);
 
 /* ---- host-pointer tier (drop-in for the reference's *_cpu shims) ----------------------- */

@@ -21,7 +21,28 @@ def build(force=False):
     return _SO
 
 
+_SO_BENCH = os.path.join(_HERE, "_build", "libdt_oracle_bench.so")
+
+
+def build_bench(force=False):
+    """the timed CPU-baseline build (bench.py cpu_baseline): -O3 -march=native + OpenMP over the per-cell loops"""
+    src = os.path.join(_HERE, "dt_oracle.c")
+    if force or not os.path.exists(_SO_BENCH) or os.path.getmtime(_SO_BENCH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "bench"])
+    return _SO_BENCH
+
+
 _lib = None
+
+
+def use_bench_build(threads):
+    """switch this module to the baseline build with `threads` OpenMP threads (None: back to the checker build)"""
+    global _lib
+    if threads is None:
+        _lib = None
+        return
+    _lib = C.CDLL(build_bench())
+    C.CDLL("libgomp.so.1").omp_set_num_threads(int(threads))
 
 
 def lib():

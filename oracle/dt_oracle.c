@@ -39,6 +39,15 @@
 #define DT_SYNTH_TILT 64 /* 1/256 m per cell along +y */
 #define DT_SYNTH_KMIN 5 /* coarsest..finest octave: lambda_y = 2^O .. 2^KMIN */
 #define DT_SYNTH_SX 4   /* lambda_x = lambda_y >> SX */
+/* The per-cell loops are independent across cells (each cell's walk reads the rasters only): bench.py's
+ * all-cores CPU baseline builds this file with -fopenmp -DDT_ORACLE_OMP (Makefile target bench); the checker build
+ * used by the tests is the plain sequential one. */
+#ifdef DT_ORACLE_OMP
+#define DT_OMP_FOR _Pragma("omp parallel for schedule(dynamic, 4096)")
+#else
+#define DT_OMP_FOR
+#endif
+
 static const int32_t DT_SYNTH_AMP[15] = {/* floor(16 * 2^(0.8 k)), k = log2(lambda_y) */
                                          0,    0,    0,    0,    0,     256,   445,  776,
                                          1351, 2352, 4096, 7131, 12416, 21618, 37640};
@@ -133,6 +142,7 @@ static const uint8_t DT_CODE[8] = {32, 64, 128, 16, 1, 8, 4, 2};
 int dt_oracle_slope_d8_f32(const float *dem, int64_t H, int64_t W, double px, float *slope,
                            uint8_t *fdr) {
   const double dcard = px, ddiag = px * sqrt(2.0);
+  DT_OMP_FOR
   for (int64_t y = 0; y < H; y++)
     for (int64_t x = 0; x < W; x++) {
       int64_t i = y * W + x;
@@ -244,6 +254,7 @@ int dt_oracle_flowhand(const float *dem, const uint8_t *fdr, const int8_t *river
                        int64_t W, double px, float *fdist, int64_t *idx, float *hand) {
   const int64_t N = H * W;
   const double dcard = px, ddiag = px * sqrt(2.0);
+  DT_OMP_FOR
   for (int64_t i = 0; i < N; i++) {
     int64_t res_idx = -100;
     float res_d = DT_NODATA;
@@ -278,6 +289,7 @@ int dt_oracle_flowhand(const float *dem, const uint8_t *fdr, const int8_t *river
     idx[i] = res_idx;
   }
   if (hand && dem) {
+    DT_OMP_FOR
     for (int64_t i = 0; i < N; i++) {
       float h = DT_NODATA;
       if (dem[i] != DT_NODATA && idx[i] != -100) {
@@ -349,6 +361,7 @@ int dt_oracle_flowhand_fast(const uint8_t *fdr, const int8_t *river, int64_t H, 
  * ---------------------------------------------------------------------------------- */
 int dt_oracle_twi(const int64_t *fac, const float *slope_rad, int64_t N, double px, double n,
                   float *ti, float *mti) {
+  DT_OMP_FOR
   for (int64_t i = 0; i < N; i++) {
     if (fac[i] <= -100) {
       ti[i] = DT_NODATA;
@@ -371,6 +384,7 @@ int dt_oracle_twi(const int64_t *fac, const float *slope_rad, int64_t N, double 
  * ---------------------------------------------------------------------------------- */
 int dt_oracle_gfi(const float *hand, const int64_t *fac, const int64_t *idx, int64_t N, double n,
                   double b, double size, float *gfi) {
+  DT_OMP_FOR
   for (int64_t i = 0; i < N; i++) {
     if (hand[i] <= DT_NODATA) {
       gfi[i] = DT_NODATA;
@@ -384,6 +398,7 @@ int dt_oracle_gfi(const float *hand, const int64_t *fac, const int64_t *idx, int
 
 int dt_oracle_lnhlh(const float *hand, const int64_t *fac, int64_t N, double n, double b,
                     double size, float *out) {
+  DT_OMP_FOR
   for (int64_t i = 0; i < N; i++) {
     if (hand[i] <= DT_NODATA) {
       out[i] = DT_NODATA;
@@ -412,6 +427,7 @@ int dt_oracle_downslope(const float *dem, const uint8_t *fdr, int64_t H, int64_t
                         double dz, float *out) {
   const int64_t N = H * W;
   const double dcard = px, ddiag = px * sqrt(2.0);
+  DT_OMP_FOR
   for (int64_t i = 0; i < N; i++) {
     float z0 = dem[i];
     if (z0 <= DT_NODATA) {

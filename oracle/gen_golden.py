@@ -292,7 +292,139 @@ def case_example_full():
          counts=np.bincount(cm.reshape(-1).astype(np.int64), minlength=4))
 
 
-CASES = {"synth": case_synth, "example_windows": case_example_windows, "edge": case_edge,
+
+def case_shims():
+    """G-shim: the tile-level shims called the way the reference's own tile loops call them
+    (slope.py:126-147, flowhand.py:293-405): slope_cpu with all 16 `extra` combinations, sloper with divisions,
+    flow_distance_index_cpu with neighbouring tiles on every combination of sides (boundary vectors, global
+    index arithmetic with row_start / col_start / matrix_columns)."""
+    print("shims", flush=True)
+    res = {}
+    px = 10.0
+    dem32 = oracle.synth_dem(4, 1024, 1024, 100, 100, 40, 56, 5)
+    dem = dem32.astype(np.float64)
+    res["sl_dem"] = dem32
+    standin_cuda.TOLERATE_UNBOUND = True
+    try:
+        k = 0
+        for u in (0, 1):
+            for l in (0, 1):
+                for r in (0, 1):
+                    for d in (0, 1):
+                        mS, mE = (0 if u else 10), (40 if d else 30)
+                        nS, nE = (0 if l else 12), (56 if r else 44)
+                        tile = dem[mS - 1 + u:mE + 1 - d, nS - 1 + l:nE + 1 - r]
+                        out = R_slope.slope_cpu(tile, px, np.array([u, l, r, d]))
+                        res["sl_extra%d" % k] = np.array([u, l, r, d, mS, mE, nS, nE])
+                        res["sl_out%d" % k] = out.astype(np.float32)
+                        k += 1
+        res["sl_tiled22"] = R_slope.sloper(dem, px, 2, 2).astype(np.float32)
+    finally:
+        standin_cuda.TOLERATE_UNBOUND = False
+    res["sl_untiled"] = R_slope.sloper(dem, px).astype(np.float32)
+    # flow distance: a 48 x 60 raster solved untiled, then tiles of it through flow_distance_index_cpu with the
+    # ring of the untiled solution as boundary vectors, exactly as flowhand.py:313-390 slices them
+    H, W = 48, 60
+    dem32 = oracle.synth_dem(6, 1024, 1024, 500, 300, H, W, 4)
+    _, fdr = oracle.slope_d8(dem32, px)
+    fac = oracle.flowacc(fdr, dem32)
+    river = (fac > 25).astype(np.int8)
+    fd_full, idx_full, _ = R_flowhand.flow_hand_index(dem32.astype(np.float64), fdr, river, px)
+    res.update(fd_dem=dem32, fd_fdr=fdr, fd_river=river, fd_full=fd_full.astype(np.float32),
+               fd_idx_full=idx_full.astype(np.int64))
+    k = 0
+    for (mS, mE, nS, nE) in ((-1, 20, -1, 25), (20, 48, 25, 60), (10, 30, 15, 45), (-1, 48, 30, 60), (25, 48, -1, 60),
+                             (-1, 15, 40, 60), (12, 13 + 12, 5, 5 + 9)):
+        # separator lines at rows mS / mE and columns nS / nE (-1 / H / W = raster edge: no neighbour)
+        out = np.array([1 if mS >= 0 else 0, 1 if nS >= 0 else 0, 1 if nE < W else 0, 1 if mE < H else 0], float)
+
+        def line(vals, lo, hi, fixed, axis, before, after):
+            seg = vals[fixed, lo + 1:hi] if axis == 0 else vals[lo + 1:hi, fixed]
+            seg = np.asarray(seg, float)
+            if after:
+                seg = np.append(seg, vals[fixed, hi] if axis == 0 else vals[hi, fixed])
+            if before:
+                seg = np.insert(seg, 0, vals[fixed, lo] if axis == 0 else vals[lo, fixed])
+            return seg
+        vecs_d, vecs_i = [np.zeros(1)] * 4, [np.zeros(1)] * 4
+        if out[0]:
+            vecs_d[0] = line(fd_full, nS, nE, mS, 0, nS >= 0, nE < W)
+            vecs_i[0] = line(idx_full, nS, nE, mS, 0, nS >= 0, nE < W)
+        if out[3]:
+            vecs_d[3] = line(fd_full, nS, nE, mE, 0, nS >= 0, nE < W)
+            vecs_i[3] = line(idx_full, nS, nE, mE, 0, nS >= 0, nE < W)
+        if out[1]:
+            vecs_d[1] = line(fd_full, mS, mE, nS, 1, mS >= 0, mE < H)
+            vecs_i[1] = line(idx_full, mS, mE, nS, 1, mS >= 0, mE < H)
+        if out[2]:
+            vecs_d[2] = line(fd_full, mS, mE, nE, 1, mS >= 0, mE < H)
+            vecs_i[2] = line(idx_full, mS, mE, nE, 1, mS >= 0, mE < H)
+        size = max(len(v) for v in vecs_d)
+        bound, bound_i = np.zeros((4, size)), np.zeros((4, size))
+        for q in range(4):
+            bound[q, :len(vecs_d[q])] = vecs_d[q]
+            bound_i[q, :len(vecs_i[q])] = vecs_i[q]
+        r0, c0 = mS + 1, nS + 1
+        f, i = R_flowhand.flow_distance_index_cpu(dem32[r0:mE, c0:nE].astype(np.float64), fdr[r0:mE, c0:nE],
+                                                  river[r0:mE, c0:nE], px, bound, bound_i, out, r0, c0, W)
+        res.update({"fd_tile%d" % k: np.array([r0, mE, c0, nE]), "fd_out%d" % k: out, "fd_bound%d" % k: bound,
+                    "fd_boundi%d" % k: bound_i, "fd_f%d" % k: np.asarray(f, np.float32),
+                    "fd_i%d" % k: np.asarray(i, np.float64)})
+        k += 1
+    res["fd_ntiles"] = k
+    # the separator pre-solve itself (flowhand.py:128-239, :283-286): only the cells marked -50 are solved
+    marks = np.zeros((H, W), np.float32)
+    marks[:, [20, 40]] = -50
+    marks[[16, 32], :] = -50
+    res["sep_marks"] = marks.copy()
+    sf, si = R_flowhand.fdist_indexes_sequential_jit(fdr, river, px, marks)
+    res.update(sep_fdist=np.asarray(sf, np.float32), sep_idx=np.asarray(si, np.int32))
+    sf, si = R_flowhand.fdist_indexes_sequential_jit(fdr, river, px)
+    res.update(sep_all_fdist=np.asarray(sf, np.float32), sep_all_idx=np.asarray(si, np.int32))
+    # whole tiled driver (flowhand.py:242-411) with 2 x 1 divisions: what callers with division_* > 0 get
+    tf, tidx, thand = R_flowhand.flow_hand_index(dem32.astype(np.float64), fdr, river, px, 1, 2)
+    res.update(fh_tiled_fdist=np.asarray(tf, np.float32), fh_tiled_idx=np.asarray(tidx, np.int64),
+               fh_tiled_hand=np.asarray(thand, np.float32))
+    save("shims", **res)
+
+
+def _sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+def case_example_descriptors():
+    """The six float / walk descriptors of the whole bundled Example raster (example.py:59-91), ~8 min:
+    sha256 of the bit-exact rasters (slope %, downslope), and for the float descriptors a strided sample, the
+    nodata count and min / max / mean."""
+    print("example_descriptors", flush=True)
+    dem, fdr, fac, flood, _ = load_example()
+    river = np.where(fac > 128000, 1, 0).astype("int8")
+    g = np.load(os.path.join(GOLD, "example_full.npz"))
+    t = time.time()
+    sl = R_slope.sloper(dem, 12.5).astype("float32")
+    slr = np.where(dem == -100, -100, np.arctan(sl / 100).astype("float32")).astype("float32")
+    ti, mti = R_topo.topographic_index(fac, slr.astype(np.float64), 12.5, 0.1)
+    print("   slope + TI %.0fs" % (time.time() - t), flush=True)
+    down = R_down.downsloper(dem, fdr, 12.5, 5).astype(np.float32)
+    print("   downslope %.0fs" % (time.time() - t), flush=True)
+    hand, idx = g["hand"], g["idx"].astype(np.int64)
+    gf = R_gfi.gfi_calculator(hand, fac, idx, 0.4, 0.1, 12.5)
+    ln = R_gfi.ln_hl_H_calculator(hand, fac, 0.4, 0.1, 12.5)
+    print("   gfi %.0fs" % (time.time() - t), flush=True)
+    res = {"sha_slope": _sha(sl), "sha_down": _sha(down), "slope_rad_sample": slr[::13, ::11]}
+    for name, a in (("slope", sl), ("ti", ti), ("mti", mti), ("gfi", gf), ("lnhlh", ln), ("down", down)):
+        a32 = np.asarray(a, np.float32)
+        v = a32[a32 != -100]
+        res[name + "_sample"] = a32[::13, ::11].copy()
+        res[name + "_stats"] = np.array([int((a32 == -100).sum()), float(v.min()), float(v.max()),
+                                         float(v.astype(np.float64).mean())])
+        print("   %-6s nodata %d min %r max %r mean %r sha %s" % (name, (a32 == -100).sum(), v.min(), v.max(),
+                                                                  v.astype(np.float64).mean(), _sha(a32)), flush=True)
+    save("example_desc", **res)
+
+
+CASES = {"shims": case_shims, "example_descriptors": case_example_descriptors, "synth": case_synth, "example_windows": case_example_windows, "edge": case_edge,
          "eval": case_eval, "example_full": case_example_full}
 
 if __name__ == "__main__":

@@ -8,6 +8,13 @@ _tid = [0]
 # thread interpretively would take hours).  None = run every thread.
 THREAD_FILTER = None
 
+# Numba compiles a read of a never-assigned local into an undefined value, it does not raise.  The reference
+# relies on that in slope_gpu (slope.py:234-259: `aux` on border cells of a tile whose ring is real data; the
+# garbage only reaches the ring slope_cpu strips, slope.py:202-205).  With this knob set a thread that hits
+# UnboundLocalError is dropped where Numba would have written garbage -- used by oracle/gen_golden.py for the
+# tiled slope cases only.
+TOLERATE_UNBOUND = False
+
 
 def grid(ndim):
     assert ndim == 1
@@ -32,7 +39,11 @@ class _Launcher:
         ids = range(self.n) if THREAD_FILTER is None else [t for t in THREAD_FILTER if t < self.n]
         for t in ids:
             _tid[0] = t
-            f(*args)
+            try:
+                f(*args)
+            except UnboundLocalError:
+                if not TOLERATE_UNBOUND:
+                    raise
 
 
 class _Kernel:

@@ -1,0 +1,62 @@
+"""One rank of tests/test_gpu_run_rank.py (launched by torch.distributed.run): builds its RankTile, fills the DEM
+halo (generated locally, or exchanged point-to-point with the neighbouring ranks), drives tiling.run_rank -- the
+product's N > 1 step -- and writes its core rasters for the parent to compare with the untiled chain."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", required=True)
+    ap.add_argument("--h", type=int, required=True)
+    ap.add_argument("--w", type=int, required=True)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--nodata", type=int, default=0)
+    ap.add_argument("--backend", default="gloo")
+    ap.add_argument("--halo", default="synth", choices=["synth", "exchange"])
+    ap.add_argument("--overlap", type=int, default=0)
+    ap.add_argument("--force-world", type=int, default=0)
+    a = ap.parse_args()
+    import torch
+    import torch.distributed as dist
+    from descriptools_amd import tiling
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)  # the logical ranks share the one GPU of the box
+    if a.backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo")
+    layout = tiling.Layout.uniform(world, a.h, a.w)
+    thr = (layout.Hg * layout.Wg) // 512
+    tile = tiling.RankTile(layout, rank, device=0, px=10.0, river_threshold=thr)
+    if a.halo == "synth":
+        tile.synth_dem(a.seed, a.nodata)
+    else:
+        import oracle  # test infrastructure: the same generator on the host
+        h = tiling.HALO
+        y0, x0 = layout.origin(rank)
+        core = oracle.synth_dem(a.seed, layout.Hg, layout.Wg, y0, x0, tile.H, tile.W, a.nodata)
+        ext = torch.full((tile.He, tile.We), float("nan"))  # NaN = never received, must never be read
+        ext[h:h + tile.H, h:h + tile.W] = torch.as_tensor(core)
+        tiling.exchange_halo(ext, layout, rank)  # gloo: CPU tensors (RCCL: the same call on device tensors)
+        tile.set_dem_ext(ext.numpy())
+    exchange = tiling.Exchange(tile, layout, max(world, a.force_world))
+    for _ in range(2):  # twice: the step reuses its buffers
+        tiling.run_rank(tile, layout, exchange, overlap=bool(a.overlap))
+    tile.check_status()
+    assert tile.unresolved_downslope() == 0
+    names = ["dem", "fdr", "fac", "river", "fdist", "idx", "hand", "slope", "ti", "mti", "gfi", "lnhlh", "down"]
+    np.savez(os.path.join(a.out, "rank%d.npz" % rank), origin=np.array(layout.origin(rank)),
+             **{n: tile.host(n) for n in names})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

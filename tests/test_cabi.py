@@ -142,3 +142,20 @@ def test_python_api_mirrors_reference_names():
             if params is not None:
                 got = list(inspect.signature(getattr(m, name)).parameters)
                 assert got == params, "%s.%s%s != %s" % (mod, name, got, params)
+
+
+def test_reference_import_block_runs_unchanged():
+    """Callers of the reference import `descriptools.<module>` (Example/example.py:11-16): the alias package at
+    the repository root serves those names from descriptools_amd, function for function."""
+    ns = {}
+    exec("import descriptools.topoindexes as topoindexes\nimport descriptools.downslope as downslope\n"
+         "import descriptools.slope as slope\nimport descriptools.flowhand as flowhand\n"
+         "import descriptools.gfi as gfi\nimport descriptools.evaluation as evaluation\n", ns)
+    import descriptools
+    import descriptools.helpers
+    import descriptools_amd.slope, descriptools_amd.evaluation, descriptools_amd.flowhand  # noqa: E401
+    assert open(descriptools.__file__).read() == "", "descriptools/__init__.py is empty like the reference's"
+    assert ns["slope"].sloper is descriptools_amd.slope.sloper
+    assert ns["evaluation"].calibration is descriptools_amd.evaluation.calibration
+    assert ns["flowhand"].flow_hand_index is descriptools_amd.flowhand.flow_hand_index
+    assert descriptools.helpers.divisor(10, 10, 1, 1)[0][0] == 5

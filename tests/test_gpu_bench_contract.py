@@ -21,7 +21,7 @@ def _run(*extra):
 
 
 def test_bench_line_contract():
-    d = _run()
+    d = _run("--cpu-n", "512")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -35,6 +35,10 @@ def test_bench_line_contract():
     assert r["traffic"] is None  # the committed PMC summary is for 16384^2 only
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "Mcells/s" and c["value"] > 0 and c["sample"]
+    assert c["all_cores"]["cores"] >= 1 and c["all_cores"]["value"] > 0 and "-O3 -march=native" in c["sample"]
+    v = d["verified"]  # the timed step's rasters were cross-checked after the timed loop
+    assert v["fac_idx_fdist_hand_vs_global_kernels"] == "equal" and v["cells_drained_through_outlets"] == 2048 * 2048
+    assert set(v["checksums"]) >= {"fdr", "fac", "river", "fdist", "idx", "hand", "slope", "ti", "mti", "gfi", "lnhlh", "down"}
     assert sum(v["ms"] for v in d["per_op"].values()) <= 1.2 * d["ms_per_step"] + 0.5
 
 
@@ -42,3 +46,18 @@ def test_bench_tiled_path_at_one_rank():
     d = _run("--tiled", "--no-cpu-baseline")
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["downslope_walks_beyond_halo"] == 0
     assert "rank tiles" in d["config"]["parallelism"]
+
+
+def test_bench_gpus_flag_without_a_launcher_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no torchrun around it must not quietly run one rank: it launches the ranks
+    as a child torch.distributed.run (here: gloo rehearsal, two ranks sharing the one GPU)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--size",
+                          "1024", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=900,
+                         cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["backend"] == "gloo" and d["distinct_gpus"] == 1 and d["value"] > 0
+    assert d["config"]["global_dem"] == "1024x2048" and d["downslope_walks_beyond_halo"] == 0

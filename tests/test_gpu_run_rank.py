@@ -1,0 +1,101 @@
+"""GPU (-m gpu): tiling.run_rank -- the step the N > 1 bench and the 8-GPU driver run execute (side-stream
+all-gathers behind events on the context stream, dt_dev_rank_solve_*, fused finish) -- driven by real
+torch.distributed ranks in child processes that share the one GPU, and compared raster by raster with the untiled
+chain.  gloo carries the collectives between the ranks (RCCL refuses two ranks on one device); the RCCL calls
+themselves run in the one-rank case."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NAMES = ["fdr", "fac", "river", "fdist", "idx", "hand", "slope", "ti", "mti", "gfi", "lnhlh", "down"]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _launch(tmp_path, world, h, w, **kw):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "_rank_child.py"), "--out", str(tmp_path), "--h", str(h), "--w", str(w)]
+    for k, v in kw.items():
+        cmd += ["--" + k.replace("_", "-"), str(v)]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    return [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+
+
+def _check(parts, Hg, Wg, seed, nodata):
+    from descriptools_amd import chain
+    dem = oracle.synth_dem(seed, Hg, Wg, 0, 0, Hg, Wg, nodata)
+    ref = chain.run_host(dem, 10.0, river_threshold=(Hg * Wg) // 512)
+    for r, p in enumerate(parts):
+        y0, x0 = (int(v) for v in p["origin"])
+        H, W = p["fdr"].shape
+        sl = (slice(y0, y0 + H), slice(x0, x0 + W))
+        assert np.array_equal(p["dem"], dem[sl])
+        for n in NAMES:
+            got, want = p[n], ref[n][sl]
+            assert np.array_equal(got, want.astype(got.dtype), equal_nan=True), \
+                "rank %d %s: %d cells differ" % (r, n, int((got != want).sum()))
+
+
+@pytest.mark.parametrize("world,h,w,nodata,halo,overlap", [
+    (2, 256, 192, 0, "synth", 0),        # 1 x 2
+    (4, 192, 256, 2, "exchange", 0),     # 2 x 2, DEM halo exchanged point-to-point, nodata blobs
+    (4, 128, 128, 0, "synth", 1),        # 2 x 2, downslope as a second branch
+    (3, 128, 192, 3, "exchange", 0),     # 1 x 3 (at most 4 ranks: the box admits 6 GPU processes, pytest is one)
+])
+def test_run_rank_gloo_ranks_sharing_the_gpu(tmp_path, world, h, w, nodata, halo, overlap):
+    parts = _launch(tmp_path, world, h, w, seed=5, nodata=nodata, halo=halo, overlap=overlap)
+    from descriptools_amd import tiling
+    layout = tiling.Layout.uniform(world, h, w)
+    _check(parts, layout.Hg, layout.Wg, 5, nodata)
+
+
+def test_run_rank_rccl_single_rank(tmp_path):
+    """the RCCL all-gathers on device tensors (side stream, events) with one rank: the collective path of the
+    8-GPU run, minus the peers"""
+    parts = _launch(tmp_path, 1, 320, 448, seed=3, nodata=2, backend="nccl", force_world=2)
+    _check(parts, 320, 448, 3, 2)
+
+
+def test_exchange_halo_on_device_tensors():
+    """the halo exchange's strip slicing / placement on DEVICE tensors, N logical ranks on one device (the
+    transport is a device-to-device copy instead of isend / irecv, like simulate() for the all-gathers): every
+    halo cell inside the global raster must equal the global DEM, ragged last row / column included."""
+    import torch
+    from descriptools_amd import tiling
+    for heights, widths in (([128, 192], [192, 128, 64]), ([256], [128, 128]), ([128, 70], [64, 200])):
+        layout = tiling.Layout(heights, widths)
+        Hg, Wg = layout.Hg, layout.Wg
+        dem = torch.as_tensor(oracle.synth_dem(9, Hg, Wg, 0, 0, Hg, Wg, 0), device="cuda")
+        h = tiling.HALO
+        exts = []
+        for r in range(layout.size):
+            y0, x0 = layout.origin(r)
+            H, W = layout.shape(r)
+            e = torch.full((H + 2 * h, W + 2 * h), float("nan"), device="cuda")
+            e[h:h + H, h:h + W] = dem[y0:y0 + H, x0:x0 + W]
+            exts.append(e)
+        tiling.exchange_halo_local(exts, layout)
+        pad = torch.full((Hg + 2 * h, Wg + 2 * h), float("nan"), device="cuda")
+        pad[h:h + Hg, h:h + Wg] = dem
+        for r in range(layout.size):
+            y0, x0 = layout.origin(r)
+            H, W = layout.shape(r)
+            want = pad[y0:y0 + H + 2 * h, x0:x0 + W + 2 * h]
+            assert torch.equal(torch.nan_to_num(exts[r], nan=-1.0), torch.nan_to_num(want, nan=-1.0)), (heights, widths, r)
