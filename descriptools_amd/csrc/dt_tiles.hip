@@ -555,6 +555,14 @@ __global__ __launch_bounds__(256) void k_fa_rank_summary(DtWin w, int tiles_x,
   if (i >= P) return;
   int y, x;
   dt_perim_cell(w.H, w.W, i, y, x);
+  // a ring cell of a ragged last tile row / column (H or W not a multiple of 64) is not on its TILE's perimeter:
+  // it lies on the edge of the global raster (Layout), nothing enters or leaves the rank there
+  if (dt_slot_of(y % TH, x % TW) < 0) {
+    A[i] = 0;
+    xr[i] = -1;
+    code[i] = 0;
+    return;
+  }
   uint32_t n = dt_node_of(y, x, tiles_x);
   unsigned long long r = rec[n];
   bool rex = (r & REC_RANK_EXIT) != 0ull;
@@ -590,6 +598,7 @@ __global__ __launch_bounds__(256) void k_fa_propagate(DtWin w, int tiles_x, int6
   if (v == 0ull) return;
   int y, x;
   dt_perim_cell(w.H, w.W, i, y, x);
+  if (dt_slot_of(y % TH, x % TW) < 0) return;  // ragged raster edge: no perimeter node, nothing can arrive here
   uint32_t n = dt_node_of(y, x, tiles_x);
   const unsigned long long val = FA_VALUE(v), cyc = v & FA_CYCLE;
   for (int64_t it = 0; it < nnodes; it++) {
@@ -1122,7 +1131,9 @@ __global__ __launch_bounds__(256) void k_fh_rank_summary(DtWin w, int tiles_x, u
   if (i >= P) return;
   int y, x;
   dt_perim_cell(w.H, w.W, i, y, x);
-  unsigned long long s = nodes[dt_node_of(y, x, tiles_x)];
+  // ragged last tile row / column: see k_fa_rank_summary (the cell has no perimeter node)
+  const bool has_node = dt_slot_of(y % TH, x % TW) >= 0;
+  unsigned long long s = has_node ? nodes[dt_node_of(y, x, tiles_x)] : fht_pack(FHT_DEAD, 0, FHT_DONE);
   uint32_t ptr = (uint32_t)(s >> 32), ncf = (uint32_t)(s & 0xFFFFu);
   uint8_t k = (uint8_t)K_DEAD;
   int32_t r = -1;

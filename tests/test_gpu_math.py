@@ -79,7 +79,7 @@ def _slope_probe(q):
 
 
 def test_stencil_arctangent_and_fused_twi_sweep():
-    """slope -> radians (dt_slope_rad) within 1 float32 ulp of numpy's float32 arctan over q = 1e-6 .. 1e6, and the
+    """slope -> radians (dt_slope_rad) within 2 float32 ulp (2.4e-7) of the float64 arctangent over q = 1e-6 .. 1e6, and the
     fused stencil's arctangent-free TI / MTI (sd_twi_fast) plus its exact fix-up path against the float64
     expression, both sides of DT_FAST_MIN and of the q <= 2.5 fast domain."""
     import torch
@@ -108,8 +108,9 @@ def test_stencil_arctangent_and_fused_twi_sweep():
     assert np.array_equal(sl, (q.astype(np.float64) / 1.0 * 100.0).astype(np.float32)), "slope %: exact"
     qq = (sl / np.float32(100.0)).astype(np.float32)
     want = np.arctan(qq.astype(np.float64))
-    assert _ulps(rad, want.astype(np.float32)).max() <= 1
-    assert np.abs(rad.astype(np.float64) - want).max() <= 1.3e-7
+    u = _ulps(rad, want.astype(np.float32))
+    assert u.max() <= 2 and (u > 1).mean() < 1e-3, (u.max(), (u > 1).mean())  # float32 polynomial: ~1 ulp, 2 at most
+    assert np.abs(rad.astype(np.float64) - want).max() <= 2.4e-7
     # TI / MTI against the reference's expression on OUR float32 radians (what Example/example.py:63-69 feeds it)
     f = fac[::3, 0].astype(np.float64)
     A = np.maximum(f, 1.0)  # px = 1
