@@ -177,3 +177,134 @@ def test_tiled_evaluation_matches_untiled():
         dh.free()
         df.free()
     ctx.close()
+
+
+def _boustrophedon(H, W, period):
+    """east on even rows, west on odd rows, south at the row ends: ONE path through the whole raster; a river cell
+    at the end of every `period`-th row cuts it into stretches of period * W moves."""
+    fdr = np.zeros((H, W), np.uint8)
+    fdr[0::2, :] = 1
+    fdr[1::2, :] = 16
+    fdr[0::2, W - 1] = 4
+    fdr[1::2, 0] = 4
+    river = np.zeros((H, W), np.int8)
+    for y in range(period - 1, H, period):
+        river[y, W - 1 if y % 2 == 0 else 0] = 1
+    return fdr, river
+
+
+def test_move_cap_through_tiles_and_ranks():
+    """The 20000-move cap (flowhand.py:834-837) on paths that cross hundreds of tiles and several ranks: a
+    2048-wide boustrophedon whose river cells sit 24576 moves apart, so the first 4576 cells of every stretch exceed
+    the cap and must come out -100, the others with their exact move counts -- untiled (tile -> perimeter
+    hierarchy) and as 2 x 2 logical ranks (tile -> perimeter -> rank), against the oracle's O(N) solve."""
+    import torch
+    from descriptools_amd import flowhand, tiling
+    H = W = 2048
+    px = 10.0
+    fdr, river = _boustrophedon(H, W, 12)
+    idx_o, nc, nd = oracle.flowhand_fast(fdr, river)
+    ok = idx_o != -100
+    assert (~ok).sum() > 0.15 * H * W and ok.sum() > 0.7 * H * W, "both sides of the cap are exercised"
+    d_o = np.where(ok, px * nc + (px * np.sqrt(2.0)) * nd, -100.0).astype(np.float32)
+    assert nc[ok].max() == 20000
+    dem = np.ones((H, W), np.float32)
+    fd, idx, _ = flowhand.flow_hand_index(dem, fdr, river, px)
+    assert np.array_equal(idx, idx_o) and np.array_equal(fd, d_o)
+    layout = tiling.Layout([1024, 1024], [1024, 1024])
+    h = tiling.HALO
+    pf = np.zeros((H + 2 * h, W + 2 * h), np.uint8)
+    pr = np.zeros((H + 2 * h, W + 2 * h), np.int8)
+    pf[h:h + H, h:h + W], pr[h:h + H, h:h + W] = fdr, river
+    tiles = []
+    for r in range(layout.size):
+        t = tiling.RankTile(layout, r, device=0, px=px, river_threshold=10)
+        y0, x0 = layout.origin(r)
+        t.t["fdr"].copy_(torch.as_tensor(pf[y0:y0 + t.He, x0:x0 + t.We]))
+        t.t["river"].copy_(torch.as_tensor(pr[y0:y0 + t.He, x0:x0 + t.We]))
+        t.t["dem"].fill_(1.0)
+        tiles.append(t)
+    torch.cuda.synchronize()
+    for t in tiles:
+        t.fill_ring_codes()
+        t.fh_local(sync=False)
+    for t in tiles:
+        t.ctx.sync()
+    rows = torch.cat([t.fh_row for t in tiles])
+    torch.cuda.synchronize()
+    for t in tiles:
+        t.fh_solve_finish(rows)
+    for t in tiles:
+        y0, x0 = layout.origin(t.rank)
+        sl = (slice(y0, y0 + t.H), slice(x0, x0 + t.W))
+        assert np.array_equal(t.host("idx"), idx_o[sl]), "rank %d river index" % t.rank
+        assert np.array_equal(t.host("fdist"), d_o[sl]), "rank %d flow distance" % t.rank
+
+
+@pytest.mark.parametrize("heights,widths,nod,seed", [
+    ([192, 192], [128, 192, 128, 192], 0, 8),       # config #5's 2 x 4 rank grid
+    ([256, 150], [128, 128, 192, 100], 3, 9),       # 2 x 4, ragged last row / column, nodata blobs
+])
+def test_tiled_2x4_equals_untiled(heights, widths, nod, seed):
+    test_tiled_equals_untiled(heights, widths, nod, seed, "device")
+
+
+def test_tiled_2x4_flowacc_cycles_across_ranks():
+    """arbitrary direction field on the 2 x 4 grid: cycles inside tiles, across tiles and across ranks"""
+    from descriptools_amd import tiling
+    import torch
+    rng = np.random.default_rng(21)
+    layout = tiling.Layout([128, 128], [64, 128, 64, 128])
+    Hg, Wg = layout.Hg, layout.Wg
+    codes = np.array([1, 2, 4, 8, 16, 32, 64, 128], np.uint8)
+    fdr = codes[rng.integers(0, 8, size=(Hg, Wg))]
+    fdr[rng.random((Hg, Wg)) < 0.3] = 1
+    ref = oracle.flowacc(fdr)
+    h = tiling.HALO
+    pad = np.zeros((Hg + 2 * h, Wg + 2 * h), np.uint8)
+    pad[h:h + Hg, h:h + Wg] = fdr
+    tiles = []
+    for r in range(layout.size):
+        t = tiling.RankTile(layout, r, device=0, river_threshold=10)
+        y0, x0 = layout.origin(r)
+        t.t["fdr"].copy_(torch.as_tensor(pad[y0:y0 + t.He, x0:x0 + t.We]))
+        t.t["dem"].fill_(1.0)
+        tiles.append(t)
+    torch.cuda.synchronize()
+    for t in tiles:
+        t.fa_local(sync=False)
+        t.fill_ring_codes()
+    for t in tiles:
+        t.ctx.sync()
+    rows = torch.cat([t.fa_row for t in tiles])
+    torch.cuda.synchronize()
+    for t in tiles:
+        t.fa_solve_finish(rows)
+        y0, x0 = layout.origin(t.rank)
+        got, want = t.host("fac"), ref[y0:y0 + t.H, x0:x0 + t.W]
+        assert np.array_equal(got, want), "rank %d: %d cells differ" % (t.rank, int((got != want).sum()))
+
+
+def test_accumulation_overflow_is_reported():
+    """int32 accumulation rasters: an inflow that takes a value to 2^31 raises the context's status instead of
+    wrapping silently (DT_STATUS_ACC_OVERFLOW); just below the limit it does not."""
+    import torch
+    from descriptools_amd import tiling
+    layout = tiling.Layout([128], [128, 128])
+    for inflow, expect in ((2 ** 31 - 20000, False), (2 ** 31 - 100, True), (2 ** 33, True)):
+        t = tiling.RankTile(layout, 1, device=0, river_threshold=10)
+        t.t["fdr"].fill_(1)            # everything flows east
+        t.t["dem"].fill_(1.0)
+        torch.cuda.synchronize()
+        t.fa_local()
+        ext = np.zeros(t.P, np.uint64)
+        ys, xs = tiling.ring_coords(t.H, t.W)
+        ext[(ys == 5) & (xs == 0)] = inflow  # enters at the west border of row 5
+        t.fa_finish(ext)
+        if expect:
+            with pytest.raises(OverflowError):
+                t.check_status()
+        else:
+            t.check_status()
+            fac = t.host("fac")
+            assert fac[5, 0] == inflow and fac[5, 127] == inflow + 127 and fac[6, 127] == 127
