@@ -288,6 +288,28 @@ extern "C" int dt_dev_slope_d8(dt_ctx *c, const float *dem, int64_t H, int64_t W
   return DT_OK;
 }
 
+// Conditioned D8: fill depressions, D8 on the filled surface, resolve flats.  `filled` (device,
+// H*W floats) receives the filled surface; info3 (host, may be NULL) = {flat cells left without a code (0), fill
+// rounds, flat rounds}.  Synchronous: the fixed-point iterations read a flag back per batch of rounds.
+extern "C" int dt_dev_condition_d8(dt_ctx *c, const float *dem, int64_t H, int64_t W, double px, float *filled,
+                                   uint8_t *fdr, int32_t *info3) {
+  DT_CTX(c);
+  DT_TRY(dt_check_hw(H, W));
+  DT_REQUIRE((dem && filled) || H * W == 0, "NULL raster");
+  size_t need = dt_hydro_scratch(H, W);
+  DT_TRY(dt_scratch_reset(c, need));
+  void *scr = dt_scratch_take(c, need);
+  int unresolved = 0, rounds[2] = {0, 0};
+  DT_TRY(dt_launch_condition(c->stream, dem, H, W, px, filled, fdr, scr, &unresolved, rounds));
+  DT_HIP(hipGetLastError());
+  if (info3) {
+    info3[0] = unresolved;
+    info3[1] = rounds[0];
+    info3[2] = rounds[1];
+  }
+  return DT_OK;
+}
+
 extern "C" int dt_dev_flowacc(dt_ctx *c, const uint8_t *fdr, const float *dem, int64_t H, int64_t W,
                               int32_t *acc32) {
   DT_CTX(c);
@@ -1022,5 +1044,27 @@ extern "C" int dt_avaliacao(const int32_t *binary, int8_t *flood, int64_t N, int
     if (klass) D2H(klass, d_k, n * 4, c);
   }
   D2H(counts4, d_c, 4 * sizeof(int64_t), c);
+  return dt_ctx_sync(c);
+}
+
+// conditioned D8, host tier: dem in, D8 codes (flats resolved on the filled surface) and optionally the filled
+// surface out
+extern "C" int dt_d8_conditioned_f32(const float *dem, int64_t H, int64_t W, double px, uint8_t *fdr, float *filled,
+                                     int32_t *info3) {
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  dt_ctx *c;
+  DT_TRY(host_ctx(&c));
+  DT_TRY(dt_check_hw(H, W));
+  size_t n = (size_t)H * W;
+  if (n == 0) return DT_OK;
+  DT_REQUIRE(dem && fdr, "NULL raster");
+  DevBuf d_dem, d_w, d_f;
+  DT_TRY(d_dem.alloc(n * 4));
+  DT_TRY(d_w.alloc(n * 4));
+  DT_TRY(d_f.alloc(n));
+  H2D(d_dem, dem, n * 4, c);
+  DT_TRY(dt_dev_condition_d8(c, d_dem.as<float>(), H, W, px, d_w.as<float>(), d_f.as<uint8_t>(), info3));
+  D2H(fdr, d_f, n, c);
+  if (filled) D2H(filled, d_w, n * 4, c);
   return dt_ctx_sync(c);
 }

@@ -85,4 +85,9 @@ int dt_launch_rank_solve_flowhand(hipStream_t s, int ty, int tx, const int64_t *
                                   int64_t P_rank, void *scratch, uint8_t *res_ok, int32_t *res_nc,
                                   int32_t *res_nd, long long *gidx, float *zr, int32_t *ar);
 
+// hydrological conditioning (dt_hydro.hip): depression filling + flat resolution; synchronous
+size_t dt_hydro_scratch(int64_t H, int64_t W);
+int dt_launch_condition(hipStream_t s, const float *dem, int64_t H, int64_t W, double px, float *filled, uint8_t *fdr,
+                        void *scratch, int *unresolved_host, int *rounds_host);
+
 int dt_flow_impl();  // 1 global kernels, 2 tile-hierarchical (default)

@@ -86,6 +86,17 @@ int dt_slope_f32(const float *dem, int64_t H, int64_t W, double px, float *slope
  * neighbour that sets slope_gpu's maximum, first in its scan order.  `slope` may be NULL. */
 int dt_d8_f32(const float *dem, int64_t H, int64_t W, double px, uint8_t *fdr, float *slope);
 
+/* Net-new: D8 on a hydrologically conditioned surface, for DEMs with pits and flats (the reference
+ * reads such an `fdr` from a GIS tool, Example/example.py:36).  Depressions are filled (priority-flood surface:
+ * outlets = raster edge and cells next to nodata), D8 is taken on the filled surface, and the cells left without a
+ * lower neighbour are routed over their flat to the nearest cell that has a code (hop distance through cells of
+ * the same filled height; among the neighbours one hop closer the first of N,W,E,S, else of NW,NE,SW,SE); a
+ * code-less cell next to nodata drains into its first nodata neighbour.  Every valid cell gets a code and the codes
+ * contain no cycle.  filled (may be NULL) receives the filled surface; info3 (may be NULL) = {cells left without a
+ * code (0), fill rounds, flat rounds}. */
+int dt_d8_conditioned_f32(const float *dem, int64_t H, int64_t W, double px, uint8_t *fdr, float *filled,
+                          int32_t *info3);
+
 /* Net-new N2: flow accumulation = number of upstream cells excluding self; `dem` may be NULL,
  * otherwise cells with dem <= -100 are set to -100.  Cells on a D8 cycle get -100. */
 int dt_flowacc_u8(const uint8_t *fdr, const float *dem, int64_t H, int64_t W, int64_t *acc);
@@ -164,6 +175,9 @@ int dt_dev_slope_d8(dt_ctx *ctx, const float *dem, int64_t H, int64_t W, double 
  * re-read (topoindexes.py:234-295 on top of slope.py:210-259). */
 int dt_dev_slope_twi(dt_ctx *ctx, const float *dem, const int32_t *acc32, int64_t H, int64_t W,
                      double px, double n_top, float *slope, float *slope_rad, float *ti, float *mti);
+/* dt_d8_conditioned_f32 on device rasters; synchronous (the fixed-point iterations read a flag back). */
+int dt_dev_condition_d8(dt_ctx *ctx, const float *dem, int64_t H, int64_t W, double px, float *filled, uint8_t *fdr,
+                        int32_t *info3);
 /* acc32: int32 accumulation (H*W < 2^31); dem may be NULL. */
 int dt_dev_flowacc(dt_ctx *ctx, const uint8_t *fdr, const float *dem, int64_t H, int64_t W,
                    int32_t *acc32);

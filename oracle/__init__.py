@@ -165,3 +165,17 @@ def confusion_multi(desc, flood, th, under=True):
                                     _p(th, C.c_double), C.c_int(th.size), C.c_int(1 if under else 0),
                                     _p(counts, C.c_int64))
     return counts
+
+
+def condition_d8(dem, px):
+    """(fdr, filled): D8 on the depression-filled surface with flats resolved (the definition of
+    dt_d8_conditioned_f32)"""
+    dem = np.ascontiguousarray(dem, np.float32)
+    H, W = dem.shape
+    filled = np.empty((H, W), np.float32)
+    fdr = np.empty((H, W), np.uint8)
+    f = lib().dt_oracle_condition_d8
+    f.restype = C.c_int64
+    rc = f(_p(dem, C.c_float), C.c_int64(H), C.c_int64(W), C.c_double(px), _p(filled, C.c_float), _p(fdr, C.c_uint8))
+    assert rc == 0, "%d flat cells without a code" % rc
+    return fdr, filled

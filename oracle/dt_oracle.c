@@ -359,6 +359,140 @@ int dt_oracle_flowhand_fast(const uint8_t *fdr, const int8_t *river, int64_t H, 
  *   fac <= -100 -> -100 (:252); fac == 0 -> 1 (:255); "+0.01" INSIDE tan (:257,:261);
  *   float64 math, float32 store (:210-211).
  * ---------------------------------------------------------------------------------- */
+/* ---------------------------------------------------------------------------------------------
+ * Hydrological conditioning (net-new; no reference counterpart -- the definition the HIP kernels
+ * of dt_hydro.hip are held to): sequential priority flood for the filled surface, D8 on it, breadth-first hop
+ * distances over the flats.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct { float w; int64_t i; } dt_heap_item;
+static void dt_heap_push(dt_heap_item *h, int64_t *n, dt_heap_item v) {
+  int64_t k = (*n)++;
+  h[k] = v;
+  while (k > 0) {
+    int64_t p = (k - 1) / 2;
+    if (h[p].w <= h[k].w) break;
+    dt_heap_item t = h[p]; h[p] = h[k]; h[k] = t;
+    k = p;
+  }
+}
+static dt_heap_item dt_heap_pop(dt_heap_item *h, int64_t *n) {
+  dt_heap_item top = h[0];
+  h[0] = h[--(*n)];
+  int64_t k = 0;
+  for (;;) {
+    int64_t l = 2 * k + 1, r = l + 1, m = k;
+    if (l < *n && h[l].w < h[m].w) m = l;
+    if (r < *n && h[r].w < h[m].w) m = r;
+    if (m == k) break;
+    dt_heap_item t = h[m]; h[m] = h[k]; h[k] = t;
+    k = m;
+  }
+  return top;
+}
+
+/* filled[c] = min over paths from c to an outlet (raster edge / next to nodata) of the highest cell on the path */
+int dt_oracle_fill(const float *dem, int64_t H, int64_t W, float *filled) {
+  const int64_t N = H * W;
+  uint8_t *done = (uint8_t *)calloc((size_t)N, 1);
+  dt_heap_item *heap = (dt_heap_item *)malloc((size_t)(N + 1) * sizeof(dt_heap_item));
+  if (!done || !heap) return -1;
+  int64_t hn = 0;
+  for (int64_t y = 0; y < H; y++)
+    for (int64_t x = 0; x < W; x++) {
+      int64_t i = y * W + x;
+      if (dem[i] == DT_NODATA) { filled[i] = DT_NODATA; done[i] = 1; continue; }
+      int outlet = (y == 0 || x == 0 || y == H - 1 || x == W - 1);
+      for (int k = 0; k < 8 && !outlet; k++)
+        if (dem[(y + DT_DY[k]) * W + x + DT_DX[k]] == DT_NODATA) outlet = 1;
+      if (outlet) {
+        filled[i] = dem[i];
+        done[i] = 1;
+        dt_heap_item it = {dem[i], i};
+        dt_heap_push(heap, &hn, it);
+      }
+    }
+  while (hn > 0) {
+    dt_heap_item c = dt_heap_pop(heap, &hn);
+    int64_t y = c.i / W, x = c.i % W;
+    for (int k = 0; k < 8; k++) {
+      int64_t yy = y + DT_DY[k], xx = x + DT_DX[k];
+      if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+      int64_t n = yy * W + xx;
+      if (done[n]) continue;
+      done[n] = 1;
+      filled[n] = dem[n] > c.w ? dem[n] : c.w;
+      dt_heap_item it = {filled[n], n};
+      dt_heap_push(heap, &hn, it);
+    }
+  }
+  free(done);
+  free(heap);
+  return 0;
+}
+
+/* D8 on the filled surface with the flats resolved (see include/descriptools_hip.h, dt_d8_conditioned_f32);
+ * returns the number of valid cells left without a code */
+int64_t dt_oracle_condition_d8(const float *dem, int64_t H, int64_t W, double px, float *filled, uint8_t *fdr) {
+  const int64_t N = H * W;
+  if (dt_oracle_fill(dem, H, W, filled) != 0) return -1;
+  float *sl = (float *)malloc((size_t)N * sizeof(float));
+  int64_t *queue = (int64_t *)malloc((size_t)N * sizeof(int64_t));
+  uint32_t *dist = (uint32_t *)malloc((size_t)N * sizeof(uint32_t));
+  if (!sl || !queue || !dist) return -1;
+  dt_oracle_slope_d8_f32(filled, H, W, px, sl, fdr);
+  free(sl);
+  int64_t qh = 0, qt = 0;
+  for (int64_t i = 0; i < N; i++) {
+    dist[i] = 0u;
+    if (filled[i] != DT_NODATA && fdr[i] == 0) {
+      dist[i] = 0x7FFFFFFFu;
+      int64_t y = i / W, x = i % W;
+      for (int k = 0; k < 8; k++) {
+        int64_t yy = y + DT_DY[k], xx = x + DT_DX[k];
+        if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+        if (filled[yy * W + xx] == DT_NODATA) { fdr[i] = DT_CODE[k]; dist[i] = 0u; break; }
+      }
+    }
+  }
+  for (int64_t i = 0; i < N; i++)
+    if (filled[i] != DT_NODATA && dist[i] == 0u) queue[qt++] = i;
+  while (qh < qt) {
+    int64_t c = queue[qh++];
+    int64_t y = c / W, x = c % W;
+    for (int k = 0; k < 8; k++) {
+      int64_t yy = y + DT_DY[k], xx = x + DT_DX[k];
+      if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+      int64_t n = yy * W + xx;
+      if (dist[n] != 0x7FFFFFFFu || filled[n] != filled[c]) continue;
+      dist[n] = dist[c] + 1u;
+      queue[qt++] = n;
+    }
+  }
+  int64_t unresolved = 0;
+  for (int64_t i = 0; i < N; i++) {
+    if (dist[i] == 0u) continue;
+    uint8_t code = 0;
+    if (dist[i] != 0x7FFFFFFFu) {
+      int64_t y = i / W, x = i % W;
+      /* one hop closer: the four cardinal neighbours first (N, W, E, S), then the diagonals (NW, NE, SW, SE) --
+       * the order in which N1's steepest descent would rank equal drops (a cardinal step is the shorter one) */
+      static const int pref[8] = {1, 3, 4, 6, 0, 2, 5, 7};
+      for (int q = 0; q < 8 && !code; q++) {
+        int k = pref[q];
+        int64_t yy = y + DT_DY[k], xx = x + DT_DX[k];
+        if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+        int64_t n = yy * W + xx;
+        if (filled[n] == filled[i] && dist[n] == dist[i] - 1u) code = DT_CODE[k];
+      }
+    }
+    if (!code) unresolved++;
+    fdr[i] = code;
+  }
+  free(queue);
+  free(dist);
+  return unresolved;
+}
+
 int dt_oracle_twi(const int64_t *fac, const float *slope_rad, int64_t N, double px, double n,
                   float *ti, float *mti) {
   DT_OMP_FOR
