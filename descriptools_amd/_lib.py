@@ -27,6 +27,9 @@ _SIGS = {
     "dt_device_count": (ci, []),
     "dt_set_flow_impl": (ci, [ci]),
     "dt_debug_set": (ci, [ci, ci]),
+    "dt_host_trim": (ci, []),
+    "dt_host_alloc": (ci, [i64, C.POINTER(vp)]),
+    "dt_host_free": (ci, [vp]),
     "dt_ctx_create": (ci, [ci, vp, C.POINTER(vp)]),
     "dt_ctx_destroy": (ci, [vp]),
     "dt_ctx_set_stream": (ci, [vp, vp]),

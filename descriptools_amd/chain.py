@@ -112,20 +112,27 @@ class Chain:
 
 
 def run_host(dem, px, **kw):
-    """Convenience: host DEM in, dict of host rasters out (fac / idx widened to int64)."""
+    """Convenience: host DEM in, dict of host rasters out (fac / idx widened to int64 on the device)."""
     dem32 = _lib.dem_f32(dem)
     H, W = dem32.shape
     ctx = Context()
     ch = Chain(H, W, ctx=ctx, px=px, **kw)
     d_dem = ctx.to_device(dem32)
+    wide = ctx.empty((H, W), np.int64)
     try:
         ch.run(d_dem.ptr)
-        ctx.sync()
-        out = {k: ch.buf[k].to_host() for k, _ in OUTPUTS}
+        # rasters come back into page-locked host memory from a recycling pool (device.PinnedPool): the copies are
+        # the cost of this call, not the kernels
+        out = {}
+        for k, _ in OUTPUTS:
+            if k in ("fac", "idx"):  # the reference's dtypes for these are int64
+                check(_lib.lib().dt_dev_i32_to_i64(ctx.h, ch.buf[k].ptr, ch.N, wide.ptr))
+                out[k] = wide.to_host(pinned=True)
+            else:
+                out[k] = ch.buf[k].to_host(pinned=True)
     finally:
         d_dem.free()
+        wide.free()
         ch.free()
         ctx.close()
-    out["fac"] = out["fac"].astype(np.int64)
-    out["idx"] = out["idx"].astype(np.int64)
     return out

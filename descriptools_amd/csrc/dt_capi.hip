@@ -3,6 +3,7 @@
 #include <stdlib.h>
 
 #include <mutex>
+#include <vector>
 
 #include "dt_common.h"
 #include "dt_kernels.h"
@@ -47,6 +48,8 @@ extern "C" int dt_ctx_create(int device, void *stream, dt_ctx **out) {
   c->scratch = nullptr;
   c->scratch_bytes = 0;
   c->scratch_used = 0;
+  c->scratch_owner = 0;
+  c->owner_h = c->owner_w = 0;
   c->scratch2 = nullptr;
   c->scratch2_bytes = 0;
   c->ev = nullptr;
@@ -145,6 +148,7 @@ int dt_scratch_reset(dt_ctx *c, size_t total) {
     c->scratch_bytes = total;
   }
   c->scratch_used = 0;
+  c->scratch_owner = 0;  // whatever two-phase state was here is about to be overwritten
   return DT_OK;
 }
 void *dt_scratch_take(dt_ctx *c, size_t bytes) {
@@ -574,6 +578,9 @@ extern "C" int dt_dev_flowacc_local_w(dt_ctx *c, const dt_window *win, const uin
   DT_TRY(dt_launch_fa_local(c->stream, w, fdr, scr, need, acc32, 1));
   DT_TRY(dt_launch_fa_summary(c->stream, w, scr, A_perim, xr_perim, code_perim));
   DT_HIP(hipGetLastError());
+  c->scratch_owner = 1;
+  c->owner_h = w.H;
+  c->owner_w = w.W;
   return DT_OK;
 }
 
@@ -585,7 +592,9 @@ extern "C" int dt_dev_flowacc_finish_w(dt_ctx *c, const dt_window *win, const ui
   DtWin w;
   DT_TRY(dt_convert_window(win, &w));
   DT_REQUIRE(fdr && acc32, "NULL raster");
-  DT_REQUIRE(c->scratch && c->scratch_bytes >= dt_flowacc_tiled_scratch(w.H, w.W), "no local phase before finish");
+  DT_REQUIRE(c->scratch && c->scratch_owner == 1 && c->owner_h == w.H && c->owner_w == w.W,
+             "dt_dev_flowacc_finish_w without a matching dt_dev_flowacc_local_w on this context (another call has "
+             "used the context's scratch in between)");
   DT_TRY(dt_launch_fa_finish(c->stream, w, fdr, dem, c->scratch, (const unsigned long long *)ext_perim, threshold,
                              acc32, river, c->status));
   DT_HIP(hipGetLastError());
@@ -605,6 +614,9 @@ extern "C" int dt_dev_flowhand_local_w(dt_ctx *c, const dt_window *win, const fl
   DT_TRY(dt_launch_fh_local(c->stream, w, fdr, river, scr, need));
   DT_TRY(dt_launch_fh_summary(c->stream, w, scr, dem, acc32, kind, ref, nc, nd, zr, ar));
   DT_HIP(hipGetLastError());
+  c->scratch_owner = 2;
+  c->owner_h = w.H;
+  c->owner_w = w.W;
   return DT_OK;
 }
 
@@ -622,7 +634,9 @@ extern "C" int dt_dev_flowhand_finish_w(dt_ctx *c, const dt_window *win, const f
   DT_REQUIRE(!hand || dem, "hand needs dem");
   DT_REQUIRE(!a_river || acc32, "a_river needs acc32");
   DT_REQUIRE(!res_ok || (res_nc && res_nd && rem_gidx && rem_zr && rem_ar), "incomplete rank-exit results");
-  DT_REQUIRE(c->scratch && c->scratch_bytes >= dt_flowhand_tiled_scratch(w.H, w.W), "no local phase before finish");
+  DT_REQUIRE(c->scratch && c->scratch_owner == 2 && c->owner_h == w.H && c->owner_w == w.W,
+             "flowhand finish without a matching dt_dev_flowhand_local_w on this context (another call has used the "
+             "context's scratch in between)");
   DT_TRY(dt_launch_fh_finish(c->stream, w, dem, fdr, river, acc32, px, c->scratch, res_ok, res_nc, res_nd,
                              (const long long *)rem_gidx, rem_zr, rem_ar, fdist, idx32, (long long *)idx64, hand,
                              a_river));
@@ -642,7 +656,9 @@ extern "C" int dt_dev_flowhand_gfi_finish_w(dt_ctx *c, const dt_window *win, con
   DT_TRY(dt_convert_window(win, &w));
   DT_REQUIRE(dem && fdr && river && acc32 && gfi && lnhlh, "NULL raster");
   DT_REQUIRE(!res_ok || (res_nc && res_nd && rem_gidx && rem_zr && rem_ar), "incomplete rank-exit results");
-  DT_REQUIRE(c->scratch && c->scratch_bytes >= dt_flowhand_tiled_scratch(w.H, w.W), "no local phase before finish");
+  DT_REQUIRE(c->scratch && c->scratch_owner == 2 && c->owner_h == w.H && c->owner_w == w.W,
+             "flowhand finish without a matching dt_dev_flowhand_local_w on this context (another call has used the "
+             "context's scratch in between)");
   DT_TRY(dt_launch_fh_finish(c->stream, w, dem, fdr, river, acc32, px, c->scratch, res_ok, res_nc, res_nd,
                              (const long long *)rem_gidx, rem_zr, rem_ar, fdist, idx32, (long long *)idx64, hand,
                              a_river, gfi, lnhlh, n_gfi, b, px));
@@ -699,15 +715,59 @@ static int host_ctx(dt_ctx **out) {
   return hipSetDevice(g_host_ctx->device) == hipSuccess ? DT_OK : DT_EHIP;
 }
 
-// RAII device buffer
+// Device blocks of the host tier, cached per process: a drop-in caller makes one dt_<op> call per descriptor and
+// raster-sized hipMalloc / hipFree pairs cost more than the kernels.  Blocks are handed out best-fit (within 25 %
+// of the request) and kept when released; dt_host_trim() frees the idle ones.  Guarded by g_host_mu.
+struct HostBlock {
+  void *p;
+  size_t bytes;
+  bool busy;
+};
+static std::vector<HostBlock> g_blocks;
+static void *host_block_take(size_t bytes) {
+  int best = -1;
+  for (size_t i = 0; i < g_blocks.size(); i++)
+    if (!g_blocks[i].busy && g_blocks[i].bytes >= bytes && g_blocks[i].bytes <= bytes + bytes / 4 + 4096 &&
+        (best < 0 || g_blocks[i].bytes < g_blocks[(size_t)best].bytes))
+      best = (int)i;
+  if (best >= 0) {
+    g_blocks[(size_t)best].busy = true;
+    return g_blocks[(size_t)best].p;
+  }
+  void *p = nullptr;
+  if (hipMalloc(&p, bytes) != hipSuccess) {
+    // out of memory: drop every idle block and try once more
+    for (size_t i = 0; i < g_blocks.size();) {
+      if (!g_blocks[i].busy) {
+        (void)hipFree(g_blocks[i].p);
+        g_blocks.erase(g_blocks.begin() + (long)i);
+      } else {
+        i++;
+      }
+    }
+    (void)hipGetLastError();
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+  }
+  g_blocks.push_back(HostBlock{p, bytes, true});
+  return p;
+}
+static void host_block_release(void *p) {
+  for (auto &b : g_blocks)
+    if (b.p == p) b.busy = false;
+}
+// RAII device buffer of the host tier
 struct DevBuf {
   void *p = nullptr;
   ~DevBuf() {
-    if (p) (void)hipFree(p);
+    if (p) host_block_release(p);
   }
   int alloc(size_t bytes) {
     if (bytes == 0) bytes = 16;
-    DT_HIP(hipMalloc(&p, bytes));
+    p = host_block_take(bytes);
+    if (!p) {
+      dt_set_error("hipMalloc of %zu bytes failed", bytes);
+      return DT_ENOMEM;
+    }
     return DT_OK;
   }
   template <typename T>
@@ -715,6 +775,31 @@ struct DevBuf {
     return (T *)p;
   }
 };
+extern "C" int dt_host_trim(void) {
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  if (g_host_ctx) DT_HIP(hipStreamSynchronize(g_host_ctx->stream));
+  for (size_t i = 0; i < g_blocks.size();) {
+    if (!g_blocks[i].busy) {
+      DT_HIP(hipFree(g_blocks[i].p));
+      g_blocks.erase(g_blocks.begin() + (long)i);
+    } else {
+      i++;
+    }
+  }
+  return DT_OK;
+}
+// page-locked host memory for rasters that cross PCIe at full rate (the Python package keeps a pool of these
+// behind the arrays chain.run_host returns)
+extern "C" int dt_host_alloc(int64_t bytes, void **out) {
+  DT_REQUIRE(out && bytes >= 0, "bad arguments");
+  *out = nullptr;
+  DT_HIP(hipHostMalloc(out, bytes > 0 ? (size_t)bytes : 16, hipHostMallocDefault));
+  return DT_OK;
+}
+extern "C" int dt_host_free(void *p) {
+  if (p) DT_HIP(hipHostFree(p));
+  return DT_OK;
+}
 #define H2D(dst, src, bytes, c) DT_HIP(hipMemcpyAsync((dst).p, (src), (bytes), hipMemcpyHostToDevice, (c)->stream))
 #define D2H(dst, src, bytes, c) DT_HIP(hipMemcpyAsync((dst), (src).p, (bytes), hipMemcpyDeviceToHost, (c)->stream))
 

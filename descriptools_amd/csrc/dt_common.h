@@ -48,6 +48,8 @@ struct dt_ctx {
   char *scratch;
   size_t scratch_bytes;
   size_t scratch_used;  // bump pointer, reset at the start of every entry point
+  int scratch_owner;    // which two-phase op's state lives in `scratch` (0 none, 1 flow accumulation, 2 HAND):
+  int64_t owner_h, owner_w;  // set by *_local_w, cleared by every dt_scratch_reset, required by *_finish_w
   char *scratch2;       // rank-level solves (must not disturb the two-phase tile scratch)
   size_t scratch2_bytes;
   hipEvent_t ev;        // fork / join with another context's stream (created on first use)

@@ -8,6 +8,49 @@ from . import _lib
 from ._lib import check
 
 
+class PinnedPool:
+    """Page-locked host rasters (dt_host_alloc) behind numpy arrays.  Device-to-host copies into pageable memory
+    run at a fraction of the PCIe rate, and locking pages costs more than the copy, so blocks are recycled: when
+    the last reference to an array dies its block returns to the pool, and a later array of the same size class
+    gets it.  chain.run_host's rasters come from here."""
+
+    def __init__(self):
+        self._free = {}   # bytes (size class) -> [address]
+        self._live = 0
+
+    @staticmethod
+    def _klass(nbytes):
+        return max(4096, 1 << (int(nbytes) - 1).bit_length()) if nbytes > (1 << 26) else max(4096, (int(nbytes) + 4095) // 4096 * 4096)
+
+    def empty(self, shape, dtype):
+        import weakref
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        k = self._klass(max(n, 1))
+        lst = self._free.get(k)
+        if lst:
+            addr = lst.pop()
+        else:
+            out = C.c_void_p()
+            check(_lib.lib().dt_host_alloc(k, C.byref(out)))
+            addr = out.value
+        buf = (C.c_char * k).from_address(addr)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        weakref.finalize(buf, self._give_back, k, addr)  # buf lives as long as any view of it
+        return arr
+
+    def _give_back(self, k, addr):
+        self._free.setdefault(k, []).append(addr)
+
+    def trim(self):
+        for k, lst in self._free.items():
+            while lst:
+                check(_lib.lib().dt_host_free(C.c_void_p(lst.pop())))
+
+
+PINNED = PinnedPool()
+
+
 class DeviceArray:
     def __init__(self, ctx, shape, dtype):
         self.ctx, self.shape, self.dtype = ctx, tuple(np.atleast_1d(shape)), np.dtype(dtype)
@@ -26,8 +69,9 @@ class DeviceArray:
         check(_lib.lib().dt_dev_h2d(self.ctx.h, self.ptr, a.ctypes.data_as(C.c_void_p), self.nbytes))
         return self
 
-    def to_host(self):
-        out = np.empty(self.shape, self.dtype)
+    def to_host(self, pinned=False):
+        """copy to a fresh host array (pinned=True: page-locked, from the recycling pool: PCIe at full rate)"""
+        out = PINNED.empty(self.shape, self.dtype) if pinned and self.nbytes >= (1 << 20) else np.empty(self.shape, self.dtype)
         check(_lib.lib().dt_dev_d2h(self.ctx.h, out.ctypes.data_as(C.c_void_p), self.ptr, self.nbytes))
         return out
 

@@ -75,7 +75,13 @@ int dt_ctx_sync(dt_ctx *ctx);
 int dt_ctx_status(dt_ctx *ctx, int32_t *out);
 int64_t dt_ctx_scratch_bytes(dt_ctx *ctx);
 
-/* ---- host-pointer tier (drop-in for the reference's *_cpu shims) ----------------------- */
+/* ---- host-pointer tier (drop-in for the reference's *_cpu shims) -----------------------
+ * Device blocks behind these calls are cached per process (dt_host_trim frees the idle ones); dt_host_alloc /
+ * dt_host_free give page-locked host memory for rasters that should cross PCIe at the full rate. */
+int dt_host_trim(void);
+int dt_host_alloc(int64_t bytes, void **out);
+int dt_host_free(void *p);
+
 
 /* slope.slope_cpu + slope_gpu (slope.py:152-259): steepest-descent slope in percent.  The
  * -100 ring the reference pads on (slope.py:175-182) is implicit: neighbours outside the raster

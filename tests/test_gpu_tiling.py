@@ -308,3 +308,27 @@ def test_accumulation_overflow_is_reported():
             t.check_status()
             fac = t.host("fac")
             assert fac[5, 0] == inflow and fac[5, 127] == inflow + 127 and fac[6, 127] == 127
+
+
+def test_two_phase_state_is_guarded():
+    """dt_dev_*_finish_w needs the state its *_local_w left in the context's scratch: a scratch-using call in
+    between must make the finish fail loudly instead of producing wrong rasters with rc 0."""
+    import ctypes as C
+    import torch
+    from descriptools_amd import _lib, tiling
+    layout = tiling.Layout([128], [128])
+    t = tiling.RankTile(layout, 0, device=0, river_threshold=10)
+    t.synth_dem(3)
+    t.d8()
+    t.fa_local()
+    out3 = torch.zeros(3, dtype=torch.float32, device="cuda")
+    _lib.check(_lib.lib().dt_dev_unique_extremes_f32(t.ctx.h, t.p("dem"), 16, out3.data_ptr()))  # takes the scratch
+    with pytest.raises(RuntimeError, match="without a matching"):
+        t.fa_finish(None)
+    t.fa_local()
+    t.fa_finish(None)          # fine again
+    t.fh_local()
+    with pytest.raises(RuntimeError, match="without a matching"):
+        t.fa_finish(None)      # the HAND state replaced the flow-accumulation state
+    t.fh_finish(None)
+    t.ctx.sync()
