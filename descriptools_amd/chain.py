@@ -27,7 +27,7 @@ ALGO_BYTES_PER_CELL = 90
 # dem 4 + fac 4 and writes fdist, idx, hand, gfi, lnhlh (20).  "d8" writes fdr only: slope comes out of the fused
 # slope+TI+MTI stencil (dem 4 + fac 4 read, slope 4 + TI 4 + MTI 4 written = the north_star's 20 B/cell).
 OPS = (
-    ("d8", 5, ["k_stencil<false, true, false>"]),
+    ("d8", 5, ["k_d8<false>", "k_d8_fix"]),
     ("downslope", 9, ["k_downslope_win"]),
     ("flowacc_river", 5 + 1, ["k_fa_tile1", "k_fa_reduce", "k_fa_poison", "k_fa_tile3<true, true>"]),
     ("flowhand_local", 2, ["k_fh_tile1n", "k_fh_tile1", "k_fh_ghost_init", "k_fh_node_jump", "k_fh_rank_summary"]),

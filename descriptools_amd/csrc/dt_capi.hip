@@ -286,8 +286,9 @@ extern "C" int dt_dev_slope_d8(dt_ctx *c, const float *dem, int64_t H, int64_t W
   DT_TRY(dt_check_hw(H, W));
   DT_REQUIRE(dem || H * W == 0, "dem is NULL");
   DT_REQUIRE(slope || fdr || slope_rad, "no output requested");
+  DT_TRY(dt_side_reserve(c, &c->aux, &c->aux_bytes, dt_stencil_aux_bytes(H, W)));
   DT_TRY(dt_launch_stencil(c->stream, dt_full_window(H, W), dem, px, slope, fdr, slope_rad, nullptr, 0.0, nullptr,
-                           nullptr));
+                           nullptr, c->aux));
   DT_HIP(hipGetLastError());
   return DT_OK;
 }
@@ -536,7 +537,8 @@ extern "C" int dt_dev_slope_d8_w(dt_ctx *c, const dt_window *win, const float *d
   DtWin w;
   DT_TRY(dt_convert_window(win, &w));
   DT_REQUIRE(dem && (slope || fdr || slope_rad), "NULL raster");
-  DT_TRY(dt_launch_stencil(c->stream, w, dem, px, slope, fdr, slope_rad, nullptr, 0.0, nullptr, nullptr));
+  DT_TRY(dt_side_reserve(c, &c->aux, &c->aux_bytes, dt_stencil_aux_bytes(w.H, w.W)));
+  DT_TRY(dt_launch_stencil(c->stream, w, dem, px, slope, fdr, slope_rad, nullptr, 0.0, nullptr, nullptr, c->aux));
   DT_HIP(hipGetLastError());
   return DT_OK;
 }

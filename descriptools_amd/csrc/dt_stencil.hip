@@ -135,6 +135,41 @@ __device__ __forceinline__ void sd_stage(float *t, const float *__restrict__ dem
   const int ylo = -(w.gy0 > 0 ? 1 : 0), yhi = H + (w.gy0 + H < w.Hg ? 1 : 0);  // readable rows [ylo, yhi)
   const int xlo = -(w.gx0 > 0 ? 1 : 0), xhi = W + (w.gx0 + W < w.Wg ? 1 : 0);
   const float pinf = __builtin_inff();
+  // Block-uniform fast form for tiles whose whole 18 x 258 window is readable: every load of a thread is issued
+  // before the first use (five 16-byte loads and one halo value in flight per thread).  The guarded loop below
+  // waits for each load before the next: five dependent memory round trips per workgroup, which made every
+  // stencil kernel latency-bound (the D8-only kernel took as long as the 8 B/cell slope kernel).
+  if (vec_ok && y0 - 1 >= ylo && y0 + SD_TY + 1 <= yhi && x0 - 1 >= xlo && x0 + SD_TX + 1 <= xhi) {
+    constexpr int NV = ((SD_TY + 2) * (SD_TX / 4) + 255) / 256;  // 5
+    float4 v[NV];
+    const float *base = dem + (long long)(y0 - 1) * w.ld + x0;
+#pragma unroll
+    for (int u = 0; u < NV; u++) {
+      const int i = threadIdx.x + 256 * u;
+      if (i < (SD_TY + 2) * (SD_TX / 4)) {
+        const int r = i / (SD_TX / 4), c4 = i - r * (SD_TX / 4);
+        v[u] = *reinterpret_cast<const float4 *>(base + (long long)r * w.ld + c4 * 4);
+      }
+    }
+    float hv = 0.0f;
+    const int hr = threadIdx.x >> 1, hside = threadIdx.x & 1;
+    if (threadIdx.x < (SD_TY + 2) * 2) hv = base[(long long)hr * w.ld + (hside ? SD_TX : -1)];
+#pragma unroll
+    for (int u = 0; u < NV; u++) {
+      const int i = threadIdx.x + 256 * u;
+      if (i < (SD_TY + 2) * (SD_TX / 4)) {
+        const int r = i / (SD_TX / 4), c4 = i - r * (SD_TX / 4);
+        float4 q = v[u];
+        q.x = q.x == DT_NODATA ? pinf : q.x;
+        q.y = q.y == DT_NODATA ? pinf : q.y;
+        q.z = q.z == DT_NODATA ? pinf : q.z;
+        q.w = q.w == DT_NODATA ? pinf : q.w;
+        *reinterpret_cast<float4 *>(&t[r * SD_LDW + 4 + c4 * 4]) = q;
+      }
+    }
+    if (threadIdx.x < (SD_TY + 2) * 2) t[hr * SD_LDW + (hside ? 4 + SD_TX : 3)] = hv == DT_NODATA ? pinf : hv;
+    return;
+  }
   for (int i = threadIdx.x; i < (SD_TY + 2) * (SD_TX / 4); i += 256) {
     int r = i / (SD_TX / 4), c4 = i - r * (SD_TX / 4);
     int gy = y0 - 1 + r, gx = x0 + c4 * 4;
@@ -510,6 +545,167 @@ __global__ __launch_bounds__(256) void k_slope_twi_fix(const float *__restrict__
   }
 }
 
+// ===========================================================================================
+// D8 alone (N1), hot / cold like k_slope_twi: the chain's first kernel writes only the direction codes.
+// Within a class the first strict maximum of the float32 differences wins (scan order N, W, E, S / NW, NE, SW, SE);
+// between the classes the reference compares cb / px with db / (px sqrt 2), i.e. cb with db / sqrt 2: decided in
+// float32 whenever the two differ by more than 2^-21 relative (the float32 product is within 2^-23 of db / sqrt 2),
+// flagged for the exact float64 path of dt_slope_cell otherwise (~1e-6 of the cells; equality is impossible for
+// non-zero differences, the ratio being irrational).
+// ===========================================================================================
+__device__ __forceinline__ bool sd_d8_fast(float c, float nw, float n, float ne, float w, float e, float sw, float s,
+                                           float se, uint32_t &code) {
+  float cb = 0.0f, db = 0.0f;
+  uint32_t ccode = 0, dcode = 0;
+#define SD_CAND(nb, best, bcode, code_) \
+  {                                     \
+    const float d_ = c - (nb);          \
+    const bool up_ = d_ > best;         \
+    best = up_ ? d_ : best;             \
+    bcode = up_ ? code_ : bcode;        \
+  }
+  SD_CAND(n, cb, ccode, 64u)
+  SD_CAND(w, cb, ccode, 16u)
+  SD_CAND(e, cb, ccode, 1u)
+  SD_CAND(s, cb, ccode, 4u)
+  SD_CAND(nw, db, dcode, 32u)
+  SD_CAND(ne, db, dcode, 128u)
+  SD_CAND(sw, db, dcode, 8u)
+  SD_CAND(se, db, dcode, 2u)
+#undef SD_CAND
+  const float t = db * 0.70710678118654752f;
+  const float hi = fmaxf(cb, t);
+  code = cb > t ? ccode : dcode;  // both zero: dcode == 0
+  // not finite / tiny differences go to the exact path as well (inf - finite = inf would compare equal)
+  return hi != 0.0f && (fabsf(cb - t) <= hi * 4.76837158e-7f || !(hi < 3.0e38f) || hi < 1.0e-30f);
+}
+
+template <bool NT>
+__global__ __launch_bounds__(256, 8) void k_d8(const float *__restrict__ dem, DtWin w, uint8_t *__restrict__ fdr,
+                                              int tiles_x, int tiles_y, int vec_ok, uint8_t *__restrict__ tile_mark,
+                                              uint16_t *__restrict__ lane_mask) {
+  __shared__ __attribute__((aligned(16))) float t[(SD_TY + 2) * SD_LDW];
+  const int tile = sd_tile_of_block(blockIdx.x, tiles_x * tiles_y);
+  const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+  const int x0 = txi * SD_TX, y0 = tyi * SD_TY;
+  const int H = w.H, W = w.W;
+  const float pinf = __builtin_inff();
+  sd_stage(t, dem, w, x0, y0, vec_ok);
+  __syncthreads();
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int cx = tx * 4, ry = ty * 4;
+  const int gx = x0 + cx;
+  auto load_row = [&](int lr, float *dst) {
+    const float *row = &t[lr * SD_LDW];
+    float4 m = *reinterpret_cast<const float4 *>(row + 4 + cx);
+    float lh = row[3], rh = row[4 + SD_TX];
+    dst[0] = sd_from_prev_lane(lh, m.w);
+    dst[1] = m.x;
+    dst[2] = m.y;
+    dst[3] = m.z;
+    dst[4] = m.w;
+    dst[5] = sd_from_next_lane(rh, m.x);
+  };
+  const bool full = vec_ok && gx + 3 < W;
+  float a[6], bb[6], cc[6];
+  load_row(ry, a);
+  load_row(ry + 1, bb);
+  uint32_t mask = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int gy = y0 + ry + j;
+    load_row(ry + 2 + j, cc);
+    uint32_t codes = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const float c = bb[k + 1];
+      const bool nod = !(c < pinf) || c <= DT_NODATA;  // staged nodata (+inf), NaN, or below the sentinel: code 0
+      uint32_t code;
+      bool flag = sd_d8_fast(c, a[k], a[k + 1], a[k + 2], bb[k], bb[k + 2], cc[k], cc[k + 1], cc[k + 2], code);
+      // N1 border rule: a border cell with no lower neighbour drains out of the raster
+      const int gyy = w.gy0 + gy, gxx = w.gx0 + gx + k;
+      const uint32_t out = gyy == w.Hg - 1 ? 4u : (gyy == 0 ? 64u : (gxx == 0 ? 16u : (gxx == w.Wg - 1 ? 1u : 0u)));
+      code = code == 0u ? out : code;
+      codes |= (nod ? 0u : code) << (8 * k);
+      mask |= ((flag && !nod) ? 1u : 0u) << (4 * j + k);
+    }
+    if (gy < H) {
+      const long long o = (long long)gy * w.ld + gx;
+      if (full) {
+        if (NT) __builtin_nontemporal_store(codes, reinterpret_cast<uint32_t *>(fdr + o));
+        else *reinterpret_cast<uint32_t *>(fdr + o) = codes;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          if (gx + k < W) fdr[o + k] = (uint8_t)(codes >> (8 * k));
+          else mask &= ~(1u << (4 * j + k));
+        }
+      }
+    } else {
+      mask &= ~(0xFu << (4 * j));
+    }
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+      a[q] = bb[q];
+      bb[q] = cc[q];
+    }
+  }
+  const int any = __syncthreads_or(mask != 0u);
+  if (threadIdx.x == 0) tile_mark[tile] = (uint8_t)(any != 0);
+  if (any) lane_mask[(size_t)tile * 256 + threadIdx.x] = (uint16_t)mask;
+}
+
+__global__ __launch_bounds__(256) void k_d8_fix(const float *__restrict__ dem, DtWin w, double px,
+                                               uint8_t *__restrict__ fdr, int tiles_x, int tiles_y, int vec_ok,
+                                               const uint8_t *__restrict__ tile_mark,
+                                               const uint16_t *__restrict__ lane_mask) {
+  __shared__ __attribute__((aligned(16))) float t[(SD_TY + 2) * SD_LDW];
+  __shared__ uint8_t s_mark[256];
+  const int ntiles = tiles_x * tiles_y;
+  const double dcard = px, ddiag = px * sqrt(2.0);
+  const double inv_card = 1.0 / dcard, inv_diag = 1.0 / ddiag;
+  const float pinf = __builtin_inff();
+  for (int chunk = blockIdx.x; chunk * 256 < ntiles; chunk += gridDim.x) {
+    const int mine = chunk * 256 + (int)threadIdx.x;
+    const uint8_t m = mine < ntiles ? tile_mark[mine] : (uint8_t)0;
+    __syncthreads();
+    s_mark[threadIdx.x] = m;
+    if (!__syncthreads_or(m)) continue;
+    for (int i = 0; i < 256; i++) {
+      if (!s_mark[i]) continue;  // block-uniform
+      const int tile = chunk * 256 + i;
+      const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+      const int x0 = txi * SD_TX, y0 = tyi * SD_TY;
+      __syncthreads();
+      sd_stage(t, dem, w, x0, y0, vec_ok);
+      __syncthreads();
+      uint32_t mask = lane_mask[(size_t)tile * 256 + threadIdx.x];
+      const int cx = (threadIdx.x & 63) * 4, ry = (threadIdx.x >> 6) * 4;
+      while (mask) {
+        const int bit = __ffs((int)mask) - 1;
+        mask &= mask - 1u;
+        const int j = bit >> 2, k = bit & 3;
+        const int gy = y0 + ry + j, gx = x0 + cx + k;
+        if (gy >= w.H || gx >= w.W) continue;
+        const float *p = &t[(ry + j + 1) * SD_LDW + 4 + cx + k];
+        const float cz = p[0] == pinf ? DT_NODATA : p[0];
+        SlopeCell sc = dt_slope_cell<true, false>(cz, p[-SD_LDW - 1], p[-SD_LDW], p[-SD_LDW + 1], p[-1], p[1],
+                                                  p[SD_LDW - 1], p[SD_LDW], p[SD_LDW + 1], inv_card, inv_diag, dcard,
+                                                  ddiag);
+        uint32_t code = sc.code;
+        const int gyy = w.gy0 + gy, gxx = w.gx0 + gx;
+        if (code == 0u && cz > DT_NODATA) {
+          if (gyy == w.Hg - 1) code = 4u;
+          else if (gyy == 0) code = 64u;
+          else if (gxx == 0) code = 16u;
+          else if (gxx == w.Wg - 1) code = 1u;
+        }
+        fdr[(long long)gy * w.ld + gx] = (uint8_t)code;
+      }
+    }
+  }
+}
+
 // bytes of the mark / mask workspace of the fused slope + TI + MTI launch for an H x W window
 size_t dt_stencil_aux_bytes(int64_t H, int64_t W) {
   int64_t ntiles = ((W + SD_TX - 1) / SD_TX) * ((H + SD_TY - 1) / SD_TY);
@@ -559,7 +755,13 @@ int dt_launch_stencil(hipStream_t s, const DtWin &w, const float *dem, double px
   else if (ws && wr) DT_GO(true, false, true);
   else if (wf && wr) DT_GO(false, true, true);
   else if (ws) DT_GO(true, false, false);
-  else if (wf) DT_GO(false, true, false);
+  else if (wf && aux) {  // D8 alone with a workspace: the hot / cold pair
+    uint8_t *mark = (uint8_t *)aux;
+    uint16_t *lmask = (uint16_t *)((char *)aux + dt_align256((size_t)ntiles));
+    hipLaunchKernelGGL(k_d8<false>, g, b, 0, s, dem, w, fdr, tiles_x, tiles_y, vec_ok, mark, lmask);
+    unsigned fix_blocks = (unsigned)((ntiles + 255) / 256 < 1024 ? (ntiles + 255) / 256 : 1024);
+    hipLaunchKernelGGL(k_d8_fix, dim3(fix_blocks), b, 0, s, dem, w, px, fdr, tiles_x, tiles_y, vec_ok, mark, lmask);
+  } else if (wf) DT_GO(false, true, false);
   else if (wr) DT_GO(false, false, true);
 #undef DT_GO
   return DT_OK;
