@@ -59,10 +59,11 @@ __device__ __forceinline__ uint32_t dt_node_of(int y, int x, int tiles_x) {
 }
 
 // ---- tile staging -----------------------------------------------------------------------------
-// direction codes of the tile's core cells into LDS (0 outside the core)
-__device__ __forceinline__ void dt_tile_load_fdr(const uint8_t *__restrict__ fdr, const DtWin &w, int y0,
-                                                 int x0, uint8_t *s_fdr) {
-  int t = threadIdx.x;  // 256 threads x 16 bytes: one 64-byte row per 4 threads
+// direction codes of the tile's core cells into LDS (0 outside the core): 256 threads x 16 bytes, one 64-byte row
+// per 4 threads.  Split into the load and the LDS store so that a kernel can have several tile loads in flight
+// before it waits for the first (dt_tile_load_fdr = both at once).
+__device__ __forceinline__ uint4 dt_tile_fetch16(const uint8_t *__restrict__ fdr, const DtWin &w, int y0, int x0) {
+  int t = threadIdx.x;
   int r = t >> 2, c = (t & 3) * 16;
   int gy = y0 + r, gx = x0 + c;
   uint4 v = make_uint4(0, 0, 0, 0);
@@ -78,7 +79,15 @@ __device__ __forceinline__ void dt_tile_load_fdr(const uint8_t *__restrict__ fdr
       v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
     }
   }
-  *reinterpret_cast<uint4 *>(&s_fdr[r * TW + c]) = v;
+  return v;
+}
+__device__ __forceinline__ void dt_tile_put16(uint8_t *s_fdr, uint4 v) {
+  int t = threadIdx.x;
+  *reinterpret_cast<uint4 *>(&s_fdr[(t >> 2) * TW + (t & 3) * 16]) = v;
+}
+__device__ __forceinline__ void dt_tile_load_fdr(const uint8_t *__restrict__ fdr, const DtWin &w, int y0,
+                                                 int x0, uint8_t *s_fdr) {
+  dt_tile_put16(s_fdr, dt_tile_fetch16(fdr, w, y0, x0));
 }
 
 // local successor of tile cell (ly, lx): local index, NX_EXIT, NX_REXIT or NX_SINK
@@ -218,7 +227,27 @@ __global__ __launch_bounds__(256, 6) void k_fa_tile1(const uint8_t *__restrict__
   const int tile = blockIdx.x;
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int y0 = ty * TH, x0 = tx * TW;
-  dt_tile_load_fdr(fdr, w, y0, x0, s_fdr);
+  // The tile's codes and, for the perimeter lanes, the codes of the <= 5 neighbours outside the tile: all loads in
+  // flight together, before the first barrier (fetched one by one, each behind the test of the previous, the
+  // neighbour codes were five dependent memory round trips on the workgroup's path to its barrier).
+  const uint4 v_fdr = dt_tile_fetch16(fdr, w, y0, x0);
+  const int8_t qdy[8] = {-1, -1, -1, 0, 0, 1, 1, 1}, qdx[8] = {-1, 0, 1, -1, 1, -1, 0, 1};  // NW N NE W E SW S SE
+  uint32_t c2[8];
+  int ply = 0, plx = 0;
+  if (threadIdx.x < PS) dt_cell_of_slot(threadIdx.x, ply, plx);
+  {
+    const int y = y0 + ply, x = x0 + plx;
+    const bool live = threadIdx.x < PS && y < w.H && x < w.W;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const int dy = qdy[q], dx = qdx[q];
+      const int ny = ply + dy, nx = plx + dx;
+      const bool inside = ny >= 0 && ny < TH && nx >= 0 && nx < TW;  // my own tile
+      // other ranks' cells arrive as injected inflow
+      c2[q] = (live && !inside && dt_in_core(w, y + dy, x + dx)) ? (uint32_t)fdr[(long long)(y + dy) * w.ld + x + dx] : 0u;
+    }
+  }
+  dt_tile_put16(s_fdr, v_fdr);
   __syncthreads();
   uint32_t nx[CPT];
   if (dt_tile_interior(w, y0, x0)) {
@@ -235,10 +264,9 @@ __global__ __launch_bounds__(256, 6) void k_fa_tile1(const uint8_t *__restrict__
   }
   uint32_t my_code = 0, my_flags = 0;  // D8 code of my perimeter cell when it is an exit cell
   uint32_t feeders = 0;                // exits of neighbouring tiles (inside the core) that step onto my cell
-  uint32_t fnode[5];                   // their node ids (a perimeter cell has <= 5 neighbours outside the tile)
+  uint32_t fnode[8];                   // their node ids, by neighbour (a perimeter cell has <= 5 outside the tile)
   if (threadIdx.x < PS) {
-    int ly, lx;
-    dt_cell_of_slot(threadIdx.x, ly, lx);
+    const int ly = ply, lx = plx;
     uint32_t code = s_fdr[ly * TW + lx];
     uint32_t n = dt_tile_next(code, ly, lx, y0, x0, w);
     if (n == NX_EXIT || n == NX_REXIT) my_code = code;
@@ -249,25 +277,15 @@ __global__ __launch_bounds__(256, 6) void k_fa_tile1(const uint8_t *__restrict__
     // its own exits' pending feeders in LDS.
     const int y = y0 + ly, x = x0 + lx;
 #pragma unroll
-    for (int k = 0; k < 5; k++) fnode[k] = FA_NONE;
+    for (int q = 0; q < 8; q++) fnode[q] = FA_NONE;
     if (y < w.H && x < w.W) {
-      int k = 0;
+      // neighbour q drains into me iff its code points back at me
+      const uint8_t back[8] = {2, 4, 8, 1, 16, 128, 64, 32};
 #pragma unroll
-      for (int dy = -1; dy <= 1; dy++)
-#pragma unroll
-        for (int dx = -1; dx <= 1; dx++) {
-          int ny = ly + dy, nx = lx + dx;
-          if ((dy == 0 && dx == 0) || (ny >= 0 && ny < TH && nx >= 0 && nx < TW)) continue;  // inside my tile
-          if (!dt_in_core(w, y + dy, x + dx)) continue;  // other ranks' cells arrive as injected inflow
-          uint32_t c2 = fdr[(long long)(y + dy) * w.ld + x + dx];
-          if (dt_d8_valid(c2)) {
-            int ey, ex;
-            dt_d8_delta(c2, ey, ex);
-            if (ey == -dy && ex == -dx && k < 5) {
-              fnode[k++] = dt_node_of(y + dy, x + dx, tiles_x);
-              feeders++;
-            }
-          }
+      for (int q = 0; q < 8; q++)
+        if (c2[q] == (uint32_t)back[q]) {
+          fnode[q] = dt_node_of(y + qdy[q], x + qdx[q], tiles_x);
+          feeders++;
         }
     }
   }
@@ -300,7 +318,7 @@ __global__ __launch_bounds__(256, 6) void k_fa_tile1(const uint8_t *__restrict__
     if (xs != X_NONE && feeders) atomicAdd(&s_pend[xs], feeders);
     const uint32_t me = (uint32_t)tile * PS + threadIdx.x, par = xs != X_NONE ? (uint32_t)tile * PS + xs : FA_NONE;
 #pragma unroll
-    for (int k = 0; k < 5; k++)
+    for (int k = 0; k < 8; k++)
       if (fnode[k] != FA_NONE) {
         entry_of[fnode[k]] = me;
         parent[fnode[k]] = par;
@@ -395,40 +413,11 @@ __global__ __launch_bounds__(256, 6) void k_fa_tile3(const uint8_t *__restrict__
   const int tile = blockIdx.x;
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int y0 = ty * TH, x0 = tx * TW;
-  dt_tile_load_fdr(fdr, w, y0, x0, s_fdr);
+  // every global load of the kernel is issued here, before the first wait: the tile's codes, the resolved inflow
+  // of its entries, pass 1's counts and the heights
+  const uint4 v_fdr = dt_tile_fetch16(fdr, w, y0, x0);
   unsigned long long e = 0ull;
   if (threadIdx.x < PS) e = ext[(size_t)tile * PS + threadIdx.x];
-  // The accumulation raster is int32 (a device tile has < 2^31 cells), but across ranks a basin can reach 2^31
-  // cells.  No value of this tile can exceed the inflow entering it plus its own 4096 cells: a tile whose entries
-  // bring in >= 2^31 - 4096 in total raises the context's overflow status (dt_ctx_status) instead of wrapping
-  // silently.  Only such a tile pays for the 64-bit sum.
-  if (__syncthreads_or(!(e & FA_CYCLE) && FA_VALUE(e) >= (1ull << 22))) {
-    __shared__ unsigned long long s_in;
-    if (threadIdx.x == 0) s_in = 0ull;
-    __syncthreads();
-    if (e != 0ull && !(e & FA_CYCLE)) atomicAdd(&s_in, FA_VALUE(e));
-    __syncthreads();
-    if (threadIdx.x == 0 && s_in >= (1ull << 31) - (unsigned long long)NT && status) atomicOr(status, DT_STATUS_ACC_OVERFLOW);
-  }
-  uint32_t nx[CPT];
-  if (dt_tile_interior(w, y0, x0)) {
-#pragma unroll
-    for (int j = 0; j < CPT; j++) {
-      int c = threadIdx.x + 256 * j;
-      nx[j] = dt_tile_next_interior(s_fdr[c], c / TW, c % TW);
-    }
-  } else {
-    for (int j = 0; j < CPT; j++) {
-      int c = threadIdx.x + 256 * j;
-      nx[j] = dt_tile_next(s_fdr[c], c / TW, c % TW, y0, x0, w);
-    }
-  }
-  __syncthreads();
-  for (int j = 0; j < CPT; j++) {
-    int c = threadIdx.x + 256 * j;
-    s_nxt[c] = (uint16_t)nx[j];
-    s_delta[c] = 0u;
-  }
   // pass 1's counts and the heights are fetched now, so that their latency hides behind the serial walks.
   // Block-uniform fast form: whole 64-cell rows inside the core, 16-byte aligned rasters -> each lane owns 4
   // groups of 4 consecutive cells (8- and 16-byte loads, 16- and 4-byte stores)
@@ -459,6 +448,38 @@ __global__ __launch_bounds__(256, 6) void k_fa_tile3(const uint8_t *__restrict__
       av[j] = l16 == 0xFFFFu ? -100 : (int32_t)l16;
       zv[j] = (HAS_DEM && in) ? dem[o] : 0.0f;
     }
+  }
+  dt_tile_put16(s_fdr, v_fdr);
+  // The accumulation raster is int32 (a device tile has < 2^31 cells), but across ranks a basin can reach 2^31
+  // cells.  No value of this tile can exceed the inflow entering it plus its own 4096 cells: a tile whose entries
+  // bring in >= 2^31 - 4096 in total raises the context's overflow status (dt_ctx_status) instead of wrapping
+  // silently.  Only such a tile pays for the 64-bit sum.
+  if (__syncthreads_or(!(e & FA_CYCLE) && FA_VALUE(e) >= (1ull << 22))) {
+    __shared__ unsigned long long s_in;
+    if (threadIdx.x == 0) s_in = 0ull;
+    __syncthreads();
+    if (e != 0ull && !(e & FA_CYCLE)) atomicAdd(&s_in, FA_VALUE(e));
+    __syncthreads();
+    if (threadIdx.x == 0 && s_in >= (1ull << 31) - (unsigned long long)NT && status) atomicOr(status, DT_STATUS_ACC_OVERFLOW);
+  }
+  uint32_t nx[CPT];
+  if (dt_tile_interior(w, y0, x0)) {
+#pragma unroll
+    for (int j = 0; j < CPT; j++) {
+      int c = threadIdx.x + 256 * j;
+      nx[j] = dt_tile_next_interior(s_fdr[c], c / TW, c % TW);
+    }
+  } else {
+    for (int j = 0; j < CPT; j++) {
+      int c = threadIdx.x + 256 * j;
+      nx[j] = dt_tile_next(s_fdr[c], c / TW, c % TW, y0, x0, w);
+    }
+  }
+  __syncthreads();
+  for (int j = 0; j < CPT; j++) {
+    int c = threadIdx.x + 256 * j;
+    s_nxt[c] = (uint16_t)nx[j];
+    s_delta[c] = 0u;
   }
   __syncthreads();
   if (e != 0ull) {
@@ -952,18 +973,29 @@ __global__ __launch_bounds__(256, 6) void k_fh_tile1n(const uint8_t *__restrict_
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int y0 = ty * TH, x0 = tx * TW;
   FhTile T{s_fdr, s_halo, nullptr};
-  dt_tile_load_fdr(fdr, w, y0, x0, s_fdr);
-  for (int i = threadIdx.x; i < 2 * (TW + 2) + 2 * TH; i += 256) {
-    int y, x;
-    if (i < TW + 2) { y = y0 - 1; x = x0 - 1 + i; }
-    else if (i < 2 * (TW + 2)) { y = y0 + TH; x = x0 - 1 + (i - (TW + 2)); }
-    else if (i < 2 * (TW + 2) + TH) { y = y0 + (i - 2 * (TW + 2)); x = x0 - 1; }
-    else { y = y0 + (i - 2 * (TW + 2) - TH); x = x0 + TW; }
-    uint8_t v = 0;
-    if (dt_readable(w, y, x)) v = fdr[(long long)y * w.ld + x];
-    s_halo[i] = v;
+  // the tile's codes, its river mask and the halo ring: all loads issued before the first is waited for
+  const uint4 v_fdr = dt_tile_fetch16(fdr, w, y0, x0);
+  const uint4 v_riv = dt_tile_fetch16(reinterpret_cast<const uint8_t *>(river), w, y0, x0);
+  uint8_t hv[2] = {0, 0};
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+    const int i = threadIdx.x + 256 * u;
+    if (i < 2 * (TW + 2) + 2 * TH) {
+      int y, x;
+      if (i < TW + 2) { y = y0 - 1; x = x0 - 1 + i; }
+      else if (i < 2 * (TW + 2)) { y = y0 + TH; x = x0 - 1 + (i - (TW + 2)); }
+      else if (i < 2 * (TW + 2) + TH) { y = y0 + (i - 2 * (TW + 2)); x = x0 - 1; }
+      else { y = y0 + (i - 2 * (TW + 2) - TH); x = x0 + TW; }
+      if (dt_readable(w, y, x)) hv[u] = fdr[(long long)y * w.ld + x];
+    }
   }
-  dt_tile_load_fdr(reinterpret_cast<const uint8_t *>(river), w, y0, x0, s_kind);
+  dt_tile_put16(s_fdr, v_fdr);
+  dt_tile_put16(s_kind, v_riv);
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+    const int i = threadIdx.x + 256 * u;
+    if (i < 2 * (TW + 2) + 2 * TH) s_halo[i] = hv[u];
+  }
   if (threadIdx.x == 0) s_ovf = 0;
   __syncthreads();
   uint32_t riv = 0;
