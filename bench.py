@@ -111,7 +111,7 @@ def main():
     S = args.size
     H = W = S
     # a torch-owned NON-default stream: the library launches on it and torch events see it
-    stream = torch.cuda.Stream(device=dev)
+    stream = torch.cuda.Stream(device=dev, priority=-1 if args.overlap else 0)  # --overlap: the main branch first
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
     ctx = Context(device=local_rank, stream=stream.cuda_stream)
