@@ -252,6 +252,12 @@ def verify_step(torch, L, _lib, ctx, dem, rasters, ch, H, W):
     fac2, fd2, idx2, hand2 = i32(), f32(), i32(), f32()
     _lib.check(L.dt_set_flow_impl(1))
     try:
+        # downslope by the one-thread-per-cell walk on global memory (fd2 as the temporary)
+        _lib.check(L.dt_dev_downslope(c, dem.data_ptr(), rasters["fdr"].data_ptr(), H, W, ch.px, ch.dz, 0,
+                                      fd2.data_ptr()))
+        ctx.sync()
+        if not torch.equal(rasters["down"].view(torch.int32), fd2.view(torch.int32)):
+            raise SystemExit("bench.py: timed step's downslope differs from the global walk")
         _lib.check(L.dt_dev_flowacc(c, rasters["fdr"].data_ptr(), dem.data_ptr(), H, W, fac2.data_ptr()))
         _lib.check(L.dt_dev_flowhand(c, dem.data_ptr(), rasters["fdr"].data_ptr(), rasters["river"].data_ptr(), None,
                                      H, W, ch.px, fd2.data_ptr(), idx2.data_ptr(), hand2.data_ptr(), None))
@@ -261,7 +267,7 @@ def verify_step(torch, L, _lib, ctx, dem, rasters, ch, H, W):
     for name, other in (("fac", fac2), ("fdist", fd2), ("idx", idx2), ("hand", hand2)):
         if not torch.equal(rasters[name], other):
             raise SystemExit("bench.py: timed step's %s differs from the global-kernel computation" % name)
-    res["fac_idx_fdist_hand_vs_global_kernels"] = "equal"
+    res["fac_idx_fdist_hand_downslope_vs_global_kernels"] = "equal"
     if not torch.equal(rasters["river"], (rasters["fac"] > ch.river_threshold).to(torch.int8)):
         raise SystemExit("bench.py: river mask != fac > threshold")
     # unfused slope / radians / TI / MTI and GFI / ln(hl/H)
@@ -348,7 +354,8 @@ def main_tiled(args, torch, dist, world, rank, local_rank, dev):
         tiling.run_rank(tile, layout, exchange, overlap=args.overlap)
     barrier()
     dt = time.perf_counter() - t0
-    unres = torch.tensor([tile.unresolved_downslope()], dtype=torch.int64, device="cpu" if cpu_red else dev)
+    unres = torch.tensor([tile.unresolved_downslope(), tile.ctx.status() & 1], dtype=torch.int64,
+                         device="cpu" if cpu_red else dev)
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if cpu_red else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -373,7 +380,8 @@ def main_tiled(args, torch, dist, world, rank, local_rank, dev):
                      "frac": round(cells * args.steps * chain.ALGO_BYTES_PER_CELL / dt / 1e9 / world
                                    / HBM_PEAK_GBS, 4),
                      "traffic": None, "kernel": "whole chain, per GPU (per-kernel figures: N = 1 run)"},
-        "downslope_walks_beyond_halo": int(unres.item()),
+        "downslope_walks_beyond_halo": int(unres[0].item()),
+        "accumulation_overflow_ranks": int(unres[1].item()),  # ranks whose int32 accumulation may have reached 2^31
         "backend": (dist.get_backend() if use_dist else "none"),
         "distinct_gpus": min(world, torch.cuda.device_count()) if not cpu_red else 1,
     }

@@ -450,7 +450,11 @@ extern "C" int dt_dev_downslope(dt_ctx *c, const float *dem, const uint8_t *fdr,
   DT_CTX(c);
   DT_TRY(dt_check_hw(H, W));
   DT_REQUIRE((dem && fdr && out) || H * W == 0, "NULL raster");
-  DT_TRY(dt_launch_downslope(c->stream, dt_full_window(H, W), dem, fdr, px, dz, raw, out, nullptr));
+  if (dt_flow_impl() == 1) {  // v1: one thread per cell walking global memory (kept for A/B and verification runs)
+    DT_TRY(dt_launch_downslope_v1(c->stream, dem, fdr, H, W, px, dz, raw, out));
+  } else {
+    DT_TRY(dt_launch_downslope(c->stream, dt_full_window(H, W), dem, fdr, px, dz, raw, out, nullptr));
+  }
   DT_HIP(hipGetLastError());
   return DT_OK;
 }

@@ -738,20 +738,32 @@ __global__ __launch_bounds__(1024, 8) void k_downslope_win(const float *__restri
         if (++loop == 5000u) { failed = true; break; }  // downslope.py:303-304
       }
     }
-    double dist = 0.0;
-    if (!slow && !unresolved) {
-      // count form of the path length, accepted only if every value within the rounding error of the
-      // sequential sum (<= (n + 8) * 2^-53 relative, n = moves) gives the same float32 quotient
-      dist = dcard * (double)(loop - nd) + ddiag * (double)nd;
-      if (loop != 0u) {
-        const double q = (double)drop / dist, dl = (double)(loop + 8u) * 1.1102230246251565e-16;
-        const float r = (float)q;
-        if ((float)(q * (1.0 - dl)) != r || (float)(q * (1.0 + dl)) != r) slow = true;
-      }
+    float res = 0.0f;  // no move: distance 0 -> 0 (downslope.py:306-309)
+    if (!slow && !unresolved && loop != 0u) {
+      // Count form of the path length, px*nc + px*sqrt(2)*nd, within (n + 8) * 2^-53 (n = moves) of the
+      // reference's sequential float64 sum; the quotient by reciprocal + two Newton steps, within 2^-50 of the
+      // reference's division.  The float32 result is accepted only if every value that close rounds to the same
+      // float32: q's low 29 mantissa bits stay more than n + 24 float64 ulps away from the float32 rounding
+      // midpoint 2^28 (and q is a normal float32, dist far from the ends of the double range).  One IEEE
+      // float64 division, two products and three conversions per cell gave way to 4 FMAs and integer tests:
+      // this kernel is bound by VALU issue and float64 runs at half rate.
+      const double dist = dcard * (double)(loop - nd) + ddiag * (double)nd;
+      double rc = __builtin_amdgcn_rcp(dist);
+      rc = fma(fma(-dist, rc, 1.0), rc, rc);
+      rc = fma(fma(-dist, rc, 1.0), rc, rc);
+      const double q = (double)drop * rc;
+      res = (float)q;
+      const uint64_t qb = (uint64_t)__double_as_longlong(q);
+      const uint32_t qlo = (uint32_t)qb, qe = (uint32_t)(qb >> 52) & 0x7FFu;
+      const uint32_t de = (uint32_t)((uint64_t)__double_as_longlong(dist) >> 52) & 0x7FFu;
+      const uint32_t m = loop + 24u;
+      const bool near_mid = ((qlo & 0x1FFFFFFFu) - (0x10000000u - m)) <= 2u * m;
+      // 2^-126 <= |q| < 2^128 (biased exponent 897..1150); 2^-500 <= |dist| < 2^501
+      if (near_mid || (qe - 897u) > 253u || (de - 523u) > 1000u) slow = true;
     }
     if (slow) {  // the reference's own walk with its sequential float64 sum, from the start, on global memory
       int y = y0, x = x0;
-      dist = 0.0;
+      double dist = 0.0;
       drop = 0.0f;
       failed = false;
       unresolved = false;
@@ -773,12 +785,13 @@ __global__ __launch_bounds__(1024, 8) void k_downslope_win(const float *__restri
         drop = z0 - zt;
         if (++moves == 5000u) { failed = true; break; }
       }
+      res = dist == 0.0 ? 0.0f : (float)((double)drop / dist);
     }
     if (unresolved) {  // the walk left the memory of this rank: a wider halo is needed
       out[o] = -50.0f;
       if (n_unresolved) atomicAdd(n_unresolved, 1);
     } else if (raw && failed) out[o] = -50.0f;
-    else out[o] = dist == 0.0 ? 0.0f : (float)((double)drop / dist);
+    else out[o] = res;
   }
 }
 

@@ -37,7 +37,7 @@ def test_bench_line_contract():
     assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "Mcells/s" and c["value"] > 0 and c["sample"]
     assert c["all_cores"]["cores"] >= 1 and c["all_cores"]["value"] > 0 and "-O3 -march=native" in c["sample"]
     v = d["verified"]  # the timed step's rasters were cross-checked after the timed loop
-    assert v["fac_idx_fdist_hand_vs_global_kernels"] == "equal" and v["cells_drained_through_outlets"] == 2048 * 2048
+    assert v["fac_idx_fdist_hand_downslope_vs_global_kernels"] == "equal" and v["cells_drained_through_outlets"] == 2048 * 2048
     assert set(v["checksums"]) >= {"fdr", "fac", "river", "fdist", "idx", "hand", "slope", "ti", "mti", "gfi", "lnhlh", "down"}
     assert sum(v["ms"] for v in d["per_op"].values()) <= 1.2 * d["ms_per_step"] + 0.5
 
