@@ -965,37 +965,20 @@ __global__ __launch_bounds__(256, 6) void k_fh_tile1n(const uint8_t *__restrict_
                                                      unsigned long long *__restrict__ cache,
                                                      uint8_t *__restrict__ cache_wide) {
   __shared__ __attribute__((aligned(16))) uint8_t s_fdr[NT];
-  __shared__ uint8_t s_halo[2 * (TW + 2) + 2 * TH];
   __shared__ __attribute__((aligned(16))) uint32_t s_w[NT];
   __shared__ __attribute__((aligned(16))) uint8_t s_kind[NT];  // first the river mask, then the end kinds
   __shared__ int s_ovf;
   const int tile = blockIdx.x;
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int y0 = ty * TH, x0 = tx * TW;
-  FhTile T{s_fdr, s_halo, nullptr};
-  // the tile's codes, its river mask and the halo ring: all loads issued before the first is waited for
+  // the tile's codes and its river mask: both loads issued before the first is waited for.  (No halo ring of
+  // codes: "the successor's code is 0" need not be tested at the predecessor -- a cell whose code is 0 is a dead
+  // end in its own right (flowhand.py:601, :826), inside the tile through s_kind of the path's end, across a
+  // tile or rank border through that cell's perimeter node / ring summary.)
   const uint4 v_fdr = dt_tile_fetch16(fdr, w, y0, x0);
   const uint4 v_riv = dt_tile_fetch16(reinterpret_cast<const uint8_t *>(river), w, y0, x0);
-  uint8_t hv[2] = {0, 0};
-#pragma unroll
-  for (int u = 0; u < 2; u++) {
-    const int i = threadIdx.x + 256 * u;
-    if (i < 2 * (TW + 2) + 2 * TH) {
-      int y, x;
-      if (i < TW + 2) { y = y0 - 1; x = x0 - 1 + i; }
-      else if (i < 2 * (TW + 2)) { y = y0 + TH; x = x0 - 1 + (i - (TW + 2)); }
-      else if (i < 2 * (TW + 2) + TH) { y = y0 + (i - 2 * (TW + 2)); x = x0 - 1; }
-      else { y = y0 + (i - 2 * (TW + 2) - TH); x = x0 + TW; }
-      if (dt_readable(w, y, x)) hv[u] = fdr[(long long)y * w.ld + x];
-    }
-  }
   dt_tile_put16(s_fdr, v_fdr);
   dt_tile_put16(s_kind, v_riv);
-#pragma unroll
-  for (int u = 0; u < 2; u++) {
-    const int i = threadIdx.x + 256 * u;
-    if (i < 2 * (TW + 2) + 2 * TH) s_halo[i] = hv[u];
-  }
   if (threadIdx.x == 0) s_ovf = 0;
   __syncthreads();
   uint32_t riv = 0;
@@ -1018,8 +1001,8 @@ __global__ __launch_bounds__(256, 6) void k_fh_tile1n(const uint8_t *__restrict_
         dt_d8_delta(code, dy, dx);
         uint32_t ny = (uint32_t)(ly + dy), nx = (uint32_t)(lx + dx);
         bool in_tile = ny < (uint32_t)TH && nx < (uint32_t)TW;
-        // raster exit / arrival on fdr == 0 (flowhand.py:623-628, :826) stay dead
-        if ((interior || dt_in_global(w, y + dy, x + dx)) && fht_fdr_at(T, ly + dy, lx + dx) != 0u) {
+        // a step off the raster stays dead (flowhand.py:623-628)
+        if (interior || dt_in_global(w, y + dy, x + dx)) {
           if (!interior && !dt_in_core(w, y + dy, x + dx)) kind = K_REXIT;
           else if (!in_tile) kind = K_EXIT;  // the step itself is added by the user
           else word = ((ny * TW + nx) << FN_PTR_SH) | ((dy != 0 && dx != 0) ? (1u << 9) : 1u);
