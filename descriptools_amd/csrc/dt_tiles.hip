@@ -133,59 +133,63 @@ __device__ __forceinline__ uint32_t dt_tile_next_interior(uint32_t code, int ly,
 #define PT_EXIT 0x4000u
 #define PT_IDX 0x0FFFu
 
-// One LDS word per cell: val:16 (<= 4096 in pass 1) | ptr bits:16, so a round is 5-6 LDS instructions
-// per cell (own word, scatter atomic, gather, received sum, write back) instead of 8.
-// Each lane owns PAIRS of adjacent cells (2 * (t + 256 j), +1) so that its own words and received sums
-// move with 64-bit LDS instructions; only the scatter atomic and the gather are per cell.
-__device__ __forceinline__ void dt_tile_sums(uint32_t *s_pv, uint32_t *s_recv, uint8_t *s_cyc) {
-  uint2 pv[CPT / 2], np[CPT / 2];
-  uint2 *s_pv2 = reinterpret_cast<uint2 *>(s_pv);
-  // s_recv: two 16-bit sums per word (cells 2i, 2i + 1).  What a cell receives in one round are the sums of
-  // disjoint subtrees (<= 4096 cells in total) plus, on an in-tile D8 cycle, the one cycle cell 2^k moves
-  // behind it, whose sum is garbage and may be huge: a cell whose sum exceeds the tile size is on such a
-  // cycle and no longer scatters, so a half never carries into its neighbour (<= 8192 per round)
-  // a lane's own words change only by its own hand: they live in registers, LDS gets the copies others gather
+// LDS holds what OTHER lanes need: a cell's pointer word (16 bits: idx:12 | PT_EXIT | PT_ALIVE; gathered by the
+// cells that jump over it) and a 32-bit receive word (scatter target).  A cell's running sum is read and written
+// by its owner only and lives in a register.  Each lane owns PAIRS of adjacent cells (2 * (t + 256 j), +1): its
+// two pointer words move as one 32-bit LDS word, its two receive words as one 64-bit exchange.  Per cell and
+// round: one LDS atomic add, one 16-bit gather and ~5 VALU instructions (the previous form, val:16 | ptr:16 in
+// one word with two 16-bit receive sums per word, spent 18 for the same time: the rounds are bound by the LDS
+// atomics and their bank conflicts, not by instruction issue).
+// On an in-tile D8 cycle the sums are garbage and double every round: they wrap in 32 bits, harmlessly (such
+// cells end up in s_cyc).
+__device__ __forceinline__ void dt_tile_sums(uint16_t *s_ptr, uint32_t *s_recv, uint8_t *s_cyc,
+                                             uint32_t (&va)[CPT / 2], uint32_t (&vb)[CPT / 2]) {
+  uint32_t P[CPT / 2], NP[CPT / 2];
+  uint32_t *s_ptr2 = reinterpret_cast<uint32_t *>(s_ptr);
+  unsigned long long *s_recv2 = reinterpret_cast<unsigned long long *>(s_recv);
 #pragma unroll
-  for (int j = 0; j < CPT / 2; j++) pv[j] = s_pv2[threadIdx.x + 256 * j];
+  for (int j = 0; j < CPT / 2; j++) {
+    P[j] = s_ptr2[threadIdx.x + 256 * j];
+    va[j] = vb[j] = 1u;
+  }
   for (int round = 0; round < 12; round++) {
     int any = 0;
 #pragma unroll
     for (int j = 0; j < CPT / 2; j++) {
-      np[j].x = pv[j].x & 0xFFFFu;
-      np[j].y = pv[j].y & 0xFFFFu;
-      if (pv[j].x & PT_ALIVE) {
-        uint32_t t = pv[j].x & PT_IDX;
-        if ((pv[j].x >> 16) <= (uint32_t)NT) atomicAdd(&s_recv[t >> 1], (pv[j].x >> 16) << ((t & 1u) * 16u));
-        np[j].x = s_pv[t] & 0xFFFFu;
+      uint32_t npa = P[j] & 0xFFFFu, npb = P[j] >> 16;
+      if (P[j] & PT_ALIVE) {
+        uint32_t t = P[j] & PT_IDX;
+        atomicAdd(&s_recv[t], va[j]);
+        npa = s_ptr[t];
         any = 1;
       }
-      if (pv[j].y & PT_ALIVE) {
-        uint32_t t = pv[j].y & PT_IDX;
-        if ((pv[j].y >> 16) <= (uint32_t)NT) atomicAdd(&s_recv[t >> 1], (pv[j].y >> 16) << ((t & 1u) * 16u));
-        np[j].y = s_pv[t] & 0xFFFFu;
+      if (P[j] & (PT_ALIVE << 16)) {
+        uint32_t t = (P[j] >> 16) & PT_IDX;
+        atomicAdd(&s_recv[t], vb[j]);
+        npb = s_ptr[t];
         any = 1;
       }
+      NP[j] = npa | (npb << 16);
     }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < CPT / 2; j++) {
       int c2 = threadIdx.x + 256 * j;
-      uint32_t r = atomicExch(&s_recv[c2], 0u);  // read and clear in one LDS instruction
-      // a finished pair that received nothing keeps its words
-      if (r || ((pv[j].x | pv[j].y) & PT_ALIVE)) {
-        pv[j] = make_uint2((((pv[j].x >> 16) + (r & 0xFFFFu)) << 16) | np[j].x,
-                           (((pv[j].y >> 16) + (r >> 16)) << 16) | np[j].y);
-        s_pv2[c2] = pv[j];
+      unsigned long long r = atomicExch(&s_recv2[c2], 0ull);  // read and clear in one LDS instruction
+      va[j] += (uint32_t)r;
+      vb[j] += (uint32_t)(r >> 32);
+      if (P[j] != NP[j]) {
+        P[j] = NP[j];
+        s_ptr2[c2] = NP[j];
       }
     }
     if (!__syncthreads_or(any)) return;
   }
   // still alive after 2^12 moves: the path never ends inside the tile -> in-tile cycle
 #pragma unroll
-  for (int j = 0; j < CPT; j++) {
-    int c = threadIdx.x + 256 * j;
-    uint32_t p = s_pv[c];
-    if (p & PT_ALIVE) s_cyc[p & PT_IDX] = 1;
+  for (int j = 0; j < CPT / 2; j++) {
+    if (P[j] & PT_ALIVE) s_cyc[P[j] & PT_IDX] = 1;
+    if (P[j] & (PT_ALIVE << 16)) s_cyc[(P[j] >> 16) & PT_IDX] = 1;
   }
   __syncthreads();
 }
@@ -220,9 +224,10 @@ __global__ __launch_bounds__(256, 6) void k_fa_tile1(const uint8_t *__restrict__
                                                     uint32_t *__restrict__ entry_of,
                                                     uint32_t *__restrict__ parent) {
   // 24 KiB of LDS: six tiles per CU.  The direction codes are staged through the receive array (free until
-  // the rounds start), which is all zero again when the rounds end and then serves as the cycle mask.
-  __shared__ __attribute__((aligned(16))) uint32_t s_pv[NT];  // val:16 | idx:12 | PT_EXIT | PT_ALIVE
-  __shared__ __attribute__((aligned(16))) uint32_t s_recv[NT / 2];  // 16-bit sums, two cells per word
+  // the rounds start), which is all zero again when the rounds end and then serves as the cycle mask (bytes
+  // [0, 4 KiB)), the pending counts (252 words from 4 KiB) and the final sums (16 bits per cell from 8 KiB).
+  __shared__ __attribute__((aligned(16))) uint16_t s_ptr[NT];   // idx:12 | PT_EXIT | PT_ALIVE
+  __shared__ __attribute__((aligned(16))) uint32_t s_recv[NT];  // what a cell receives in a round
   uint8_t *s_fdr = reinterpret_cast<uint8_t *>(s_recv);
   const int tile = blockIdx.x;
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
@@ -298,22 +303,29 @@ __global__ __launch_bounds__(256, 6) void k_fa_tile1(const uint8_t *__restrict__
     // terminals point at themselves; an exit terminal carries PT_EXIT, which every cell whose
     // in-tile path ends there inherits through the jumps
     bool ex = (n == NX_EXIT || n == NX_REXIT);
-    s_pv[c] = (1u << 16) | (n < NT ? (n | PT_ALIVE) : ((uint32_t)c | (ex ? PT_EXIT : 0u)));
-    if (j < CPT / 2) s_recv[c] = 0u;
+    s_ptr[c] = (uint16_t)(n < NT ? (n | PT_ALIVE) : ((uint32_t)c | (ex ? PT_EXIT : 0u)));
+    s_recv[c] = 0u;
   }
   __syncthreads();
-  dt_tile_sums(s_pv, s_recv, s_cyc);
+  uint32_t va[CPT / 2], vb[CPT / 2];  // running sums of my cells 2 (t + 256 j) and + 1
+  dt_tile_sums(s_ptr, s_recv, s_cyc, va, vb);
+  // the final sums where the perimeter lanes can read them (<= 4096 off cycles: 16 bits)
+  uint32_t *s_val2 = s_recv + NT / 2;
+  const uint16_t *s_val = reinterpret_cast<const uint16_t *>(s_val2);
+#pragma unroll
+  for (int j = 0; j < CPT / 2; j++) s_val2[threadIdx.x + 256 * j] = (va[j] & 0xFFFFu) | (vb[j] << 16);
+  __syncthreads();
   if (threadIdx.x < PS) {
     int ly, lx;
     dt_cell_of_slot(threadIdx.x, ly, lx);
     int c = ly * TW + lx;
-    uint32_t p = s_pv[c];
+    uint32_t p = s_ptr[c];
     uint32_t xs = X_NONE;
     if (!(p & PT_ALIVE) && (p & PT_EXIT)) {
       uint32_t f = p & PT_IDX;
       xs = (uint32_t)dt_slot_of((int)f / TW, (int)f % TW);
     }
-    rec[(size_t)tile * PS + threadIdx.x] = fa_rec(my_code ? (p >> 16) : 0u, xs, my_code, my_flags);
+    rec[(size_t)tile * PS + threadIdx.x] = fa_rec(my_code ? (uint32_t)s_val[c] : 0u, xs, my_code, my_flags);
     // what enters at my cell waits at the exit its in-tile path leads to
     if (xs != X_NONE && feeders) atomicAdd(&s_pend[xs], feeders);
     const uint32_t me = (uint32_t)tile * PS + threadIdx.x, par = xs != X_NONE ? (uint32_t)tile * PS + xs : FA_NONE;
@@ -335,17 +347,14 @@ __global__ __launch_bounds__(256, 6) void k_fa_tile1(const uint8_t *__restrict__
   }
   // in-tile accumulation (upstream cells of this tile only, <= 4095: 2 bytes per cell, tile-major; 0xFFFF =
   // on an in-tile cycle); pass 3 adds what enters from outside
-  // (4 cells per lane: one 16-byte LDS read, one 4-byte mask read, one 8-byte store)
+  // (a lane's pairs, straight from its registers: one 2-byte mask read and one 4-byte store per pair)
 #pragma unroll
-  for (int u = 0; u < NT / 4 / 256; u++) {
-    int c = 4 * (threadIdx.x + 256 * u);
-    uint4 pv = *reinterpret_cast<const uint4 *>(&s_pv[c]);
-    uint32_t cy = *reinterpret_cast<const uint32_t *>(&s_cyc[c]);
-    uint32_t a = (cy & 0xFFu) ? 0xFFFFu : ((pv.x >> 16) - 1u) & 0xFFFFu;
-    uint32_t b = (cy & 0xFF00u) ? 0xFFFFu : ((pv.y >> 16) - 1u) & 0xFFFFu;
-    uint32_t d = (cy & 0xFF0000u) ? 0xFFFFu : ((pv.z >> 16) - 1u) & 0xFFFFu;
-    uint32_t e = (cy & 0xFF000000u) ? 0xFFFFu : ((pv.w >> 16) - 1u) & 0xFFFFu;
-    *reinterpret_cast<uint2 *>(loc16 + (size_t)tile * NT + c) = make_uint2(a | (b << 16), d | (e << 16));
+  for (int j = 0; j < CPT / 2; j++) {
+    int c2 = threadIdx.x + 256 * j;
+    uint32_t cy = *reinterpret_cast<const uint16_t *>(&s_cyc[2 * c2]);
+    uint32_t a = (cy & 0xFFu) ? 0xFFFFu : (va[j] - 1u) & 0xFFFFu;
+    uint32_t b = (cy & 0xFF00u) ? 0xFFFFu : (vb[j] - 1u) & 0xFFFFu;
+    *reinterpret_cast<uint32_t *>(loc16 + (size_t)tile * NT + 2 * c2) = a | (b << 16);
   }
 }
 
