@@ -21,14 +21,20 @@ cp $OUT/pmc_traffic.json profiles/$ROUND/pmc_traffic.json
 echo "pmc done"
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/sq_a -- $B > $OUT/sq_a.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS --output-format csv -d $OUT/sq_b -- $B > $OUT/sq_b.log 2>&1 || exit 1
-python3 tools/sq_summary.py $OUT/sq_a $OUT/sq_b > $OUT/sq_counters.txt || exit 1
 echo "sq done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify > $OUT/trace.log 2>&1 || exit 1
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/bench16384_kernel_stats.csv
+python3 tools/sq_summary.py $OUT/sq_a $OUT/sq_b $OUT/bench16384_kernel_stats.csv > $OUT/sq_counters.txt || exit 1
 echo "trace done"
 python3 bench.py --steps 20 --warmup 5 > $OUT/bench16384.json 2> $OUT/bench16384.err || exit 1
 echo "bench done"
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-verify --overlap > $OUT/bench16384_overlap.json 2>/dev/null || exit 1
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --tiled > $OUT/bench16384_tiled.json 2>/dev/null || exit 1
 rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/sq_a $OUT/sq_b $OUT/trace
+# calibration of the instruction-issue model used in DESIGN.md 6 (cycles per wave64 VALU instruction, latency of a
+# dependent atomic) and the device's clocks
+for m in valu_rate atomic_chain; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w tools/micro/$m.hip -o /tmp/$m && timeout -k 5 60 /tmp/$m > $OUT/micro_$m.txt 2>&1
+done
+rocm-smi --showclocks --showpower > $OUT/rocm_smi.txt 2>&1 || true
 ls -la $OUT
