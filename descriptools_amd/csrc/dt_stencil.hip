@@ -607,6 +607,9 @@ __global__ __launch_bounds__(256, 8) void k_d8(const float *__restrict__ dem, Dt
     dst[5] = sd_from_next_lane(rh, m.x);
   };
   const bool full = vec_ok && gx + 3 < W;
+  // block-uniform: does the tile touch the border of the GLOBAL raster?  (only there does the border rule apply;
+  // the kernel is limited by VALU issue and the rule is a sixth of a cell's instructions)
+  const bool on_border = w.gy0 + y0 == 0 || w.gx0 + x0 == 0 || w.gy0 + y0 + SD_TY >= w.Hg || w.gx0 + x0 + SD_TX >= w.Wg;
   float a[6], bb[6], cc[6];
   load_row(ry, a);
   load_row(ry + 1, bb);
@@ -622,10 +625,12 @@ __global__ __launch_bounds__(256, 8) void k_d8(const float *__restrict__ dem, Dt
       const bool nod = !(c < pinf) || c <= DT_NODATA;  // staged nodata (+inf), NaN, or below the sentinel: code 0
       uint32_t code;
       bool flag = sd_d8_fast(c, a[k], a[k + 1], a[k + 2], bb[k], bb[k + 2], cc[k], cc[k + 1], cc[k + 2], code);
-      // N1 border rule: a border cell with no lower neighbour drains out of the raster
-      const int gyy = w.gy0 + gy, gxx = w.gx0 + gx + k;
-      const uint32_t out = gyy == w.Hg - 1 ? 4u : (gyy == 0 ? 64u : (gxx == 0 ? 16u : (gxx == w.Wg - 1 ? 1u : 0u)));
-      code = code == 0u ? out : code;
+      if (on_border) {
+        // N1 border rule: a border cell with no lower neighbour drains out of the raster
+        const int gyy = w.gy0 + gy, gxx = w.gx0 + gx + k;
+        const uint32_t out = gyy == w.Hg - 1 ? 4u : (gyy == 0 ? 64u : (gxx == 0 ? 16u : (gxx == w.Wg - 1 ? 1u : 0u)));
+        code = code == 0u ? out : code;
+      }
       codes |= (nod ? 0u : code) << (8 * k);
       mask |= ((flag && !nod) ? 1u : 0u) << (4 * j + k);
     }
