@@ -47,8 +47,10 @@ typedef struct dt_window {
 const char *dt_last_error(void);
 int dt_device_count(void);
 const char *dt_version(void);
-/* A/B knob: 1 = first-generation global kernels for flow accumulation / HAND, 2 = tile-hierarchical
- * (default; also selectable with the environment variable DT_FLOW_IMPL=v1).  Same results. */
+/* A/B knob: 1 = first-generation global kernels for flow accumulation / HAND / downslope (raster-wide
+ * countdown, raster-wide pointer doubling, one thread per cell walking global memory), 2 = tile-hierarchical /
+ * windowed (default; also selectable with the environment variable DT_FLOW_IMPL=v1).  Same results: bench.py
+ * cross-checks the timed step against impl 1. */
 int dt_set_flow_impl(int impl);
 /* Test knobs, all 0 by default.  key 0 (DT_DBG_TWI_FLAG_ALL): the fused slope + TI + MTI stencil sends every
  * cell through its exact (cold) path as well as the fast one; key 1 (DT_DBG_TWI_PLAIN): default cache policy
