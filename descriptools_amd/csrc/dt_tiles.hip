@@ -413,11 +413,16 @@ __global__ __launch_bounds__(256, 6) void k_fa_tile3(const uint8_t *__restrict__
                                                     const uint16_t *__restrict__ loc16,
                                                     int32_t *__restrict__ acc32, int32_t river_thr,
                                                     int8_t *__restrict__ river, int *__restrict__ status) {
-  // 24 KiB of LDS: six tiles per CU (the kernel is a latency chain of LDS walks).  The direction codes are
+  // 25.5 KiB of LDS: six tiles per CU (the kernel is a latency chain of LDS walks).  The direction codes are
   // staged through the delta array; bit 31 of a delta (real inflow < 2^31) marks the cells of a cycle
-  // spanning tiles.
-  __shared__ uint16_t s_nxt[NT];
-  __shared__ __attribute__((aligned(16))) uint32_t s_delta[NT];
+  // spanning tiles.  Both arrays are indexed with rows 68 cells apart (P3 below): with 64, a step north or south
+  // keeps the LDS bank, so the entry walks that trail one another down a north-south stem -- the common case on
+  // tilted terrain -- serialised on one bank (76 % of the kernel's LDS cycles were bank conflicts).  The padded
+  // index of the successor is what s_nxt holds, so a step is still one read; rows stay 16-byte aligned.
+#define P3(c) ((uint32_t)(c) + (((uint32_t)(c) >> 6) << 2))
+#define NT3 (TH * (TW + 4))
+  __shared__ uint16_t s_nxt[NT3];
+  __shared__ __attribute__((aligned(16))) uint32_t s_delta[NT3];
   uint8_t *s_fdr = reinterpret_cast<uint8_t *>(s_delta);
   const int tile = blockIdx.x;
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
@@ -487,23 +492,23 @@ __global__ __launch_bounds__(256, 6) void k_fa_tile3(const uint8_t *__restrict__
   __syncthreads();
   for (int j = 0; j < CPT; j++) {
     int c = threadIdx.x + 256 * j;
-    s_nxt[c] = (uint16_t)nx[j];
-    s_delta[c] = 0u;
+    s_nxt[P3(c)] = (uint16_t)(nx[j] < NT ? P3(nx[j]) : nx[j]);  // NX_* sentinels stay (>= 0xFFFD > NT3)
+    s_delta[P3(c)] = 0u;
   }
   __syncthreads();
   if (e != 0ull) {
     int ly, lx;
     dt_cell_of_slot(threadIdx.x, ly, lx);
-    uint32_t c = (uint32_t)(ly * TW + lx);
+    uint32_t c = P3(ly * TW + lx);
     // fed by a D8 cycle spanning tiles: the path IS the cycle; else the real inflow (< 2^31)
     const uint32_t add = (e & FA_CYCLE) ? 0x80000000u : (uint32_t)e;
     if (e & FA_CYCLE) {
-      for (int it = 0; it < NT && c < NT; it++) {
+      for (int it = 0; it < NT && c < NT3; it++) {
         atomicOr(&s_delta[c], add);
         c = s_nxt[c];
       }
     } else {
-      for (int it = 0; it < NT && c < NT; it++) {
+      for (int it = 0; it < NT && c < NT3; it++) {
         atomicAdd(&s_delta[c], add);
         c = s_nxt[c];
       }
@@ -524,7 +529,7 @@ __global__ __launch_bounds__(256, 6) void k_fa_tile3(const uint8_t *__restrict__
       int y = y0 + c / TW;
       if (y >= w.H) continue;
       long long o = (long long)y * w.ld + x0 + c % TW;
-      uint4 d = *reinterpret_cast<const uint4 *>(&s_delta[c]);
+      uint4 d = *reinterpret_cast<const uint4 *>(&s_delta[P3(c)]);
       int4 v = make_int4(finish(l4[u].x & 0xFFFFu, d.x, z4[u].x), finish(l4[u].x >> 16, d.y, z4[u].y),
                          finish(l4[u].y & 0xFFFFu, d.z, z4[u].z), finish(l4[u].y >> 16, d.w, z4[u].w));
       *reinterpret_cast<int4 *>(acc32 + o) = v;
@@ -542,11 +547,13 @@ __global__ __launch_bounds__(256, 6) void k_fa_tile3(const uint8_t *__restrict__
     int y = y0 + c / TW, x = x0 + c % TW;
     if (y >= w.H || x >= w.W) continue;
     long long o = (long long)y * w.ld + x;
-    int32_t v = finish(av[j] == -100 ? 0xFFFFu : (uint32_t)av[j], s_delta[c], zv[j]);
+    int32_t v = finish(av[j] == -100 ? 0xFFFFu : (uint32_t)av[j], s_delta[P3(c)], zv[j]);
     acc32[o] = v;
     if (W_RIVER) river[o] = v > river_thr ? 1 : 0;
   }
 }
+#undef P3
+#undef NT3
 
 // ---- rank level (multi-GPU) ------------------------------------------------------------------------
 // nxt[n]: the entry node that follows perimeter node n on its path through the rank -- the node its tile's
