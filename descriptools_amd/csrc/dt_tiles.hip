@@ -1349,9 +1349,13 @@ __global__ __launch_bounds__(256, MINW) void k_fh_tile3(const uint8_t *__restric
     o.fd = ok ? (float)(dcard * (double)nc + ddiag * (double)nd) : DT_NODATA;
     o.i32 = (ok && !remote) ? (int32_t)ridx : -100;
     o.i64 = -100;
-    if (RANKED && idx64 && ok)
+    if (RANKED && ok) {
+      // rank mode: the river index is the GLOBAL raster's, in both widths (the 32-bit one is meaningful while the
+      // global raster has <= 2^31 cells: 8 ranks of 16384^2; half the bytes of the widest output raster)
       o.i64 = remote ? rem.gidx[ridx & ~FHT_REMOTE]
                      : (long long)(w.gy0 + (int)(ridx / (uint32_t)w.W)) * w.Wg + w.gx0 + (int)(ridx % (uint32_t)w.W);
+      o.i32 = (int32_t)o.i64;
+    }
     o.h = DT_NODATA;
     if (z != DT_NODATA && ok) {  // flowhand.py:436
       o.h = z - __uint_as_float((uint32_t)pay);

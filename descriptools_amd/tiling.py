@@ -260,7 +260,7 @@ class RankTile:
     """Extended rasters ((H + 2*HALO) x (W + 2*HALO)) of one rank and the windowed library calls."""
 
     def __init__(self, layout, rank, device=0, stream=None, px=10.0, n_top=0.1, n_gfi=0.4, b=0.1, dz=5.0,
-                 river_threshold=None, halo=HALO):
+                 river_threshold=None, halo=HALO, idx64=None):
         import torch
         from . import _lib
         from .device import Context
@@ -279,11 +279,17 @@ class RankTile:
         self.px, self.n_top, self.n_gfi, self.b, self.dz = px, n_top, n_gfi, b, dz
         self.river_threshold = (layout.Hg * layout.Wg) // 512 if river_threshold is None else int(river_threshold)
         self.P = perim_count(self.H, self.W)
+        # the river index is the GLOBAL raster's flat index: int32 while that raster has <= 2^31 cells (eight
+        # ranks of 16384^2), int64 beyond -- the widest output raster of the step
+        if idx64 is None:
+            idx64 = layout.Hg * layout.Wg > 2 ** 31
+        assert idx64 or layout.Hg * layout.Wg <= 2 ** 31
+        self.idx_dtype = torch.int64 if idx64 else torch.int32
         t = {}
         self._on_ts = torch.cuda.stream(self.ts)
         self._on_ts.__enter__()
         for name, dt in (("dem", torch.float32), ("fdr", torch.uint8), ("fac", torch.int32),
-                         ("river", torch.int8), ("fdist", torch.float32), ("idx", torch.int64),
+                         ("river", torch.int8), ("fdist", torch.float32), ("idx", self.idx_dtype),
                          ("hand", torch.float32), ("a_river", torch.int32), ("slope", torch.float32),
                          ("ti", torch.float32), ("mti", torch.float32), ("gfi", torch.float32),
                          ("lnhlh", torch.float32), ("down", torch.float32)):
@@ -421,6 +427,10 @@ class RankTile:
                                                  self._ext.data_ptr(), self.river_threshold, self.p("fac"),
                                                  self.p("river")))
 
+    def _idx_args(self):
+        """(idx32, idx64) of the windowed HAND calls: the one of the two that matches the idx raster's dtype"""
+        return (self.p("idx"), None) if self.idx_dtype == self.torch.int32 else (None, self.p("idx"))
+
     def fh_solve_finish(self, rows, fuse_gfi=False, want_a_river=True):
         """rank-level HAND solve on the GPU, then pass 3; fuse_gfi: GFI and ln(hl/H) in the same pass (the
         river-accumulation raster is then only an optional by-product)."""
@@ -433,13 +443,13 @@ class RankTile:
         if fuse_gfi:
             self._chk(self.L.dt_dev_flowhand_gfi_finish_w(
                 self.ctx.h, C.byref(self.win), self.p("dem"), self.p("fdr"), self.p("river"), self.p("fac"),
-                self.px, self.n_gfi, self.b, *[a.data_ptr() for a in r], self.p("fdist"), None, self.p("idx"),
+                self.px, self.n_gfi, self.b, *[a.data_ptr() for a in r], self.p("fdist"), *self._idx_args(),
                 self.p("hand"), self.p("a_river") if want_a_river else None, self.p("gfi"), self.p("lnhlh")))
         else:
             self._chk(self.L.dt_dev_flowhand_finish_w(self.ctx.h, C.byref(self.win), self.p("dem"), self.p("fdr"),
                                                       self.p("river"), self.p("fac"), self.px,
-                                                      *[a.data_ptr() for a in r], self.p("fdist"), None,
-                                                      self.p("idx"), self.p("hand"), self.p("a_river")))
+                                                      *[a.data_ptr() for a in r], self.p("fdist"),
+                                                      *self._idx_args(), self.p("hand"), self.p("a_river")))
 
     def fh_local(self, sync=True):
         v = self._fh_v
@@ -461,8 +471,8 @@ class RankTile:
             ptrs = [a.data_ptr() for a in self._keep2]
         self._chk(self.L.dt_dev_flowhand_finish_w(self.ctx.h, C.byref(self.win), self.p("dem"), self.p("fdr"),
                                                   self.p("river"), self.p("fac"), self.px, ptrs[0], ptrs[1],
-                                                  ptrs[2], ptrs[3], ptrs[4], ptrs[5], self.p("fdist"), None,
-                                                  self.p("idx"), self.p("hand"), self.p("a_river")))
+                                                  ptrs[2], ptrs[3], ptrs[4], ptrs[5], self.p("fdist"),
+                                                  *self._idx_args(), self.p("hand"), self.p("a_river")))
 
     def slope_twi(self):
         """fused slope + TI + MTI on the core window (needs fac)."""

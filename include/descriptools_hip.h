@@ -252,7 +252,9 @@ int dt_dev_flowhand_local_w(dt_ctx *ctx, const dt_window *win, const float *dem,
                             int32_t *nc, int32_t *nd, float *zr, int32_t *ar);
 /* phase 2: for every ring cell whose step leaves the rank: res_ok != 0 -> that path ends on a river
  * cell after res_nc / res_nd further moves, global flat index rem_gidx, height rem_zr, accumulation
- * rem_ar (all NULL = no other ranks).  idx64 (may be NULL) receives GLOBAL flat indices. */
+ * rem_ar (all NULL = no other ranks).  idx64 (may be NULL) receives GLOBAL flat indices; so does idx32 (may be NULL)
+ * whenever the rank tables or idx64 are given -- meaningful while the global raster has <= 2^31 cells, and half
+ * the bytes -- and the core-local flat index otherwise (a single raster: the same thing). */
 int dt_dev_flowhand_finish_w(dt_ctx *ctx, const dt_window *win, const float *dem, const uint8_t *fdr,
                              const int8_t *river, const int32_t *acc32, double px, const uint8_t *res_ok,
                              const int32_t *res_nc, const int32_t *res_nd, const int64_t *rem_gidx,

@@ -98,4 +98,5 @@ def test_config4_32768_tiled_2x2_equals_untiled():
         li = t["idx"][y0:y0 + tl.H, x0:x0 + tl.W].long()
         gy, gx = li // n, li % n
         want = torch.where(li >= 0, gy * n + gx, li)
-        assert torch.equal(gi, want), (tl.rank, "idx")
+        assert gi.dtype == torch.int32  # 2^30 cells: the 32-bit global index
+        assert torch.equal(gi.long(), want), (tl.rank, "idx")

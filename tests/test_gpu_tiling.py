@@ -38,7 +38,8 @@ def test_tiled_equals_untiled(heights, widths, nod, seed, solver):
     pad[h:h + Hg, h:h + Wg] = dem
     tiles = []
     for r in range(layout.size):
-        t = tiling.RankTile(layout, r, device=0, px=px, river_threshold=thr)
+        # the river index raster in both widths (int64 is what a global raster beyond 2^31 cells gets)
+        t = tiling.RankTile(layout, r, device=0, px=px, river_threshold=thr, idx64=(seed % 2 == 0))
         y0, x0 = layout.origin(r)
         t.set_dem_ext(pad[y0:y0 + t.He, x0:x0 + t.We])
         tiles.append(t)
@@ -52,6 +53,7 @@ def test_tiled_equals_untiled(heights, widths, nod, seed, solver):
             assert np.array_equal(got, want.astype(got.dtype), equal_nan=True), \
                 "rank %d %s: %d cells differ" % (t.rank, name, int((got != want).sum()))
         # river index: global flat index of the untiled run
+        assert t.host("idx").dtype == (np.int64 if seed % 2 == 0 else np.int32)
         assert np.array_equal(t.host("idx"), ref["idx"][sl])
 
 
