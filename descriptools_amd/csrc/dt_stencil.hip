@@ -112,12 +112,16 @@ __device__ __forceinline__ SlopeCell dt_slope_cell(float c, float nw, float n, f
 }
 
 // XCD-aware tile mapping: workgroup id b runs on XCD group (b % 8); give each group a band of tile rows
-// and walk it row-major.
+// and walk it row-major -- each group starting an eighth of a band further in than the previous one (and
+// wrapping), so that the eight write fronts are not exactly one band apart in memory: 1-1.5 % on the fused
+// stencil on every placement tried (tools/placement_probe5.py; identity and row-interleaved maps: slower).
 __device__ __forceinline__ int sd_tile_of_block(int b, int ntiles) {
   int xcd = b & 7, j = b >> 3;
   int q = ntiles >> 3, rem = ntiles & 7;
   int base = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
-  return base + j;
+  int n = q + (xcd < rem ? 1 : 0);  // tiles of this band (j < n)
+  int k = j + xcd * (n >> 3);
+  return base + (k >= n ? k - n : k);
 }
 __device__ __forceinline__ void sd_tile_origin(int b, int tiles_x, int tiles_y, int &x0, int &y0) {
   int tile = sd_tile_of_block(b, tiles_x * tiles_y);
