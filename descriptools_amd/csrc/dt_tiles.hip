@@ -399,8 +399,11 @@ __global__ __launch_bounds__(256) void k_fa_poison(const unsigned long long *__r
                                                   unsigned long long *__restrict__ ext) {
   int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (n >= nnodes) return;
+  // the countdown word first: it is 0-pending for every node that is not an exit and for every resolved exit, i.e.
+  // for all but the handful this kernel is about -- one array streamed instead of three
+  if ((state[n] >> FA2_SH) == 0ull) return;
   if (REC_CODE(rec[n]) == 0 || entry_of[n] == FA_NONE) return;
-  if ((state[n] >> FA2_SH) != 0ull) atomicOr(&ext[entry_of[n]], FA_CYCLE);
+  atomicOr(&ext[entry_of[n]], FA_CYCLE);
 }
 
 // pass 3: the inflow that enters the tile at a perimeter cell p (ext[p], resolved by pass 2) drains
