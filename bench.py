@@ -14,6 +14,7 @@ Timing: K steps bracketed by barrier + synchronize on both sides, max over ranks
 come from HIP events recorded on the stream the kernels run on, inside the same timed region.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -65,6 +66,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=4096, help="edge of the CPU baseline's DEMs (BASELINE.md 3: 4096)")
     ap.add_argument("--no-verify", action="store_true", help="skip the cross-check of the timed step's rasters")
+    ap.add_argument("--graph", action="store_true", help="N = 1: replay the step as one HIP graph launch "
+                    "(chain.Chain.capture) instead of ~45 kernel launches; per-op times are then not available")
     ap.add_argument("--overlap", action="store_true", help="run downslope as a second branch on its own stream "
                     "beside flow accumulation / HAND (Chain(overlap=True)): faster end to end, but the per-kernel "
                     "timings stop being attributable; off by default")
@@ -164,9 +167,26 @@ def main():
     barrier()
     ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in calls]
           for _ in range(args.steps)]
+    graph = None
+    if args.graph:
+        check = _lib.check
+        check(L.dt_ctx_capture_begin(ctx.h))
+        step()
+        gh = ctypes.c_void_p()
+        check(L.dt_ctx_capture_end(ctx.h, ctypes.byref(gh)))
+        graph = gh
+        for _ in range(args.warmup):
+            check(L.dt_graph_launch(graph, ctx.h))
+        barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(ev[k])
+        if graph is not None:
+            _lib.check(L.dt_graph_launch(graph, ctx.h))
+            for i in range(len(calls)):  # keep the per-op arithmetic below well-defined: zero-length intervals
+                ev[k][i][0].record(stream)
+                ev[k][i][1].record(stream)
+        else:
+            step(ev[k])
     barrier()
     dt = time.perf_counter() - t0
 
@@ -223,7 +243,8 @@ def main():
                                "(d8, flowacc, river mask, flowhand/HAND with fused GFI + ln(hl/H), fused slope+TI+MTI, "
                                "downslope), device-resident" % (S, S),
                    "global_dem": "%dx%d" % (H, W), "px": 10.0, "river_threshold_cells": ch.river_threshold,
-                   "parallelism": "single GPU" + (", downslope on a second stream (--overlap)" if args.overlap else "")},
+                   "parallelism": "single GPU" + (", downslope on a second stream (--overlap)" if args.overlap else "")
+                                  + (", the step replayed as one HIP graph (--graph)" if args.graph else "")},
         "roofline": roof,
         "per_op": per_op,
         "verified": verified,

@@ -35,6 +35,10 @@ _SIGS = {
     "dt_ctx_set_stream": (ci, [vp, vp]),
     "dt_ctx_stream": (vp, [vp]),
     "dt_ctx_sync": (ci, [vp]),
+    "dt_ctx_capture_begin": (ci, [vp]),
+    "dt_ctx_capture_end": (ci, [vp, C.POINTER(vp)]),
+    "dt_graph_launch": (ci, [vp, vp]),
+    "dt_graph_destroy": (ci, [vp]),
     "dt_ctx_status": (ci, [vp, c_i32p]),
     "dt_ctx_scratch_bytes": (i64, [vp]),
     # host tier

@@ -101,6 +101,25 @@ class Chain:
         if self.side is not None:
             self.ctx.join(self.side)
 
+    def capture(self, dem_ptr, want_a_river=True):
+        """The step as a HIP graph: runs it once (workspaces, tables), records a second run, returns a `Graph` whose
+        launch() replays the ~45 kernel launches with one.  It takes the host out of the step (one call instead
+        of 45 through ctypes), not time off it: measured 0.213 / 0.324 / 9.05 ms direct against 0.226 / 0.336 /
+        8.98 ms replayed at 1024^2 / 2048^2 / 16384^2 -- the asynchronous launches already keep ahead of the GPU,
+        and what a small step costs is the ~5 us each dependent kernel takes to start, which a graph of the same
+        kernels keeps.  The DEM pointer and this chain's buffers are baked into the graph."""
+        self.run(dem_ptr, want_a_river)
+        self.ctx.sync()
+        L = _lib.lib()
+        check(L.dt_ctx_capture_begin(self.ctx.h))
+        try:
+            self.run(dem_ptr, want_a_river)
+        finally:
+            g = C.c_void_p()
+            rc = L.dt_ctx_capture_end(self.ctx.h, C.byref(g))
+        check(rc)
+        return Graph(g, self.ctx)
+
     def free(self):
         if self._own_side:
             self.side.close()
@@ -109,6 +128,21 @@ class Chain:
             if hasattr(b, "free"):
                 b.free()
         self.buf, self._ring = {}, None
+
+
+class Graph:
+    """A captured step (Chain.capture)."""
+
+    def __init__(self, handle, ctx):
+        self.h, self.ctx = handle, ctx
+
+    def launch(self):
+        check(_lib.lib().dt_graph_launch(self.h, self.ctx.h))
+
+    def free(self):
+        if self.h:
+            check(_lib.lib().dt_graph_destroy(self.h))
+            self.h = None
 
 
 def run_host(dem, px, **kw):

@@ -70,6 +70,18 @@ void *dt_ctx_stream(dt_ctx *ctx);
 int dt_ctx_fork(dt_ctx *parent, dt_ctx *child);
 int dt_ctx_join(dt_ctx *parent, dt_ctx *child);
 int dt_ctx_sync(dt_ctx *ctx);
+/* HIP graphs.  Everything enqueued on the context's stream between dt_ctx_capture_begin and dt_ctx_capture_end
+ * (dt_dev_* calls on this context, and on contexts forked from it and joined again) is recorded instead of run;
+ * dt_graph_launch replays it with ONE launch on a context of the same device.  Capture a step whose buffers and
+ * workspaces already exist (run it once first): allocation and synchronisation inside a capture fail.  The
+ * pointers the calls were given are baked in.  No reference counterpart (the reference launches kernel by
+ * kernel, descriptools/slope.py:190-200).  It frees the host (one call per step instead of ~45), it does not
+ * shorten the step: the launches are asynchronous and already keep ahead of the GPU at every raster size tried. */
+typedef struct dt_graph dt_graph;
+int dt_ctx_capture_begin(dt_ctx *ctx);
+int dt_ctx_capture_end(dt_ctx *ctx, dt_graph **out);
+int dt_graph_launch(dt_graph *graph, dt_ctx *ctx);
+int dt_graph_destroy(dt_graph *graph);
 /* Sticky status bits raised by kernels since the last call (synchronises the context's stream, clears them).
  * DT_STATUS_ACC_OVERFLOW: a flow accumulation value of a multi-rank raster may have reached 2^31 cells; the device
  * accumulation rasters are int32 (a device tile is < 2^31 cells), so the results of that step are not valid. */
