@@ -58,6 +58,17 @@ __device__ __forceinline__ uint32_t dt_node_of(int y, int x, int tiles_x) {
   return (uint32_t)((ty * tiles_x + tx) * PS + dt_slot_of(y - ty * TH, x - tx * TW));
 }
 
+// Workgroup -> tile.  Workgroup ids congruent mod 8 share an XCD (and its L2): consecutive workgroups of one XCD
+// take horizontally adjacent tiles, two by two.  A tile row of a BYTE raster is 64 bytes, half a 128-byte line:
+// with the identity map the two halves went to two different XCDs and the line was fetched from HBM twice
+// (PMC: 4.0 B/cell fetched by the passes that read 1-2 B/cell of direction codes / river mask).
+__device__ __forceinline__ int dt_tile_of_block(int b, int ntiles) {
+  const int full = ntiles & ~15;  // whole groups of 16 tiles; the tail keeps the identity
+  if (b >= full) return b;
+  const int xcd = b & 7, j = b >> 3;
+  return ((j >> 1) * 8 + xcd) * 2 + (j & 1);
+}
+
 // ---- tile staging -----------------------------------------------------------------------------
 // direction codes of the tile's core cells into LDS (0 outside the core): 256 threads x 16 bytes, one 64-byte row
 // per 4 threads.  Split into the load and the LDS store so that a kernel can have several tile loads in flight
@@ -229,7 +240,7 @@ __global__ __launch_bounds__(256, 6) void k_fa_tile1(const uint8_t *__restrict__
   __shared__ __attribute__((aligned(16))) uint16_t s_ptr[NT];   // idx:12 | PT_EXIT | PT_ALIVE
   __shared__ __attribute__((aligned(16))) uint32_t s_recv[NT];  // what a cell receives in a round
   uint8_t *s_fdr = reinterpret_cast<uint8_t *>(s_recv);
-  const int tile = blockIdx.x;
+  const int tile = dt_tile_of_block((int)blockIdx.x, (int)gridDim.x);
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int y0 = ty * TH, x0 = tx * TW;
   // The tile's codes and, for the perimeter lanes, the codes of the <= 5 neighbours outside the tile: all loads in
@@ -427,7 +438,7 @@ __global__ __launch_bounds__(256, 6) void k_fa_tile3(const uint8_t *__restrict__
   __shared__ uint16_t s_nxt[NT3];
   __shared__ __attribute__((aligned(16))) uint32_t s_delta[NT3];
   uint8_t *s_fdr = reinterpret_cast<uint8_t *>(s_delta);
-  const int tile = blockIdx.x;
+  const int tile = dt_tile_of_block((int)blockIdx.x, (int)gridDim.x);
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int y0 = ty * TH, x0 = tx * TW;
   // every global load of the kernel is issued here, before the first wait: the tile's codes, the resolved inflow
@@ -918,7 +929,7 @@ __global__ __launch_bounds__(256) void k_fh_tile1(const uint8_t *__restrict__ fd
   __shared__ __attribute__((aligned(16))) uint8_t s_fdr[NT];
   __shared__ uint8_t s_halo[2 * (TW + 2) + 2 * TH];
   __shared__ __attribute__((aligned(16))) unsigned long long s_st[NT];
-  const int tile = blockIdx.x;
+  const int tile = dt_tile_of_block((int)blockIdx.x, (int)gridDim.x);
   if (only_marked && cache_wide[tile] != 2) return;  // block-uniform: k_fh_tile1n did this tile
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int y0 = ty * TH, x0 = tx * TW;
@@ -987,7 +998,7 @@ __global__ __launch_bounds__(256, 6) void k_fh_tile1n(const uint8_t *__restrict_
   __shared__ __attribute__((aligned(16))) uint32_t s_w[NT];
   __shared__ __attribute__((aligned(16))) uint8_t s_kind[NT];  // first the river mask, then the end kinds
   __shared__ int s_ovf;
-  const int tile = blockIdx.x;
+  const int tile = dt_tile_of_block((int)blockIdx.x, (int)gridDim.x);
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int y0 = ty * TH, x0 = tx * TW;
   // the tile's codes and its river mask: both loads issued before the first is waited for.  (No halo ring of
@@ -1252,7 +1263,7 @@ __global__ __launch_bounds__(256, MINW) void k_fh_tile3(const uint8_t *__restric
   __shared__ unsigned long long s_pay[PS];
   __shared__ DtLogEntry s_tab[DT_LOGTAB_N];  // 2 KiB: the GFI epilogue's logarithm table
   if (G.gfi) dt_math_stage(G.tab, s_tab);  // before the barrier every path below passes
-  const int tile = blockIdx.x;
+  const int tile = dt_tile_of_block((int)blockIdx.x, (int)gridDim.x);
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int y0 = ty * TH, x0 = tx * TW;
   const bool wide = cache_wide[tile] != 0;  // block-uniform
