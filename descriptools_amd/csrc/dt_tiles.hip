@@ -1134,9 +1134,12 @@ __global__ __launch_bounds__(256) void k_fh_ghost_init(unsigned long long *__res
 
 // pass 2: pointer doubling over the perimeter nodes (same word format as the v1 raster kernel)
 __global__ __launch_bounds__(256) void k_fh_node_jump(unsigned long long *__restrict__ state, int64_t n,
-                                                      int *__restrict__ flags, int round) {
+                                                      int *__restrict__ flags, int round, int hops) {
   // flags[r] != 0: round r left a node that can still make progress.  Rounds after the first quiet one are
-  // no-ops and return at once (the bound of 15 rounds is for 20000-move chains; typical rasters need ~10).
+  // no-ops and return at once.  `hops` jumps per node and launch: any value a word ever held is a true statement,
+  // so a second jump may use a target this launch has or has not updated yet -- either way the resolved distance
+  // at least triples per launch (doubles with one hop), and one stream over the 16.6 M node words serves two
+  // jumps (the kernel is bound by that stream).
   if (flags && round > 0 && flags[round - 1] == 0) {
     if (blockIdx.x == 0 && threadIdx.x == 0) flags[round] = 0;
     return;
@@ -1144,20 +1147,24 @@ __global__ __launch_bounds__(256) void k_fh_node_jump(unsigned long long *__rest
   bool pending = false;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     unsigned long long s = __hip_atomic_load(&state[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint32_t ncf = (uint32_t)(s & 0xFFFFu);
-    uint32_t ptr = (uint32_t)(s >> 32), nd = (uint32_t)((s >> 16) & 0xFFFFu);
-    if (!(ncf & FHT_DONE) && ptr != (uint32_t)i) {  // not finished, not an unresolved ghost
-      unsigned long long t = __hip_atomic_load(&state[ptr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      uint32_t tptr = (uint32_t)(t >> 32), tnd = (uint32_t)((t >> 16) & 0xFFFFu);
-      uint32_t tncf = (uint32_t)(t & 0xFFFFu);
-      uint32_t nnc = ncf + (tncf & 0x7FFFu), nnd = nd + tnd;
-      unsigned long long o;
-      if (((tncf & FHT_DONE) && tptr == FHT_DEAD) || nnc + nnd > FHT_CAP) o = fht_pack(FHT_DEAD, 0, FHT_DONE);
-      else o = fht_pack(tptr, nnd, nnc | (tncf & FHT_DONE));
-      __hip_atomic_store(&state[i], o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool open = false, changed = false;
+    for (int h = 0; h < hops; h++) {
+      const uint32_t ncf = (uint32_t)(s & 0xFFFFu);
+      const uint32_t ptr = (uint32_t)(s >> 32), nd = (uint32_t)((s >> 16) & 0xFFFFu);
+      if ((ncf & FHT_DONE) || ptr == (uint32_t)i) break;  // finished, or an unresolved ghost
+      const unsigned long long t = __hip_atomic_load(&state[ptr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t tptr = (uint32_t)(t >> 32), tnd = (uint32_t)((t >> 16) & 0xFFFFu);
+      const uint32_t tncf = (uint32_t)(t & 0xFFFFu);
+      const uint32_t nnc = ncf + (tncf & 0x7FFFu), nnd = nd + tnd;
+      if (((tncf & FHT_DONE) && tptr == FHT_DEAD) || nnc + nnd > FHT_CAP) s = fht_pack(FHT_DEAD, 0, FHT_DONE);
+      else s = fht_pack(tptr, nnd, nnc | (tncf & FHT_DONE));
+      changed = true;
       // still open and not parked on an unresolved ghost (a fixed point pointing at itself)
-      pending = pending || (!(o & (unsigned long long)FHT_DONE) && tptr != ptr);
+      open = !(s & (unsigned long long)FHT_DONE) && tptr != ptr;
+      if (!open) break;
     }
+    if (changed) __hip_atomic_store(&state[i], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    pending = pending || open;
   }
   if (flags && __any(pending) && (threadIdx.x & 63) == 0) flags[round] = 1;
 }
@@ -1506,12 +1513,13 @@ int dt_launch_fh_local(hipStream_t s, const DtWin &w, const uint8_t *fdr, const 
   hipLaunchKernelGGL(k_fh_tile1, gt, b, 0, s, fdr, river, w, f.tiles_x, (uint32_t)f.nnodes, f.nodes, f.cache,
                      f.cache_wide, 1);
   hipLaunchKernelGGL(k_fh_ghost_init, dim3((unsigned)((f.P + 255) / 256)), b, 0, s, f.nodes, (uint32_t)f.nnodes, f.P);
-  // 15 rounds resolve every chain of <= 20000 moves (each node hop is >= 1 move; 2^15 > 20000)
+  // 10 launches of 2 jumps resolve every chain of <= 20000 moves (each node hop is >= 1 move; the resolved
+  // distance at least triples per launch: 3^10 > 20000)
   int *flags = (int *)((char *)f.cache + dt_align256((size_t)f.ntiles * NT * 8));  // the layout's spare 256 bytes
   DT_HIP(hipMemsetAsync(flags, 0, 64, s));
   dim3 gj(gn.x < 4096u ? gn.x : 4096u);  // grid-stride: a quiet round costs a few microseconds
-  for (int r = 0; r < 15; r++)
-    hipLaunchKernelGGL(k_fh_node_jump, gj, b, 0, s, f.nodes, f.nnodes + f.P, flags, r);
+  for (int r = 0; r < 10; r++)
+    hipLaunchKernelGGL(k_fh_node_jump, gj, b, 0, s, f.nodes, f.nnodes + f.P, flags, r, 2);
   return DT_OK;
 }
 
@@ -1792,8 +1800,8 @@ int dt_launch_rank_solve_flowhand(hipStream_t s, int ty, int tx, const int64_t *
   unsigned long long *nodes = (unsigned long long *)scratch;
   dim3 g((unsigned)((nn + 255) / 256)), b(256);
   hipLaunchKernelGGL(k_rk_fh_build, g, b, 0, s, L, R, nodes);
-  // every hop between ranks is >= 1 move: 15 doublings cover the 20000-move cap
-  for (int r = 0; r < 15; r++) hipLaunchKernelGGL(k_fh_node_jump, g, b, 0, s, nodes, (int64_t)nn, (int *)nullptr, r);
+  // every hop between ranks is >= 1 move: 10 launches of two jumps (>= 3 x each) cover the 20000-move cap
+  for (int r = 0; r < 10; r++) hipLaunchKernelGGL(k_fh_node_jump, g, b, 0, s, nodes, (int64_t)nn, (int *)nullptr, r, 2);
   hipLaunchKernelGGL(k_rk_fh_result, dim3((unsigned)((P_rank + 255) / 256)), b, 0, s, L, R, nodes, rank,
                      (long long)P_rank, res_ok, res_nc, res_nd, gidx, zr, ar);
   return DT_OK;
