@@ -1137,9 +1137,9 @@ __global__ __launch_bounds__(256) void k_fh_node_jump(unsigned long long *__rest
                                                       int *__restrict__ flags, int round, int hops) {
   // flags[r] != 0: round r left a node that can still make progress.  Rounds after the first quiet one are
   // no-ops and return at once.  `hops` jumps per node and launch: any value a word ever held is a true statement,
-  // so a second jump may use a target this launch has or has not updated yet -- either way the resolved distance
-  // at least triples per launch (doubles with one hop), and one stream over the 16.6 M node words serves two
-  // jumps (the kernel is bound by that stream).
+  // so a later jump may use a target this launch has or has not updated yet -- either way the resolved distance
+  // grows at least (hops + 1)-fold per launch (doubles with one hop), and one stream over the 16.6 M node words
+  // serves all the jumps (the kernel is bound by that stream).
   if (flags && round > 0 && flags[round - 1] == 0) {
     if (blockIdx.x == 0 && threadIdx.x == 0) flags[round] = 0;
     return;
@@ -1513,13 +1513,14 @@ int dt_launch_fh_local(hipStream_t s, const DtWin &w, const uint8_t *fdr, const 
   hipLaunchKernelGGL(k_fh_tile1, gt, b, 0, s, fdr, river, w, f.tiles_x, (uint32_t)f.nnodes, f.nodes, f.cache,
                      f.cache_wide, 1);
   hipLaunchKernelGGL(k_fh_ghost_init, dim3((unsigned)((f.P + 255) / 256)), b, 0, s, f.nodes, (uint32_t)f.nnodes, f.P);
-  // 10 launches of 2 jumps resolve every chain of <= 20000 moves (each node hop is >= 1 move; the resolved
-  // distance at least triples per launch: 3^10 > 20000)
+  // 8 launches of 3 jumps resolve every chain of <= 20000 moves (each node hop is >= 1 move; the resolved
+  // distance at least quadruples per launch: 4^8 > 20000).  HAND's first phase at 16384^2: 1.40 ms with 15 x 1,
+  // 1.33 with 10 x 2, 1.30 with 8 x 3 or 7 x 4.
   int *flags = (int *)((char *)f.cache + dt_align256((size_t)f.ntiles * NT * 8));  // the layout's spare 256 bytes
   DT_HIP(hipMemsetAsync(flags, 0, 64, s));
   dim3 gj(gn.x < 4096u ? gn.x : 4096u);  // grid-stride: a quiet round costs a few microseconds
-  for (int r = 0; r < 10; r++)
-    hipLaunchKernelGGL(k_fh_node_jump, gj, b, 0, s, f.nodes, f.nnodes + f.P, flags, r, 2);
+  for (int r = 0; r < 8; r++)
+    hipLaunchKernelGGL(k_fh_node_jump, gj, b, 0, s, f.nodes, f.nnodes + f.P, flags, r, 3);
   return DT_OK;
 }
 
@@ -1800,8 +1801,8 @@ int dt_launch_rank_solve_flowhand(hipStream_t s, int ty, int tx, const int64_t *
   unsigned long long *nodes = (unsigned long long *)scratch;
   dim3 g((unsigned)((nn + 255) / 256)), b(256);
   hipLaunchKernelGGL(k_rk_fh_build, g, b, 0, s, L, R, nodes);
-  // every hop between ranks is >= 1 move: 10 launches of two jumps (>= 3 x each) cover the 20000-move cap
-  for (int r = 0; r < 10; r++) hipLaunchKernelGGL(k_fh_node_jump, g, b, 0, s, nodes, (int64_t)nn, (int *)nullptr, r, 2);
+  // every hop between ranks is >= 1 move: 8 launches of three jumps (>= 4 x each) cover the 20000-move cap
+  for (int r = 0; r < 8; r++) hipLaunchKernelGGL(k_fh_node_jump, g, b, 0, s, nodes, (int64_t)nn, (int *)nullptr, r, 3);
   hipLaunchKernelGGL(k_rk_fh_result, dim3((unsigned)((P_rank + 255) / 256)), b, 0, s, L, R, nodes, rank,
                      (long long)P_rank, res_ok, res_nc, res_nd, gidx, zr, ar);
   return DT_OK;
