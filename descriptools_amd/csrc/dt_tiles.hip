@@ -1058,17 +1058,29 @@ __global__ __launch_bounds__(256, 6) void k_fh_tile1n(const uint8_t *__restrict_
       uint2 v = own[j];
       bool dx = (v.x & FN_DONE) != 0u, dy = (v.y & FN_DONE) != 0u;
       if (dx && dy) continue;
+      // two jumps per round (in place: a target read here may or may not have jumped already this round; every
+      // value it ever held is true): half the rounds, barriers and done-tests for the same gathers
       if (!dx) {
         uint32_t t = s_w[v.x >> FN_PTR_SH];
         uint32_t sum = (v.x & FN_LOW) + (t & FN_LOW);
-        ovf |= sum & FN_OVF;
         v.x = (t & ~FN_LOW) | sum;
+        if (!(sum & (FN_DONE | FN_OVF))) {
+          t = s_w[v.x >> FN_PTR_SH];
+          sum = (v.x & FN_LOW) + (t & FN_LOW);
+          v.x = (t & ~FN_LOW) | sum;
+        }
+        ovf |= sum & FN_OVF;
       }
       if (!dy) {
         uint32_t t = s_w[v.y >> FN_PTR_SH];
         uint32_t sum = (v.y & FN_LOW) + (t & FN_LOW);
-        ovf |= sum & FN_OVF;
         v.y = (t & ~FN_LOW) | sum;
+        if (!(sum & (FN_DONE | FN_OVF))) {
+          t = s_w[v.y >> FN_PTR_SH];
+          sum = (v.y & FN_LOW) + (t & FN_LOW);
+          v.y = (t & ~FN_LOW) | sum;
+        }
+        ovf |= sum & FN_OVF;
       }
       own[j] = v;
       s_w2[c2] = v;
