@@ -925,12 +925,14 @@ __global__ __launch_bounds__(256) void k_fh_tile1(const uint8_t *__restrict__ fd
                                                  const int8_t *__restrict__ river, DtWin w, int tiles_x,
                                                  uint32_t nnodes, unsigned long long *__restrict__ nodes,
                                                  unsigned long long *__restrict__ cache,
-                                                 uint8_t *__restrict__ cache_wide, int only_marked) {
+                                                 uint8_t *__restrict__ cache_wide, int only_marked, int ntiles) {
   __shared__ __attribute__((aligned(16))) uint8_t s_fdr[NT];
   __shared__ uint8_t s_halo[2 * (TW + 2) + 2 * TH];
   __shared__ __attribute__((aligned(16))) unsigned long long s_st[NT];
-  const int tile = dt_tile_of_block((int)blockIdx.x, (int)gridDim.x);
-  if (only_marked && cache_wide[tile] != 2) return;  // block-uniform: k_fh_tile1n did this tile
+  // grid-stride over the tiles: launched over all of them as the 64-bit solve, over a small grid as the redo of
+  // the tiles the narrow kernel gave up (usually none: 2048 workgroups look at 32 flags each and leave)
+  for (int tile = (int)blockIdx.x; tile < ntiles; tile += (int)gridDim.x) {
+  if (only_marked && cache_wide[tile] != 2) continue;  // block-uniform: k_fh_tile1n did this tile
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int y0 = ty * TH, x0 = tx * TW;
   FhTile T{s_fdr, s_halo, s_st};
@@ -974,6 +976,8 @@ __global__ __launch_bounds__(256) void k_fh_tile1(const uint8_t *__restrict__ fd
     uint32_t *c32 = reinterpret_cast<uint32_t *>(cache + (size_t)tile * NT);
 #pragma unroll
     for (int j = 0; j < CPT; j++) c32[threadIdx.x + 256 * j] = fh_cache_pack(wv[j]);
+  }
+  __syncthreads();  // the LDS images are reused by the next tile
   }
 }
 
@@ -1522,8 +1526,8 @@ int dt_launch_fh_local(hipStream_t s, const DtWin &w, const uint8_t *fdr, const 
   // second launch is 65536 workgroups that read one byte and leave)
   hipLaunchKernelGGL(k_fh_tile1n, gt, b, 0, s, fdr, river, w, f.tiles_x, (uint32_t)f.nnodes, f.nodes, f.cache,
                      f.cache_wide);
-  hipLaunchKernelGGL(k_fh_tile1, gt, b, 0, s, fdr, river, w, f.tiles_x, (uint32_t)f.nnodes, f.nodes, f.cache,
-                     f.cache_wide, 1);
+  hipLaunchKernelGGL(k_fh_tile1, dim3(gt.x < 2048u ? gt.x : 2048u), b, 0, s, fdr, river, w, f.tiles_x,
+                     (uint32_t)f.nnodes, f.nodes, f.cache, f.cache_wide, 1, (int)f.ntiles);
   hipLaunchKernelGGL(k_fh_ghost_init, dim3((unsigned)((f.P + 255) / 256)), b, 0, s, f.nodes, (uint32_t)f.nnodes, f.P);
   // 8 launches of 3 jumps resolve every chain of <= 20000 moves (each node hop is >= 1 move; the resolved
   // distance at least quadruples per launch: 4^8 > 20000).  HAND's first phase at 16384^2: 1.40 ms with 15 x 1,
