@@ -56,6 +56,34 @@ def relaunch_under_torchrun(args):
     return subprocess.call(cmd)
 
 
+def per_op_table(events, ops, cells, size, steps):
+    """events[k][i] = (start, end) HIP events of op i in step k, recorded on the stream the op was launched on;
+    ops = [(name, algorithmic bytes per cell, kernels)] -> per-op dict + the roofline block of the dominant
+    single-kernel op"""
+    per_op = {}
+    for i, (name, bpc, kernels) in enumerate(ops):
+        ms = float(np.mean([events[k][i][0].elapsed_time(events[k][i][1]) for k in range(steps)]))
+        gbs = cells * bpc / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        tr = pmc_traffic(kernels, size) if kernels else None
+        per_op[name] = {"ms": round(ms, 4), "algo_bytes_per_cell": bpc, "achieved_GBs": round(gbs, 1),
+                        "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic_bytes": None if tr is None else int(tr),
+                        "kernels": kernels}
+    # the dominant KERNEL: ops that are one (hot) kernel are timed by their events; the kernels of the multi-kernel
+    # ops (flow accumulation, HAND's first phase) are <= 1.4 ms each (profiles/)
+    single = [k for k in per_op if per_op[k]["algo_bytes_per_cell"] > 0 and
+              len([x for x in per_op[k]["kernels"] if not x.endswith("_fix")]) == 1]
+    dom = max(single, key=lambda k: per_op[k]["ms"])
+    roof = {"kernel": per_op[dom]["kernels"][0], "op": dom, "bound": "hbm",
+            "achieved": per_op[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": per_op[dom]["frac"], "traffic": per_op[dom]["traffic_bytes"],
+            "note": "dominant single kernel; achieved = algorithmic bytes/cell x cells / mean kernel time (HIP "
+                    "events on the launch stream, in the SERIAL timed loop of this process: ms_per_step_serial; "
+                    "the headline ms_per_step is the overlapped schedule, where per-kernel durations are not "
+                    "attributable); traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc runs "
+                    "committed under profiles/; per_op lists every op (multi-kernel ops: frac of the op as a whole)"}
+    return per_op, roof
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -64,13 +92,18 @@ def main():
     ap.add_argument("--size", type=int, default=16384, help="tile edge per GPU")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-n", type=int, default=4096, help="edge of the CPU baseline's DEMs (BASELINE.md 3: 4096)")
+    ap.add_argument("--cpu-n", type=int, default=3072, help="edge of the CPU baseline's DEM (a bounded sample: ~20 s "
+                    "on one thread)")
     ap.add_argument("--no-verify", action="store_true", help="skip the cross-check of the timed step's rasters")
-    ap.add_argument("--graph", action="store_true", help="N = 1: replay the step as one HIP graph launch "
-                    "(chain.Chain.capture) instead of ~45 kernel launches; per-op times are then not available")
-    ap.add_argument("--overlap", action="store_true", help="run downslope as a second branch on its own stream "
-                    "beside flow accumulation / HAND (Chain(overlap=True)): faster end to end, but the per-kernel "
-                    "timings stop being attributable; off by default")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end_to_end block (host-tier API, PCIe included)")
+    ap.add_argument("--e2e-size", type=int, default=8192, help="edge of the host DEM of the end_to_end block")
+    ap.add_argument("--graph", action="store_true", help="N = 1: the headline loop replays the step as one HIP graph "
+                    "launch (chain.Chain.capture) instead of ~45 kernel launches")
+    ap.add_argument("--no-overlap", action="store_true", help="headline loop on ONE stream, kernels back to back "
+                    "(default: downslope as a second branch on its own stream beside flow accumulation / HAND, "
+                    "Chain(overlap=True), the fastest correct schedule; per-op times always come from a second, "
+                    "serial timed loop)")
+    ap.add_argument("--overlap", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--tiled", action="store_true", help="N = 1 through the multi-rank path (1 x 1 layout): "
                                                          "measures what the tiling machinery costs")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and use the "
@@ -78,6 +111,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; default) or gloo (rehearsal of N > 1 "
                                                         "with several ranks sharing one GPU)")
     args = ap.parse_args()
+    args.overlap = not args.no_overlap
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(relaunch_under_torchrun(args))
@@ -114,14 +148,13 @@ def main():
     S = args.size
     H = W = S
     # a torch-owned NON-default stream: the library launches on it and torch events see it
-    stream = torch.cuda.Stream(device=dev, priority=-1 if args.overlap else 0)  # --overlap: the main branch first
+    stream = torch.cuda.Stream(device=dev, priority=-1 if args.overlap else 0)  # overlap: the main branch first
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
     ctx = Context(device=local_rank, stream=stream.cuda_stream)
     # second branch of the chain (downslope beside flow accumulation / HAND, chain.Chain.run): its own stream
     stream2 = torch.cuda.Stream(device=dev) if args.overlap else stream
     ctx2 = Context(device=local_rank, stream=stream2.cuda_stream) if args.overlap else ctx
-    streams = {id(ctx): stream, id(ctx2): stream2}
 
     def alloc(shape, dt):
         tdt = {np.float32: torch.float32, np.uint8: torch.uint8, np.int8: torch.int8,
@@ -137,81 +170,55 @@ def main():
 
     dem = alloc((H, W), np.float32)
     _lib.check(L.dt_dev_synth_dem(ctx.h, args.seed, H, W, 0, 0, H, W, 0, dem.data_ptr()))
-    ch = chain.Chain(H, W, ctx=ctx, px=10.0, river_threshold=(H * W) // 512, alloc=alloc_ptr, side_ctx=ctx2,
-                     overlap=args.overlap, want_slope_rad=False)
+    ch = chain.Chain(H, W, ctx=ctx, px=10.0, river_threshold=(H * W) // 512, alloc=alloc_ptr,
+                     side_ctx=ctx2 if args.overlap else None, overlap=args.overlap, want_slope_rad=False)
     rasters = {name: bufs[i] for i, (name, _) in enumerate(chain.OUTPUTS)}
     N = H * W
-
-    # THE step: chain.Chain.ops -- the list Chain.run executes (tests validate Chain.run), timed op by op
-    calls = ch.ops(dem.data_ptr(), want_a_river=False)
-    assert [n for n, _, _ in calls] == [n for n, _, _ in chain.OPS]
-
-    def step(events=None):
-        for i, (name, octx, fn) in enumerate(calls):
-            if name == "downslope" and args.overlap:
-                ctx.fork(ctx2)  # after D8
-            st = streams[id(octx)]
-            if events is not None:
-                events[i][0].record(st)
-            _lib.check(fn())
-            if events is not None:
-                events[i][1].record(st)
-        if args.overlap:
-            ctx.join(ctx2)
 
     def barrier():
         torch.cuda.synchronize()
 
+    # ---- headline: K steps of THE step -- chain.Chain.run, the schedule the tests validate (downslope as a second
+    # branch unless --no-overlap), or its HIP graph replay ----
+    def step():
+        ch.run(dem.data_ptr(), want_a_river=False)
+
     for _ in range(args.warmup):
         step()
     barrier()
-    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in calls]
-          for _ in range(args.steps)]
     graph = None
     if args.graph:
-        check = _lib.check
-        check(L.dt_ctx_capture_begin(ctx.h))
-        step()
-        gh = ctypes.c_void_p()
-        check(L.dt_ctx_capture_end(ctx.h, ctypes.byref(gh)))
-        graph = gh
+        graph = ch.capture(dem.data_ptr(), want_a_river=False)
         for _ in range(args.warmup):
-            check(L.dt_graph_launch(graph, ctx.h))
+            graph.launch()
         barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
         if graph is not None:
-            _lib.check(L.dt_graph_launch(graph, ctx.h))
-            for i in range(len(calls)):  # keep the per-op arithmetic below well-defined: zero-length intervals
-                ev[k][i][0].record(stream)
-                ev[k][i][1].record(stream)
+            graph.launch()
         else:
-            step(ev[k])
+            step()
     barrier()
     dt = time.perf_counter() - t0
 
-    # ---- per-op device times (HIP events on the launch stream) ----
-    per_op = {}
-    for i, (name, bpc, kernels) in enumerate(chain.OPS):
-        ms = float(np.mean([ev[k][i][0].elapsed_time(ev[k][i][1]) for k in range(args.steps)]))
-        gbs = N * bpc / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        tr = pmc_traffic(kernels, S)
-        per_op[name] = {"ms": round(ms, 4), "algo_bytes_per_cell": bpc, "achieved_GBs": round(gbs, 1),
-                        "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic_bytes": None if tr is None else int(tr),
-                        "kernels": kernels}
-    # the dominant KERNEL: ops that are one (hot) kernel are timed by their events; the kernels of the multi-kernel
-    # ops (flow accumulation, HAND's first phase) are <= 1.4 ms each (profiles/)
-    single = [k for k in per_op if len([x for x in per_op[k]["kernels"] if not x.endswith("_fix")]) == 1]
-    dom = max(single, key=lambda k: per_op[k]["ms"])
-    roof = {"kernel": per_op[dom]["kernels"][0], "op": dom, "bound": "hbm",
-            "achieved": per_op[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": per_op[dom]["frac"], "traffic": per_op[dom]["traffic_bytes"],
-            "note": "dominant single kernel; achieved = algorithmic bytes/cell x cells / mean kernel time (HIP "
-                    "events on the launch stream, timed region); traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
-                    "from separate rocprofv3 --pmc runs committed under profiles/; per_op lists every op "
-                    "(flowacc_river and flowhand_local are multi-kernel ops: their frac is of the op as a whole)"
-                    + (".  --overlap: downslope runs on a second stream beside flow accumulation / HAND, so the "
-                       "per-op times overlap and add up to more than ms_per_step" if args.overlap else "")}
+    # ---- second timed loop, same process: the same ops on ONE stream, back to back, each bracketed by HIP events on
+    # that stream -> per-op / per-kernel durations that mean something (chain.Chain.ops(serial=True)) ----
+    calls = ch.ops(dem.data_ptr(), want_a_river=False, serial=True)
+    assert [n for n, _, _ in calls] == [n for n, _, _ in chain.OPS]
+    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in calls]
+          for _ in range(args.steps)]
+    for _, _, fn in calls:
+        _lib.check(fn())
+    barrier()
+    t1 = time.perf_counter()
+    for k in range(args.steps):
+        for i, (name, octx, fn) in enumerate(calls):
+            ev[k][i][0].record(stream)
+            _lib.check(fn())
+            ev[k][i][1].record(stream)
+    barrier()
+    dt_serial = time.perf_counter() - t1
+    per_op, roof = per_op_table(ev, chain.OPS, N, S, args.steps)
 
     verified = None if args.no_verify else verify_step(torch, L, _lib, ctx, dem, rasters, ch, H, W)
 
@@ -233,6 +240,8 @@ def main():
         copy_gbs = max(copy_gbs, N * 8 * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9)
     del src, dst
 
+    sched = ("downslope on a second stream beside flow accumulation / HAND (Chain(overlap=True))" if args.overlap
+             else "one stream, kernels back to back (--no-overlap)")
     value = N * args.steps / dt / 1e6
     out = {
         "metric": "Mcells/s full descriptor chain", "value": round(value, 1), "unit": "Mcells/s",
@@ -243,8 +252,9 @@ def main():
                                "(d8, flowacc, river mask, flowhand/HAND with fused GFI + ln(hl/H), fused slope+TI+MTI, "
                                "downslope), device-resident" % (S, S),
                    "global_dem": "%dx%d" % (H, W), "px": 10.0, "river_threshold_cells": ch.river_threshold,
-                   "parallelism": "single GPU" + (", downslope on a second stream (--overlap)" if args.overlap else "")
-                                  + (", the step replayed as one HIP graph (--graph)" if args.graph else "")},
+                   "parallelism": "single GPU; " + sched
+                                  + ("; the step replayed as one HIP graph (--graph)" if args.graph else "")},
+        "ms_per_step_serial": round(dt_serial / args.steps * 1e3, 3),
         "roofline": roof,
         "per_op": per_op,
         "verified": verified,
@@ -252,6 +262,15 @@ def main():
         "chain_algo_bytes_per_cell": chain.ALGO_BYTES_PER_CELL,
         "chain_frac_of_hbm_peak": round(N * args.steps * chain.ALGO_BYTES_PER_CELL / dt / 1e9 / HBM_PEAK_GBS, 4),
     }
+    if graph is not None:
+        graph.free()
+    # free the chain before the host-side blocks (they need host and device memory of their own)
+    rasters.clear()
+    bufs.clear()
+    ch.free()
+    torch.cuda.empty_cache()
+    if not args.no_e2e:
+        out["end_to_end"] = end_to_end(args.e2e_size, args.seed)
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_n)
     print(json.dumps(out), flush=True)
@@ -347,7 +366,9 @@ def verify_step(torch, L, _lib, ctx, dem, rasters, ch, H, W):
 
 def main_tiled(args, torch, dist, world, rank, local_rank, dev):
     """N > 1: one S x S core tile per rank of a (ty*S) x (tx*S) DEM; halo generated locally from the
-    global generator; two RCCL all-gathers of ring summaries per step (flow accumulation, HAND)."""
+    global generator; two RCCL all-gathers of ring summaries per step (flow accumulation, HAND).  Same line as N = 1:
+    headline = tiling.run_rank (overlapped unless --no-overlap), then a serial loop on rank 0's stream for per_op /
+    roofline, cross-checks of the rasters, cpu_baseline on rank 0."""
     from descriptools_amd import chain, tiling
     S = args.size
     stream = torch.cuda.Stream(device=dev)
@@ -366,6 +387,13 @@ def main_tiled(args, torch, dist, world, rank, local_rank, dev):
         torch.cuda.synchronize()
 
     cpu_red = use_dist and dist.get_backend() == "gloo"
+    red_dev = "cpu" if cpu_red else dev
+
+    def allreduce(vals, op=None):
+        t = torch.tensor(vals, dtype=torch.float64 if isinstance(vals[0], float) else torch.int64, device=red_dev)
+        if use_dist:
+            dist.all_reduce(t, op=op if op is not None else dist.ReduceOp.SUM)
+        return t.cpu().tolist()
 
     for _ in range(args.warmup):
         tiling.run_rank(tile, layout, exchange, overlap=args.overlap)
@@ -375,49 +403,214 @@ def main_tiled(args, torch, dist, world, rank, local_rank, dev):
         tiling.run_rank(tile, layout, exchange, overlap=args.overlap)
     barrier()
     dt = time.perf_counter() - t0
-    unres = torch.tensor([tile.unresolved_downslope(), tile.ctx.status() & 1], dtype=torch.int64,
-                         device="cpu" if cpu_red else dev)
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if cpu_red else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        dist.all_reduce(unres)
+        dt = allreduce([dt], dist.ReduceOp.MAX)[0]
+    status = tile.ctx.status() & 1
+    unres = allreduce([tile.unresolved_downslope(), status])
+
+    # ---- serial loop: the stages of rank_ops() back to back on the context's stream, HIP events around each ----
+    ops = tiling.rank_ops(tile, layout, exchange)
+    kern = {n: k for n, _, k in chain.OPS}
+    op_defs = []
+    for name, bpc in tiling.RANK_OPS:
+        k = {"d8": kern["d8"], "downslope": kern["downslope"], "slope_twi": kern["slope_twi"],
+             "flowacc_local": ["k_fa_tile1", "k_fa_reduce", "k_fa_nxt_init", "k_fa_rank_summary"],
+             "flowacc_solve_finish": ["k_rk_fa_*", "k_fa_propagate", "k_fa_poison", "k_fa_tile3"],
+             "flowhand_local": kern["flowhand_local"],
+             "flowhand_gfi_solve_finish": ["k_rk_fh_*", "k_fh_ghost_set", "k_fh_tile3"]}.get(name, [])
+        op_defs.append((name, bpc, k))
+    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in ops]
+          for _ in range(args.steps)]
+    for _, fn in ops:
+        fn()
+    barrier()
+    t1 = time.perf_counter()
+    for k in range(args.steps):
+        for i, (_, fn) in enumerate(ops):
+            ev[k][i][0].record(tile.ts)
+            fn()
+            ev[k][i][1].record(tile.ts)
+    barrier()
+    dt_serial = time.perf_counter() - t1
+    if use_dist:
+        dt_serial = allreduce([dt_serial], dist.ReduceOp.MAX)[0]
+    per_op, roof = per_op_table(ev, op_defs, S * S, -1, args.steps)  # rank 0's own stream and tile
+    roof["note"] += "; N > 1: rank 0's tile, the exchange stages (0 bytes) are the all-gathers' launch and wait"
+
+    verified = None if args.no_verify else verify_tiled(torch, tile, layout, allreduce)
     cells = S * S * world
+    sched = ("downslope as a second branch on its own stream" if args.overlap else "one stream per rank (--no-overlap)")
     out = {
         "metric": "Mcells/s full descriptor chain", "value": round(cells * args.steps / dt / 1e6, 1),
         "unit": "Mcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%dx%d synthetic tilted-integer-fBm DEM per GPU, full chain, device-resident"
-                               % (S, S),
+        "config": {"workload": "%dx%d synthetic tilted-integer-fBm DEM per GPU, full chain (d8, flowacc, river mask, "
+                               "flowhand/HAND with fused GFI + ln(hl/H), fused slope+TI+MTI, downslope), "
+                               "device-resident" % (S, S),
                    "global_dem": "%dx%d" % (layout.Hg, layout.Wg), "px": 10.0,
                    "river_threshold_cells": tile.river_threshold,
+                   "accumulation_dtype": "int64" if tile.acc64 else "int32",
                    "parallelism": "%dx%d rank tiles, 64-cell halo, 2 %s all-gathers of ring summaries per "
-                                  "step (flow accumulation inflow, HAND rank exits)"
-                                  % (layout.ty, layout.tx, "gloo (CPU rehearsal)" if cpu_red else "RCCL")},
-        "roofline": {"bound": "hbm", "achieved": round(cells * args.steps * chain.ALGO_BYTES_PER_CELL / dt / 1e9
-                                                        / world, 1),
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(cells * args.steps * chain.ALGO_BYTES_PER_CELL / dt / 1e9 / world
-                                   / HBM_PEAK_GBS, 4),
-                     "traffic": None, "kernel": "whole chain, per GPU (per-kernel figures: N = 1 run)"},
-        "downslope_walks_beyond_halo": int(unres[0].item()),
-        "accumulation_overflow_ranks": int(unres[1].item()),  # ranks whose int32 accumulation may have reached 2^31
+                                  "step (flow accumulation inflow, HAND rank exits); %s"
+                                  % (layout.ty, layout.tx, "gloo (CPU rehearsal)" if cpu_red else "RCCL", sched)},
+        "ms_per_step_serial": round(dt_serial / args.steps * 1e3, 3),
+        "roofline": roof,
+        "per_op": per_op,
+        "verified": verified,
+        "chain_algo_bytes_per_cell": chain.ALGO_BYTES_PER_CELL,
+        "chain_frac_of_hbm_peak": round(cells * args.steps * chain.ALGO_BYTES_PER_CELL / dt / 1e9 / world
+                                        / HBM_PEAK_GBS, 4),
+        "downslope_walks_beyond_halo": int(unres[0]),
+        "accumulation_overflow_ranks": int(unres[1]),  # ranks whose int32 accumulation may have reached 2^31
         "backend": (dist.get_backend() if use_dist else "none"),
+        "ranks": (dist.get_world_size() if use_dist else 1),
         "distinct_gpus": min(world, torch.cuda.device_count()) if not cpu_red else 1,
     }
+    if rank == 0 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_n)
+    if use_dist:
+        dist.barrier()  # the other ranks wait for rank 0's CPU baseline
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
 
 
-def cpu_baseline(n=4096, seeds=(1, 2, 3)):
+def verify_tiled(torch, tile, layout, allreduce):
+    """the rasters the last step left on this rank: conservation over the GLOBAL raster (every cell drains through
+    exactly one outlet), river mask == fac > threshold, river cells index themselves at distance 0, HAND >= 0 where
+    a river cell was found, one checksum per raster summed over the ranks (for the 1 x 1 layout they are the N = 1
+    run's checksums); raises on a violation"""
+    Hg, Wg = layout.Hg, layout.Wg
+    dev = tile.dev
+    fdr, fac, river, idx, fdist, hand = (tile.core(n) for n in ("fdr", "fac", "river", "idx", "fdist", "hand"))
+    tile.side_ctx.sync()
+    tile.ctx.sync()
+    dy = torch.zeros(256, dtype=torch.int64, device=dev)
+    dx = torch.zeros(256, dtype=torch.int64, device=dev)
+    for code, (a, b) in {1: (0, 1), 2: (1, 1), 4: (1, 0), 8: (1, -1), 16: (0, -1), 32: (-1, -1), 64: (-1, 0),
+                         128: (-1, 1)}.items():
+        dy[code], dx[code] = a, b
+    gy = torch.arange(tile.gy0, tile.gy0 + tile.H, device=dev, dtype=torch.int64).view(-1, 1)
+    gx = torch.arange(tile.gx0, tile.gx0 + tile.W, device=dev, dtype=torch.int64).view(1, -1)
+    f = fdr.long()
+    ty, tx = gy + dy[f], gx + dx[f]
+    outlet = (ty < 0) | (ty >= Hg) | (tx < 0) | (tx >= Wg) | (f == 0)
+    drained = int((fac[outlet].long() + 1).sum())
+    del f, ty, tx, outlet
+    ok = bool(torch.equal(river, (fac > tile.river_threshold).to(torch.int8)))
+    rv = river == 1
+    lin = gy * Wg + gx
+    ok = ok and bool(torch.equal(idx.long()[rv], lin[rv])) and (not bool(rv.any()) or float(fdist[rv].abs().max()) == 0.0)
+    found = idx >= 0
+    ok = ok and bool((hand[found] >= 0).all()) and bool((hand[~found] == -100).all())
+    del rv, lin, found
+    sums = {}
+    for name in ("slope", "fdr", "fac", "river", "fdist", "idx", "hand", "ti", "mti", "gfi", "lnhlh", "down"):
+        t = tile.core(name)
+        if t.dtype == torch.int64:   # value sums: independent of the raster's width
+            sums[name] = int(t.sum())
+        elif t.element_size() == 4:
+            sums[name] = int(t.view(torch.int32).sum(dtype=torch.int64))
+        else:
+            sums[name] = int(t.sum(dtype=torch.int64))
+    names = sorted(sums)
+    tot = allreduce([drained, 0 if ok else 1] + [sums[n] for n in names])
+    if int(tot[0]) != Hg * Wg:
+        raise SystemExit("bench.py: flow accumulation does not conserve cells over the ranks (%d != %d)" % (tot[0], Hg * Wg))
+    if int(tot[1]) != 0:
+        raise SystemExit("bench.py: river mask / river index / HAND consistency violated on %d ranks" % tot[1])
+    return {"cells_drained_through_outlets": int(tot[0]), "river_idx_hand_consistent": True,
+            "checksums": {n: int(v) for n, v in zip(names, tot[2:])}}
+
+
+def end_to_end(n, seed):
+    """What a user of the reference's API sees (SURVEY.md 8d "end-to-end incl. H2D/D2H, reported separately"; never
+    `value`): (a) chain.run_host on an n x n HOST DEM -- one H2D of the DEM, the resident chain, 13 rasters back over
+    PCIe into page-locked memory -- with the split; (b) the reference's call sequence (Example/example.py:59-91) through
+    the drop-in functions, pageable numpy in and out, the dtypes of the reference (float64 / int64 containers);
+    (c) examples/example.py on the bundled rasters (config #1)."""
+    import torch
+    from descriptools_amd import _lib, chain, downslope, flowhand, gfi, slope, topoindexes
+    from descriptools_amd.device import Context
+    L = _lib.lib()
+    px, thr = 10.0, (n * n) // 512
+    ctx = Context()
+    d = ctx.empty((n, n), np.float32)
+    _lib.check(L.dt_dev_synth_dem(ctx.h, seed, n, n, 0, 0, n, n, 0, d.ptr))
+    dem = d.to_host()
+    # (a) split of run_host: H2D, kernels, D2H
+    ch = chain.Chain(n, n, ctx=ctx, px=px, river_threshold=thr, want_slope_rad=False)
+    t0 = time.perf_counter()
+    d.copy_from(dem)
+    t1 = time.perf_counter()
+    ch.run(d.ptr, want_a_river=False)
+    ctx.sync()
+    t2 = time.perf_counter()
+    outs = {k: ch.buf[k].to_host(pinned=True) for k, _ in chain.OUTPUTS if k not in ("a_river", "slope_rad")}
+    t3 = time.perf_counter()
+    nbytes_out = sum(a.nbytes for a in outs.values())
+    fdr, fac = outs["fdr"].copy(), outs["fac"].astype(np.int64)
+    del outs
+    ch.free()
+    d.free()
+    ctx.close()
+    t4 = time.perf_counter()
+    rh = chain.run_host(dem, px, river_threshold=thr, want_slope_rad=False)  # warm pools: the steady-state call
+    t5 = time.perf_counter()
+    del rh
+    # (b) the reference's call sequence through the drop-in API
+    river = (fac > thr).astype(np.int8)
+    t6 = time.perf_counter()
+    sl = slope.sloper(dem, px).astype("float32")
+    slr = np.arctan(sl / 100).astype("float32")
+    slr = np.where(dem == -100, -100, slr)
+    ti, mti = topoindexes.topographic_index(fac, slr, px, 0.1)
+    down = downslope.downsloper(dem, fdr, px, 5)
+    flow, indices, hand = flowhand.flow_hand_index(dem, fdr, river, px)
+    geofi = gfi.gfi_calculator(hand, fac, indices, 0.4, 0.1, px)
+    lnhlh = gfi.ln_hl_H_calculator(hand, fac, 0.4, 0.1, px)
+    t7 = time.perf_counter()
+    del sl, slr, ti, mti, down, flow, indices, hand, geofi, lnhlh, river, fdr, fac, dem
+    from descriptools_amd import device
+    device.trim()
+    torch.cuda.empty_cache()
+    # (c) config #1: the headless example on the bundled rasters
+    ex = None
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "examples"))
+        import contextlib
+        import io
+        import example as ex_mod
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            ex = ex_mod.main()
+    except Exception as e:  # the example's rasters are test fixtures: report, do not fail the bench
+        ex = {"error": repr(e)}
+    cells = n * n
+    return {
+        "size": "%dx%d host DEM" % (n, n),
+        "run_host_split": {"h2d_dem_pageable_ms": round((t1 - t0) * 1e3, 1), "kernels_ms": round((t2 - t1) * 1e3, 1),
+                           "d2h_11_rasters_pinned_ms": round((t3 - t2) * 1e3, 1), "d2h_GBs": round(nbytes_out / (t3 - t2) / 1e9, 1),
+                           "note": "first call of the process: includes locking the host pages of the 11 outputs"},
+        "run_host": {"seconds": round(t5 - t4, 3), "Mcells_s": round(cells / (t5 - t4) / 1e6, 1),
+                     "note": "chain.run_host, numpy DEM in, 13 numpy rasters out (fac / idx widened to int64), warm "
+                             "page-locked pool"},
+        "dropin_api": {"seconds": round(t7 - t6, 3), "Mcells_s": round(cells / (t7 - t6) / 1e6, 1),
+                       "note": "sloper, arctan (host numpy, example.py:63), topographic_index, downsloper, "
+                               "flow_hand_index, gfi_calculator, ln_hl_H_calculator: pageable numpy in / out in the "
+                               "reference's dtypes, one H2D / D2H round trip per call as the reference's *_cpu shims"},
+        "example": ex,
+    }
+
+
+def cpu_baseline(n=3072, seeds=(1,)):
     """the reference's CPU path is its single-threaded `*_sequential_jit` family (Numba is not in
     this image), so the baseline is the oracle -- the same per-cell algorithms restated in C -- built with
-    gcc -O3 -march=native, timed on the whole chain over an n x n DEM of the same generator: median of the three
-    seeds on ONE thread (`value`), and with OpenMP over the per-cell loops on all cores (`all_cores`; the
-    in-degree-countdown flow accumulation stays sequential).  Baseline only."""
+    gcc -O3 -march=native, timed on the whole chain over an n x n DEM of the same generator: ONE thread (`value`),
+    and with OpenMP over the per-cell loops on all cores (`all_cores`, median of three; the in-degree-countdown flow
+    accumulation stays sequential).  A bounded sample (~20 + ~10 s), baseline only."""
     import oracle
     px = 10.0
 
@@ -440,17 +633,18 @@ def cpu_baseline(n=4096, seeds=(1, 2, 3)):
         oracle.use_bench_build(1)
         t1 = sorted(run(s) for s in seeds)
         oracle.use_bench_build(ncpu)
-        tn = sorted(run(s) for s in seeds)
+        tn = sorted(run(s) for s in (1, 2, 3))
     finally:
         oracle.use_bench_build(None)
     med1, medn = t1[len(t1) // 2], tn[len(tn) // 2]
     return {"value": round(n * n / med1 / 1e6, 3), "unit": "Mcells/s", "cores": 1, "kind": "port",
             "all_cores": {"value": round(n * n / medn / 1e6, 3), "unit": "Mcells/s", "cores": ncpu,
                           "nproc": os.cpu_count()},
-            "sample": "full chain on %dx%d DEMs of the same generator, seeds %s, median of %d runs (%.1f s on 1 "
-                      "thread, %.1f s on %d threads); oracle/dt_oracle.c, gcc -O3 -march=native (+ OpenMP over the "
-                      "per-cell loops for all_cores); reference-algorithm restatement, not Numba"
-                      % (n, n, list(seeds), len(seeds), med1, medn, ncpu)}
+            "sample": "full chain on a %dx%d DEM of the same generator (the 16384^2 workload's generator, a bounded "
+                      "sample): seed %s on 1 thread (%.1f s), median of seeds 1-3 on %d threads (%.1f s); "
+                      "oracle/dt_oracle.c, gcc -O3 -march=native (+ OpenMP over the per-cell loops for all_cores); "
+                      "reference-algorithm restatement, not Numba"
+                      % (n, n, list(seeds), med1, ncpu, medn)}
 
 
 if __name__ == "__main__":

@@ -99,6 +99,14 @@ _SIGS = {
     "dt_dev_rank_solve_flowacc": (ci, [vp, ci, ci, c_i64p, c_i64p, i64, vp, i64, c_i64p, ci, i64, vp]),
     "dt_dev_rank_solve_flowhand": (ci, [vp, ci, ci, c_i64p, c_i64p, i64, vp, i64, c_i64p, ci, i64, vp, vp, vp, vp,
                                         vp, vp]),
+    # int64 accumulation rasters (multi-rank rasters of >= 2^31 cells)
+    "dt_dev_flowacc_finish_w_a64": (ci, [vp, vp, vp, vp, vp, i64, vp, vp]),
+    "dt_dev_slope_twi_w_a64": (ci, [vp, vp, vp, vp, f64, f64, vp, vp, vp, vp]),
+    "dt_dev_flowhand_local_w_a64": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "dt_dev_flowhand_finish_w_a64": (ci, [vp, vp, vp, vp, vp, vp, f64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "dt_dev_flowhand_gfi_finish_w_a64": (ci, [vp, vp, vp, vp, vp, vp, f64, f64, f64, vp, vp, vp, vp, vp,
+                                              vp, vp, vp, vp, vp, vp, vp, vp]),
+    "dt_dev_gfi_lnhlh_a64": (ci, [vp, vp, vp, vp, i64, f64, f64, f64, vp, vp]),
     "dt_dev_i32_to_i64": (ci, [vp, vp, i64, vp]),
     "dt_dev_i64_to_i32": (ci, [vp, vp, i64, vp]),
 }

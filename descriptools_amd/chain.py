@@ -40,11 +40,11 @@ class Chain:
     """Owns the output rasters of one H x W tile on one device."""
 
     def __init__(self, H, W, ctx=None, px=10.0, n_top=0.1, n_gfi=0.4, b=0.1, dz=5.0,
-                 river_threshold=None, alloc=None, want_slope_rad=True, side_ctx=None, overlap=False):
-        """overlap: run downslope as a second branch on its own stream (side_ctx, created on demand) beside
-        the flow-accumulation / HAND kernels: ~5 % faster end to end at 16384^2, at the price of per-kernel
-        timings that are no longer attributable (the branch is stretched over the whole step).  Off by
-        default: one stream, kernels back to back."""
+                 river_threshold=None, alloc=None, want_slope_rad=True, side_ctx=None, overlap=True):
+        """overlap (the default): downslope runs as a second branch on its own stream (side_ctx, created on demand)
+        beside the flow-accumulation / HAND kernels, whose latency chains leave most of the GPU idle: ~3-5 % faster
+        end to end at 16384^2.  overlap=False: one stream, kernels back to back (what per-kernel timings need:
+        ops(serial=True) gives that order on a chain built either way)."""
         self.want_slope_rad = want_slope_rad
         self.H, self.W, self.N = int(H), int(W), int(H) * int(W)
         self.ctx = ctx or Context()
@@ -55,6 +55,7 @@ class Chain:
         self.px, self.n_top, self.n_gfi, self.b, self.dz = px, n_top, n_gfi, b, dz
         self.river_threshold = self.N // 512 if river_threshold is None else int(river_threshold)
         self.buf = {}
+        self._graphs = []
         for name, dt in OUTPUTS:
             self.buf[name] = alloc((H, W), dt) if alloc else self.ctx.empty((H, W), dt)
 
@@ -62,17 +63,18 @@ class Chain:
         b = self.buf[name]
         return b.ptr if hasattr(b, "ptr") else b
 
-    def ops(self, dem_ptr, want_a_river=False):
+    def ops(self, dem_ptr, want_a_river=False, serial=False):
         """The step as a list of (name, context, call) in launch order -- THE definition of the chain: run()
         executes it, bench.py times it op by op.  With `overlap` the downslope op belongs to the side context
-        (forked after D8, joined at the end by run())."""
+        (forked after D8, joined at the end by run()); serial=True binds every op to the main context (one
+        stream, back to back), whatever the chain was built with."""
         L, c, H, W = _lib.lib(), self.ctx, self.H, self.W
         p = self.p
-        side = self.side if self.side is not None else c
+        side = self.side if (self.side is not None and not serial) else c
         if getattr(self, "_ring", None) is None:
             P = max(int(L.dt_perim_cells(H, W)), 1)
             self._full = _lib.Window(H, W, W, 0, 0, H, W, 0)
-            self._ring = [c.empty(P, dt) for dt in (np.uint8, np.int32, np.int32, np.int32, np.float32, np.int32)]
+            self._ring = [c.empty(P, dt) for dt in (np.uint8, np.int32, np.int32, np.int32, np.float32, np.int64)]
         full, ring = self._full, [r.ptr for r in self._ring]
         rad = p("slope_rad") if self.want_slope_rad else None
         return [
@@ -107,20 +109,31 @@ class Chain:
         of 45 through ctypes), not time off it: measured 0.213 / 0.324 / 9.05 ms direct against 0.226 / 0.336 /
         8.98 ms replayed at 1024^2 / 2048^2 / 16384^2 -- the asynchronous launches already keep ahead of the GPU,
         and what a small step costs is the ~5 us each dependent kernel takes to start, which a graph of the same
-        kernels keeps.  The DEM pointer and this chain's buffers are baked into the graph."""
+        kernels keeps.  Baked into the graph: the DEM pointer, this chain's buffers AND the context's workspaces
+        (scratch, stencil marks).  The graph keeps the chain and its context alive; it becomes invalid -- launch()
+        raises -- when the chain is freed, or when a later call on the context needs a larger workspace and
+        reallocates it (a bigger raster, conditioning, a rank-level solve): capture again then."""
         self.run(dem_ptr, want_a_river)
         self.ctx.sync()
         L = _lib.lib()
         check(L.dt_ctx_capture_begin(self.ctx.h))
+        g = C.c_void_p()
         try:
             self.run(dem_ptr, want_a_river)
-        finally:
-            g = C.c_void_p()
-            rc = L.dt_ctx_capture_end(self.ctx.h, C.byref(g))
-        check(rc)
-        return Graph(g, self.ctx)
+        except BaseException:
+            # end the capture and drop whatever was recorded: no half-built graph is handed out or leaked
+            if L.dt_ctx_capture_end(self.ctx.h, C.byref(g)) == 0 and g:
+                L.dt_graph_destroy(g)
+            raise
+        check(L.dt_ctx_capture_end(self.ctx.h, C.byref(g)))
+        gr = Graph(g, self.ctx, self)
+        self._graphs.append(gr)
+        return gr
 
     def free(self):
+        for gr in self._graphs:  # their kernels point into the buffers that go away now
+            gr.invalidate("the chain it was captured from has been freed")
+        self._graphs = []
         if self._own_side:
             self.side.close()
             self.side, self._own_side = None, False
@@ -131,18 +144,27 @@ class Chain:
 
 
 class Graph:
-    """A captured step (Chain.capture)."""
+    """A captured step (Chain.capture).  Holds its chain and context (their buffers and workspaces are what the
+    recorded kernels address)."""
 
-    def __init__(self, handle, ctx):
-        self.h, self.ctx = handle, ctx
+    def __init__(self, handle, ctx, chain=None):
+        self.h, self.ctx, self.chain, self._dead = handle, ctx, chain, None
+
+    def invalidate(self, why):
+        self._dead = why
 
     def launch(self):
+        if self._dead:
+            raise RuntimeError("captured step cannot be replayed: " + self._dead)
         check(_lib.lib().dt_graph_launch(self.h, self.ctx.h))
 
     def free(self):
         if self.h:
             check(_lib.lib().dt_graph_destroy(self.h))
             self.h = None
+        if self.chain is not None and self in self.chain._graphs:
+            self.chain._graphs.remove(self)
+        self.chain = None
 
 
 def run_host(dem, px, **kw):

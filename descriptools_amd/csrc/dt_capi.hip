@@ -34,6 +34,16 @@ extern "C" int dt_device_count(void) {
 }
 
 // ---- context ----------------------------------------------------------------------------------
+// live contexts (a graph remembers the context it was captured on and must know whether that still exists)
+static std::mutex g_ctx_mu;
+static std::vector<dt_ctx *> g_live_ctx;
+static bool dt_ctx_alive(dt_ctx *c) {
+  std::lock_guard<std::mutex> lk(g_ctx_mu);
+  for (dt_ctx *p : g_live_ctx)
+    if (p == c) return true;
+  return false;
+}
+
 extern "C" int dt_ctx_create(int device, void *stream, dt_ctx **out) {
   DT_REQUIRE(out != nullptr, "out is NULL");
   int n = dt_device_count();
@@ -55,6 +65,7 @@ extern "C" int dt_ctx_create(int device, void *stream, dt_ctx **out) {
   c->ev = nullptr;
   c->aux = nullptr;
   c->aux_bytes = 0;
+  c->ws_gen = 0;
   c->status = nullptr;
   if (hipMalloc((void **)&c->status, 64) != hipSuccess || hipMemset(c->status, 0, 64) != hipSuccess) {
     dt_set_error("cannot allocate the context's status word");
@@ -73,12 +84,24 @@ extern "C" int dt_ctx_create(int device, void *stream, dt_ctx **out) {
     }
     c->own_stream = true;
   }
+  {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    g_live_ctx.push_back(c);
+  }
   *out = c;
   return DT_OK;
 }
 
 extern "C" int dt_ctx_destroy(dt_ctx *c) {
   if (!c) return DT_OK;
+  {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    for (size_t i = 0; i < g_live_ctx.size(); i++)
+      if (g_live_ctx[i] == c) {
+        g_live_ctx.erase(g_live_ctx.begin() + (long)i);
+        break;
+      }
+  }
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   if (c->scratch) (void)hipFree(c->scratch);
@@ -131,6 +154,8 @@ struct dt_graph {
   hipGraph_t graph;
   hipGraphExec_t exec;
   int device;
+  dt_ctx *owner;       // the context it was captured on: the kernels' workspace pointers are that context's
+  uint64_t owner_gen;  // its workspace generation at capture time
 };
 extern "C" int dt_ctx_capture_begin(dt_ctx *c) {
   DT_REQUIRE(c != nullptr, "ctx is NULL");
@@ -151,12 +176,19 @@ extern "C" int dt_ctx_capture_end(dt_ctx *c, dt_graph **out) {
     (void)hipGraphDestroy(g);
     DT_HIP(err);
   }
-  *out = new dt_graph{g, e, c->device};
+  *out = new dt_graph{g, e, c->device, c, c->ws_gen};
   return DT_OK;
 }
 extern "C" int dt_graph_launch(dt_graph *g, dt_ctx *c) {
   DT_REQUIRE(g != nullptr && c != nullptr, "NULL argument");
   DT_REQUIRE(g->device == c->device, "graph and context on different devices");
+  // The captured kernels hold the raw addresses of the capturing context's grow-only workspaces.  A later call
+  // that needed a larger one (a bigger raster, dt_dev_condition_d8, a rank-level solve) has freed the old block,
+  // and so has destroying that context: replaying would write into freed memory.
+  DT_REQUIRE(dt_ctx_alive(g->owner), "the context this graph was captured on has been destroyed: capture again");
+  DT_REQUIRE(g->owner->ws_gen == g->owner_gen,
+             "a workspace of the capturing context was reallocated after the capture (a call needed more scratch): "
+             "the graph's pointers are stale, capture the step again");
   DT_HIP(hipSetDevice(c->device));
   DT_HIP(hipGraphLaunch(g->exec, c->stream));
   return DT_OK;
@@ -188,6 +220,7 @@ int dt_scratch_reset(dt_ctx *c, size_t total) {
     if (c->scratch) DT_HIP(hipFree(c->scratch));
     c->scratch = nullptr;
     c->scratch_bytes = 0;
+    c->ws_gen++;
     DT_HIP(hipMalloc((void **)&c->scratch, total));
     c->scratch_bytes = total;
   }
@@ -209,6 +242,7 @@ static int dt_side_reserve(dt_ctx *c, char **buf, size_t *have, size_t bytes) {
     if (*buf) DT_HIP(hipFree(*buf));
     *buf = nullptr;
     *have = 0;
+    c->ws_gen++;
     DT_HIP(hipMalloc((void **)buf, bytes));
     *have = bytes;
   }
@@ -264,7 +298,13 @@ extern "C" int dt_dev_malloc(dt_ctx *c, int64_t bytes, void **out) {
   DT_CTX(c);
   DT_REQUIRE(out && bytes >= 0, "bad arguments");
   *out = nullptr;
-  DT_HIP(hipMalloc(out, bytes > 0 ? (size_t)bytes : 16));
+  const size_t n = bytes > 0 ? (size_t)bytes : 16;
+  if (hipMalloc(out, n) != hipSuccess) {
+    (void)hipGetLastError();
+    *out = nullptr;
+    dt_host_trim();  // the host tier's cached device blocks are the only memory this library holds on to
+    DT_HIP(hipMalloc(out, n));
+  }
   return DT_OK;
 }
 extern "C" int dt_dev_free(dt_ctx *c, void *p) {
@@ -298,7 +338,7 @@ extern "C" int dt_dev_slope_twi(dt_ctx *c, const float *dem, const int32_t *acc3
   DT_TRY(dt_check_hw(H, W));
   DT_REQUIRE((dem && acc32 && ti && mti) || H * W == 0, "NULL raster");
   DT_TRY(dt_side_reserve(c, &c->aux, &c->aux_bytes, dt_stencil_aux_bytes(H, W)));
-  DT_TRY(dt_launch_stencil(c->stream, dt_full_window(H, W), dem, px, slope, nullptr, slope_rad, acc32, n_top, ti,
+  DT_TRY(dt_launch_stencil(c->stream, dt_full_window(H, W), dem, px, slope, nullptr, slope_rad, acc32, 0, n_top, ti,
                            mti, c->aux));
   DT_HIP(hipGetLastError());
   return DT_OK;
@@ -331,7 +371,7 @@ extern "C" int dt_dev_slope_d8(dt_ctx *c, const float *dem, int64_t H, int64_t W
   DT_REQUIRE(dem || H * W == 0, "dem is NULL");
   DT_REQUIRE(slope || fdr || slope_rad, "no output requested");
   DT_TRY(dt_side_reserve(c, &c->aux, &c->aux_bytes, dt_stencil_aux_bytes(H, W)));
-  DT_TRY(dt_launch_stencil(c->stream, dt_full_window(H, W), dem, px, slope, fdr, slope_rad, nullptr, 0.0, nullptr,
+  DT_TRY(dt_launch_stencil(c->stream, dt_full_window(H, W), dem, px, slope, fdr, slope_rad, nullptr, 0, 0.0, nullptr,
                            nullptr, c->aux));
   DT_HIP(hipGetLastError());
   return DT_OK;
@@ -374,7 +414,7 @@ extern "C" int dt_dev_flowacc(dt_ctx *c, const uint8_t *fdr, const float *dem, i
     void *scr = dt_scratch_take(c, need);
     DtWin w = dt_full_window(H, W);
     DT_TRY(dt_launch_fa_local(c->stream, w, fdr, scr, need, acc32, 0));
-    DT_TRY(dt_launch_fa_finish(c->stream, w, fdr, dem, scr, nullptr, 0, acc32, nullptr));
+    DT_TRY(dt_launch_fa_finish(c->stream, w, fdr, dem, scr, nullptr, 0, acc32, 0, nullptr));
   }
   DT_HIP(hipGetLastError());
   return DT_OK;
@@ -407,7 +447,7 @@ extern "C" int dt_dev_flowhand(dt_ctx *c, const float *dem, const uint8_t *fdr, 
     void *scr = dt_scratch_take(c, need);
     DtWin w = dt_full_window(H, W);
     DT_TRY(dt_launch_fh_local(c->stream, w, fdr, river, scr, need));
-    DT_TRY(dt_launch_fh_finish(c->stream, w, dem, fdr, river, acc32, px, scr, nullptr, nullptr, nullptr, nullptr,
+    DT_TRY(dt_launch_fh_finish(c->stream, w, dem, fdr, river, acc32, 0, px, scr, nullptr, nullptr, nullptr, nullptr,
                                nullptr, nullptr, fdist, idx32, nullptr, hand, a_river));
   }
   DT_HIP(hipGetLastError());
@@ -428,7 +468,7 @@ extern "C" int dt_dev_flowhand_gfi(dt_ctx *c, const float *dem, const uint8_t *f
   void *scr = dt_scratch_take(c, need);
   DtWin w = dt_full_window(H, W);
   DT_TRY(dt_launch_fh_local(c->stream, w, fdr, river, scr, need));
-  DT_TRY(dt_launch_fh_finish(c->stream, w, dem, fdr, river, acc32, px, scr, nullptr, nullptr, nullptr, nullptr,
+  DT_TRY(dt_launch_fh_finish(c->stream, w, dem, fdr, river, acc32, 0, px, scr, nullptr, nullptr, nullptr, nullptr,
                              nullptr, nullptr, fdist, idx32, nullptr, hand, a_river, gfi, lnhlh, n_gfi, b, px));
   DT_HIP(hipGetLastError());
   return DT_OK;
@@ -461,13 +501,21 @@ extern "C" int dt_dev_lnhlh(dt_ctx *c, const float *hand, const int32_t *acc32, 
   return DT_OK;
 }
 
-extern "C" int dt_dev_gfi_lnhlh(dt_ctx *c, const float *hand, const int32_t *a_river, const int32_t *acc32,
-                                int64_t N, double n_gfi, double b, double size, float *gfi, float *lnhlh) {
+static int dev_gfi_lnhlh(dt_ctx *c, const float *hand, const void *a_river, const void *acc, int acc64, int64_t N,
+                         double n_gfi, double b, double size, float *gfi, float *lnhlh) {
   DT_CTX(c);
-  DT_REQUIRE((hand && a_river && acc32 && gfi && lnhlh) || N == 0, "NULL raster");
-  DT_TRY(dt_launch_gfi_both(c->stream, hand, a_river, acc32, N, n_gfi, b, size, gfi, lnhlh));
+  DT_REQUIRE((hand && a_river && acc && gfi && lnhlh) || N == 0, "NULL raster");
+  DT_TRY(dt_launch_gfi_both(c->stream, hand, a_river, acc, acc64, N, n_gfi, b, size, gfi, lnhlh));
   DT_HIP(hipGetLastError());
   return DT_OK;
+}
+extern "C" int dt_dev_gfi_lnhlh(dt_ctx *c, const float *hand, const int32_t *a_river, const int32_t *acc32,
+                                int64_t N, double n_gfi, double b, double size, float *gfi, float *lnhlh) {
+  return dev_gfi_lnhlh(c, hand, a_river, acc32, 0, N, n_gfi, b, size, gfi, lnhlh);
+}
+extern "C" int dt_dev_gfi_lnhlh_a64(dt_ctx *c, const float *hand, const int64_t *a_river, const int64_t *acc64,
+                                    int64_t N, double n_gfi, double b, double size, float *gfi, float *lnhlh) {
+  return dev_gfi_lnhlh(c, hand, a_river, acc64, 1, N, n_gfi, b, size, gfi, lnhlh);
 }
 
 extern "C" int dt_dev_flowacc_river(dt_ctx *c, const uint8_t *fdr, const float *dem, int64_t H, int64_t W,
@@ -484,7 +532,7 @@ extern "C" int dt_dev_flowacc_river(dt_ctx *c, const uint8_t *fdr, const float *
   void *scr = dt_scratch_take(c, need);
   DtWin w = dt_full_window(H, W);
   DT_TRY(dt_launch_fa_local(c->stream, w, fdr, scr, need, acc32, 0));
-  DT_TRY(dt_launch_fa_finish(c->stream, w, fdr, dem, scr, nullptr, threshold, acc32, river));
+  DT_TRY(dt_launch_fa_finish(c->stream, w, fdr, dem, scr, nullptr, threshold, acc32, 0, river));
   DT_HIP(hipGetLastError());
   return DT_OK;
 }
@@ -586,22 +634,31 @@ extern "C" int dt_dev_slope_d8_w(dt_ctx *c, const dt_window *win, const float *d
   DT_TRY(dt_convert_window(win, &w));
   DT_REQUIRE(dem && (slope || fdr || slope_rad), "NULL raster");
   DT_TRY(dt_side_reserve(c, &c->aux, &c->aux_bytes, dt_stencil_aux_bytes(w.H, w.W)));
-  DT_TRY(dt_launch_stencil(c->stream, w, dem, px, slope, fdr, slope_rad, nullptr, 0.0, nullptr, nullptr, c->aux));
+  DT_TRY(dt_launch_stencil(c->stream, w, dem, px, slope, fdr, slope_rad, nullptr, 0, 0.0, nullptr, nullptr, c->aux));
   DT_HIP(hipGetLastError());
   return DT_OK;
 }
 
-extern "C" int dt_dev_slope_twi_w(dt_ctx *c, const dt_window *win, const float *dem, const int32_t *acc32,
-                                  double px, double n_top, float *slope, float *slope_rad, float *ti,
-                                  float *mti) {
+static int dev_slope_twi_w(dt_ctx *c, const dt_window *win, const float *dem, const void *acc, int acc64, double px,
+                           double n_top, float *slope, float *slope_rad, float *ti, float *mti) {
   DT_CTX(c);
   DtWin w;
   DT_TRY(dt_convert_window(win, &w));
-  DT_REQUIRE(dem && acc32 && ti && mti, "NULL raster");
+  DT_REQUIRE(dem && acc && ti && mti, "NULL raster");
   DT_TRY(dt_side_reserve(c, &c->aux, &c->aux_bytes, dt_stencil_aux_bytes(w.H, w.W)));
-  DT_TRY(dt_launch_stencil(c->stream, w, dem, px, slope, nullptr, slope_rad, acc32, n_top, ti, mti, c->aux));
+  DT_TRY(dt_launch_stencil(c->stream, w, dem, px, slope, nullptr, slope_rad, acc, acc64, n_top, ti, mti, c->aux));
   DT_HIP(hipGetLastError());
   return DT_OK;
+}
+extern "C" int dt_dev_slope_twi_w(dt_ctx *c, const dt_window *win, const float *dem, const int32_t *acc32,
+                                  double px, double n_top, float *slope, float *slope_rad, float *ti,
+                                  float *mti) {
+  return dev_slope_twi_w(c, win, dem, acc32, 0, px, n_top, slope, slope_rad, ti, mti);
+}
+extern "C" int dt_dev_slope_twi_w_a64(dt_ctx *c, const dt_window *win, const float *dem, const int64_t *acc64,
+                                      double px, double n_top, float *slope, float *slope_rad, float *ti,
+                                      float *mti) {
+  return dev_slope_twi_w(c, win, dem, acc64, 1, px, n_top, slope, slope_rad, ti, mti);
 }
 
 extern "C" int dt_dev_downslope_w(dt_ctx *c, const dt_window *win, const float *dem, const uint8_t *fdr,
@@ -621,7 +678,7 @@ extern "C" int dt_dev_flowacc_local_w(dt_ctx *c, const dt_window *win, const uin
   DT_CTX(c);
   DtWin w;
   DT_TRY(dt_convert_window(win, &w));
-  DT_REQUIRE(fdr && acc32 && A_perim && xr_perim && code_perim, "NULL pointer");
+  DT_REQUIRE(fdr && A_perim && xr_perim && code_perim, "NULL pointer");  // acc32 is not touched by phase 1
   size_t need = dt_flowacc_tiled_scratch(w.H, w.W);
   DT_TRY(dt_scratch_reset(c, need));
   void *scr = dt_scratch_take(c, need);
@@ -635,25 +692,34 @@ extern "C" int dt_dev_flowacc_local_w(dt_ctx *c, const dt_window *win, const uin
 }
 
 // must follow dt_dev_flowacc_local_w on the same context with no other scratch-using call in between
-extern "C" int dt_dev_flowacc_finish_w(dt_ctx *c, const dt_window *win, const uint8_t *fdr, const float *dem,
-                                       const uint64_t *ext_perim, int64_t threshold, int32_t *acc32,
-                                       int8_t *river) {
+static int dev_flowacc_finish_w(dt_ctx *c, const dt_window *win, const uint8_t *fdr, const float *dem,
+                                const uint64_t *ext_perim, int64_t threshold, void *acc, int acc64, int8_t *river) {
   DT_CTX(c);
   DtWin w;
   DT_TRY(dt_convert_window(win, &w));
-  DT_REQUIRE(fdr && acc32, "NULL raster");
+  DT_REQUIRE(fdr && acc, "NULL raster");
   DT_REQUIRE(c->scratch && c->scratch_owner == 1 && c->owner_h == w.H && c->owner_w == w.W,
              "dt_dev_flowacc_finish_w without a matching dt_dev_flowacc_local_w on this context (another call has "
              "used the context's scratch in between)");
   DT_TRY(dt_launch_fa_finish(c->stream, w, fdr, dem, c->scratch, (const unsigned long long *)ext_perim, threshold,
-                             acc32, river, c->status));
+                             acc, acc64, river, c->status));
   DT_HIP(hipGetLastError());
   return DT_OK;
 }
+extern "C" int dt_dev_flowacc_finish_w(dt_ctx *c, const dt_window *win, const uint8_t *fdr, const float *dem,
+                                       const uint64_t *ext_perim, int64_t threshold, int32_t *acc32,
+                                       int8_t *river) {
+  return dev_flowacc_finish_w(c, win, fdr, dem, ext_perim, threshold, acc32, 0, river);
+}
+extern "C" int dt_dev_flowacc_finish_w_a64(dt_ctx *c, const dt_window *win, const uint8_t *fdr, const float *dem,
+                                           const uint64_t *ext_perim, int64_t threshold, int64_t *acc64,
+                                           int8_t *river) {
+  return dev_flowacc_finish_w(c, win, fdr, dem, ext_perim, threshold, acc64, 1, river);
+}
 
-extern "C" int dt_dev_flowhand_local_w(dt_ctx *c, const dt_window *win, const float *dem, const uint8_t *fdr,
-                                       const int8_t *river, const int32_t *acc32, uint8_t *kind, int32_t *ref,
-                                       int32_t *nc, int32_t *nd, float *zr, int32_t *ar) {
+static int dev_flowhand_local_w(dt_ctx *c, const dt_window *win, const float *dem, const uint8_t *fdr,
+                                const int8_t *river, const void *acc, int acc64, uint8_t *kind, int32_t *ref,
+                                int32_t *nc, int32_t *nd, float *zr, int64_t *ar) {
   DT_CTX(c);
   DtWin w;
   DT_TRY(dt_convert_window(win, &w));
@@ -662,58 +728,86 @@ extern "C" int dt_dev_flowhand_local_w(dt_ctx *c, const dt_window *win, const fl
   DT_TRY(dt_scratch_reset(c, need));
   void *scr = dt_scratch_take(c, need);
   DT_TRY(dt_launch_fh_local(c->stream, w, fdr, river, scr, need));
-  DT_TRY(dt_launch_fh_summary(c->stream, w, scr, dem, acc32, kind, ref, nc, nd, zr, ar));
+  DT_TRY(dt_launch_fh_summary(c->stream, w, scr, dem, acc, acc64, kind, ref, nc, nd, zr, (long long *)ar));
   DT_HIP(hipGetLastError());
   c->scratch_owner = 2;
   c->owner_h = w.H;
   c->owner_w = w.W;
   return DT_OK;
 }
+extern "C" int dt_dev_flowhand_local_w(dt_ctx *c, const dt_window *win, const float *dem, const uint8_t *fdr,
+                                       const int8_t *river, const int32_t *acc32, uint8_t *kind, int32_t *ref,
+                                       int32_t *nc, int32_t *nd, float *zr, int64_t *ar) {
+  return dev_flowhand_local_w(c, win, dem, fdr, river, acc32, 0, kind, ref, nc, nd, zr, ar);
+}
+extern "C" int dt_dev_flowhand_local_w_a64(dt_ctx *c, const dt_window *win, const float *dem, const uint8_t *fdr,
+                                           const int8_t *river, const int64_t *acc64, uint8_t *kind, int32_t *ref,
+                                           int32_t *nc, int32_t *nd, float *zr, int64_t *ar) {
+  return dev_flowhand_local_w(c, win, dem, fdr, river, acc64, 1, kind, ref, nc, nd, zr, ar);
+}
 
-// must follow dt_dev_flowhand_local_w on the same context with no other scratch-using call in between
-extern "C" int dt_dev_flowhand_finish_w(dt_ctx *c, const dt_window *win, const float *dem, const uint8_t *fdr,
-                                        const int8_t *river, const int32_t *acc32, double px,
-                                        const uint8_t *res_ok, const int32_t *res_nc, const int32_t *res_nd,
-                                        const int64_t *rem_gidx, const float *rem_zr, const int32_t *rem_ar,
-                                        float *fdist, int32_t *idx32, int64_t *idx64, float *hand,
-                                        int32_t *a_river) {
+// must follow dt_dev_flowhand_local_w on the same context with no other scratch-using call in between; `fused`: with
+// the GFI / ln(hl/H) epilogue (see dt_dev_flowhand_gfi)
+static int dev_flowhand_finish_w(dt_ctx *c, const dt_window *win, const float *dem, const uint8_t *fdr,
+                                 const int8_t *river, const void *acc, int acc64, double px, double n_gfi, double b,
+                                 const uint8_t *res_ok, const int32_t *res_nc, const int32_t *res_nd,
+                                 const int64_t *rem_gidx, const float *rem_zr, const int64_t *rem_ar, float *fdist,
+                                 int32_t *idx32, int64_t *idx64, float *hand, void *a_river, float *gfi,
+                                 float *lnhlh, bool fused) {
   DT_CTX(c);
   DtWin w;
   DT_TRY(dt_convert_window(win, &w));
   DT_REQUIRE(fdr && river, "NULL raster");
   DT_REQUIRE(!hand || dem, "hand needs dem");
-  DT_REQUIRE(!a_river || acc32, "a_river needs acc32");
+  DT_REQUIRE(!a_river || acc, "a_river needs the accumulation raster");
+  DT_REQUIRE(!fused || (dem && acc && gfi && lnhlh), "NULL raster");
   DT_REQUIRE(!res_ok || (res_nc && res_nd && rem_gidx && rem_zr && rem_ar), "incomplete rank-exit results");
   DT_REQUIRE(c->scratch && c->scratch_owner == 2 && c->owner_h == w.H && c->owner_w == w.W,
              "flowhand finish without a matching dt_dev_flowhand_local_w on this context (another call has used the "
              "context's scratch in between)");
-  DT_TRY(dt_launch_fh_finish(c->stream, w, dem, fdr, river, acc32, px, c->scratch, res_ok, res_nc, res_nd,
-                             (const long long *)rem_gidx, rem_zr, rem_ar, fdist, idx32, (long long *)idx64, hand,
-                             a_river));
+  DT_TRY(dt_launch_fh_finish(c->stream, w, dem, fdr, river, acc, acc64, px, c->scratch, res_ok, res_nc, res_nd,
+                             (const long long *)rem_gidx, rem_zr, (const long long *)rem_ar, fdist, idx32,
+                             (long long *)idx64, hand, a_river, fused ? gfi : nullptr, fused ? lnhlh : nullptr, n_gfi, b,
+                             px));
   DT_HIP(hipGetLastError());
   return DT_OK;
 }
-
-// dt_dev_flowhand_finish_w with the fused GFI / ln(hl/H) epilogue (see dt_dev_flowhand_gfi)
+extern "C" int dt_dev_flowhand_finish_w(dt_ctx *c, const dt_window *win, const float *dem, const uint8_t *fdr,
+                                        const int8_t *river, const int32_t *acc32, double px,
+                                        const uint8_t *res_ok, const int32_t *res_nc, const int32_t *res_nd,
+                                        const int64_t *rem_gidx, const float *rem_zr, const int64_t *rem_ar,
+                                        float *fdist, int32_t *idx32, int64_t *idx64, float *hand,
+                                        int32_t *a_river) {
+  return dev_flowhand_finish_w(c, win, dem, fdr, river, acc32, 0, px, 0.0, 1.0, res_ok, res_nc, res_nd, rem_gidx, rem_zr,
+                               rem_ar, fdist, idx32, idx64, hand, a_river, nullptr, nullptr, false);
+}
+extern "C" int dt_dev_flowhand_finish_w_a64(dt_ctx *c, const dt_window *win, const float *dem, const uint8_t *fdr,
+                                            const int8_t *river, const int64_t *acc64, double px,
+                                            const uint8_t *res_ok, const int32_t *res_nc, const int32_t *res_nd,
+                                            const int64_t *rem_gidx, const float *rem_zr, const int64_t *rem_ar,
+                                            float *fdist, int32_t *idx32, int64_t *idx64, float *hand,
+                                            int64_t *a_river64) {
+  return dev_flowhand_finish_w(c, win, dem, fdr, river, acc64, 1, px, 0.0, 1.0, res_ok, res_nc, res_nd, rem_gidx, rem_zr,
+                               rem_ar, fdist, idx32, idx64, hand, a_river64, nullptr, nullptr, false);
+}
 extern "C" int dt_dev_flowhand_gfi_finish_w(dt_ctx *c, const dt_window *win, const float *dem, const uint8_t *fdr,
                                             const int8_t *river, const int32_t *acc32, double px, double n_gfi,
                                             double b, const uint8_t *res_ok, const int32_t *res_nc,
                                             const int32_t *res_nd, const int64_t *rem_gidx, const float *rem_zr,
-                                            const int32_t *rem_ar, float *fdist, int32_t *idx32, int64_t *idx64,
+                                            const int64_t *rem_ar, float *fdist, int32_t *idx32, int64_t *idx64,
                                             float *hand, int32_t *a_river, float *gfi, float *lnhlh) {
-  DT_CTX(c);
-  DtWin w;
-  DT_TRY(dt_convert_window(win, &w));
-  DT_REQUIRE(dem && fdr && river && acc32 && gfi && lnhlh, "NULL raster");
-  DT_REQUIRE(!res_ok || (res_nc && res_nd && rem_gidx && rem_zr && rem_ar), "incomplete rank-exit results");
-  DT_REQUIRE(c->scratch && c->scratch_owner == 2 && c->owner_h == w.H && c->owner_w == w.W,
-             "flowhand finish without a matching dt_dev_flowhand_local_w on this context (another call has used the "
-             "context's scratch in between)");
-  DT_TRY(dt_launch_fh_finish(c->stream, w, dem, fdr, river, acc32, px, c->scratch, res_ok, res_nc, res_nd,
-                             (const long long *)rem_gidx, rem_zr, rem_ar, fdist, idx32, (long long *)idx64, hand,
-                             a_river, gfi, lnhlh, n_gfi, b, px));
-  DT_HIP(hipGetLastError());
-  return DT_OK;
+  return dev_flowhand_finish_w(c, win, dem, fdr, river, acc32, 0, px, n_gfi, b, res_ok, res_nc, res_nd, rem_gidx, rem_zr,
+                               rem_ar, fdist, idx32, idx64, hand, a_river, gfi, lnhlh, true);
+}
+extern "C" int dt_dev_flowhand_gfi_finish_w_a64(dt_ctx *c, const dt_window *win, const float *dem,
+                                                const uint8_t *fdr, const int8_t *river, const int64_t *acc64,
+                                                double px, double n_gfi, double b, const uint8_t *res_ok,
+                                                const int32_t *res_nc, const int32_t *res_nd,
+                                                const int64_t *rem_gidx, const float *rem_zr, const int64_t *rem_ar,
+                                                float *fdist, int32_t *idx32, int64_t *idx64, float *hand,
+                                                int64_t *a_river64, float *gfi, float *lnhlh) {
+  return dev_flowhand_finish_w(c, win, dem, fdr, river, acc64, 1, px, n_gfi, b, res_ok, res_nc, res_nd, rem_gidx, rem_zr,
+                               rem_ar, fdist, idx32, idx64, hand, a_river64, gfi, lnhlh, true);
 }
 
 static int dt_scratch2_reserve(dt_ctx *c, size_t bytes) {
@@ -738,7 +832,7 @@ extern "C" int dt_dev_rank_solve_flowhand(dt_ctx *c, int ty, int tx, const int64
                                           int64_t Pmax, const void *rows_dev, int64_t rowbytes,
                                           const int64_t *field_offsets7, int rank, int64_t P_rank,
                                           uint8_t *res_ok, int32_t *res_nc, int32_t *res_nd, int64_t *rem_gidx,
-                                          float *rem_zr, int32_t *rem_ar) {
+                                          float *rem_zr, int64_t *rem_ar) {
   DT_CTX(c);
   DT_REQUIRE(heights && widths && rows_dev && field_offsets7 && res_ok && res_nc && res_nd && rem_gidx && rem_zr &&
                  rem_ar, "NULL pointer");
@@ -746,7 +840,7 @@ extern "C" int dt_dev_rank_solve_flowhand(dt_ctx *c, int ty, int tx, const int64
   DT_TRY(dt_scratch2_reserve(c, dt_rank_solve_scratch(ty * tx, Pmax)));
   DT_TRY(dt_launch_rank_solve_flowhand(c->stream, ty, tx, heights, widths, Pmax, rows_dev, rowbytes,
                                        field_offsets7, rank, P_rank, c->scratch2, res_ok, res_nc, res_nd,
-                                       (long long *)rem_gidx, rem_zr, rem_ar));
+                                       (long long *)rem_gidx, rem_zr, (long long *)rem_ar));
   DT_HIP(hipGetLastError());
   return DT_OK;
 }
@@ -801,9 +895,36 @@ static void *host_block_take(size_t bytes) {
   g_blocks.push_back(HostBlock{p, bytes, true});
   return p;
 }
+// idle blocks kept beyond this many bytes are freed on release (DT_HOST_CACHE_MB, default 4096; 0 = keep nothing)
+static size_t host_cache_budget() {
+  static long long mb = -1;
+  if (mb < 0) {
+    const char *e = getenv("DT_HOST_CACHE_MB");
+    mb = e ? atoll(e) : 4096;
+    if (mb < 0) mb = 0;
+  }
+  return (size_t)mb << 20;
+}
+static void host_blocks_drop_idle(size_t keep_bytes) {
+  // largest idle blocks go first; the host tier's stream is idle whenever a block is released (every dt_<op> ends
+  // with a synchronisation before its DevBufs go out of scope)
+  for (;;) {
+    size_t idle = 0;
+    int big = -1;
+    for (size_t i = 0; i < g_blocks.size(); i++)
+      if (!g_blocks[i].busy) {
+        idle += g_blocks[i].bytes;
+        if (big < 0 || g_blocks[i].bytes > g_blocks[(size_t)big].bytes) big = (int)i;
+      }
+    if (idle <= keep_bytes || big < 0) return;
+    (void)hipFree(g_blocks[(size_t)big].p);
+    g_blocks.erase(g_blocks.begin() + big);
+  }
+}
 static void host_block_release(void *p) {
   for (auto &b : g_blocks)
     if (b.p == p) b.busy = false;
+  host_blocks_drop_idle(host_cache_budget());
 }
 // RAII device buffer of the host tier
 struct DevBuf {

@@ -37,7 +37,8 @@ void dt_set_error(const char *fmt, ...);
   } while (0)
 
 // ---- test / experiment knobs (dt_debug_set in the C ABI; all 0 by default) -------------------------
-enum { DT_DBG_TWI_FLAG_ALL = 0, DT_DBG_TWI_PLAIN = 1, DT_DBG_COUNT = 8 };
+enum { DT_DBG_TWI_FLAG_ALL = 0, DT_DBG_TWI_PLAIN = 1, DT_DBG_TWI_WX = 2, DT_DBG_COUNT = 8 };
+#define DT_TWI_WX_DEFAULT 1 /* tile geometry of the fused slope + TI + MTI stencil: see k_slope_twi */
 int dt_debug_get(int key);
 
 // ---- context ------------------------------------------------------------------------------
@@ -56,6 +57,8 @@ struct dt_ctx {
   int *status;          // device word of sticky DT_STATUS_* bits raised by kernels (dt_ctx_status reads and clears)
   char *aux;            // workspace of the fused slope + TI + MTI stencil (it runs between the two phases of
   size_t aux_bytes;     // the tile kernels in a multi-GPU step, so it must not touch `scratch`)
+  uint64_t ws_gen;      // bumped whenever scratch / scratch2 / aux is reallocated or freed: a captured graph holds
+                        // their raw addresses and must not be replayed across such a change (dt_graph_launch checks)
 };
 
 // grow-only scratch, bump-allocated per entry point (256-B aligned)

@@ -226,21 +226,29 @@ __global__ __launch_bounds__(256) void k_flat_assign(const float *__restrict__ w
 size_t dt_hydro_scratch(int64_t H, int64_t W) { return 256 + dt_align256((size_t)H * W * 4); }
 
 // iterate `round` (a launch of one relaxation round over all tiles) until a whole batch changes nothing
+// Termination: both relaxations are monotone (values only decrease) and every round contains at least one sweep over
+// ALL cells against the previous round's values, so after k rounds every cell whose controlling path (spill path /
+// shortest same-height path to a coded cell) has <= k cells is final -- the Bellman-Ford argument.  A controlling path
+// has at most H * W cells: `max_rounds` = H * W + 8 is a true bound, never a tuning knob.  (A tile relaxes to its
+// LOCAL fixed point each round, so in practice information moves a tile per round; but a path may cross tile borders
+// far more often than there are tiles -- a serpentine channel with 1-cell walls crosses a 64-cell border 32 times --
+// so the number of tiles bounds nothing.)
 template <typename F>
-static int hy_iterate(hipStream_t s, int *flag, int max_rounds, F round, int *rounds_out) {
-  int rounds = 0;
+static int hy_iterate(hipStream_t s, int *flag, int64_t max_rounds, F round, int *rounds_out) {
+  int64_t rounds = 0;
+  int batch = 4;
   for (;;) {
     DT_HIP(hipMemsetAsync(flag, 0, sizeof(int), s));
-    for (int b = 0; b < 4; b++) round();
-    rounds += 4;
+    for (int b = 0; b < batch; b++) round();
+    rounds += batch;
     int h = 0;
     DT_HIP(hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, s));
     DT_HIP(hipStreamSynchronize(s));
     if (!h) break;
-    // information crosses at least one tile per round: no raster needs more rounds than it has tiles
-    DT_REQUIRE(rounds < max_rounds, "conditioning does not converge");
+    DT_REQUIRE(rounds < max_rounds, "conditioning exceeded its proven bound of H * W rounds (a defect, not a property of the DEM)");
+    if (batch < 64) batch *= 2;  // long-winded rasters: fewer host round trips per round
   }
-  if (rounds_out) *rounds_out = rounds;
+  if (rounds_out) *rounds_out = (int)(rounds > 0x7FFFFFFF ? 0x7FFFFFFF : rounds);
   return DT_OK;
 }
 
@@ -256,13 +264,13 @@ int dt_launch_condition(hipStream_t s, const float *dem, int64_t H, int64_t W, d
   dim3 gc((unsigned)((n + 255) / 256)), gt((unsigned)(tiles_x * tiles_y)), b(256);
   hipLaunchKernelGGL(k_fill_init, gc, b, 0, s, dem, (int)H, (int)W, filled);
   int r1 = 0, r2 = 0;
-  const int max_rounds = 4 * tiles_x * tiles_y + 64;
+  const int64_t max_rounds = n + 8;
   DT_TRY(hy_iterate(s, flag, max_rounds, [&] { hipLaunchKernelGGL(k_fill_relax, gt, b, 0, s, dem, filled, (int)H, (int)W, tiles_x, flag); },
                     &r1));
   if (fdr) {
     DtWin w;
     w.H = (int)H; w.W = (int)W; w.ld = W; w.gy0 = 0; w.gx0 = 0; w.Hg = (int)H; w.Wg = (int)W; w.halo = 0;
-    DT_TRY(dt_launch_stencil(s, w, filled, px, nullptr, fdr, nullptr, nullptr, 0.0, nullptr, nullptr));
+    DT_TRY(dt_launch_stencil(s, w, filled, px, nullptr, fdr, nullptr, nullptr, 0, 0.0, nullptr, nullptr));
     hipLaunchKernelGGL(k_flat_init, gc, b, 0, s, filled, fdr, (int)H, (int)W, dist);
     DT_TRY(hy_iterate(s, flag, max_rounds, [&] { hipLaunchKernelGGL(k_flat_relax, gt, b, 0, s, filled, dist, (int)H, (int)W, tiles_x, flag); },
                       &r2));

@@ -5,7 +5,7 @@
 int dt_launch_synth_dem(hipStream_t s, uint32_t seed, int O, int64_t Hg, int64_t y0, int64_t x0,
                         int64_t h, int64_t w, int nodata_pct, float *out);
 int dt_launch_stencil(hipStream_t s, const DtWin &w, const float *dem, double px, float *slope,
-                      uint8_t *fdr, float *slope_rad, const int32_t *acc32, double n_top, float *ti,
+                      uint8_t *fdr, float *slope_rad, const void *acc, int acc64, double n_top, float *ti,
                       float *mti, void *aux = nullptr);
 // workspace (tile marks + lane masks) of the fused slope + TI + MTI launch; see dt_stencil.hip
 size_t dt_stencil_aux_bytes(int64_t H, int64_t W);
@@ -44,20 +44,20 @@ int dt_launch_fa_local(hipStream_t s, const DtWin &w, const uint8_t *fdr, void *
                        int32_t *acc32, int rank_level);
 int dt_launch_fa_summary(hipStream_t s, const DtWin &w, void *scratch, int64_t *A, int32_t *xr, uint8_t *code);
 int dt_launch_fa_finish(hipStream_t s, const DtWin &w, const uint8_t *fdr, const float *dem, void *scratch,
-                        const unsigned long long *ext_perim, int64_t river_thr, int32_t *acc32,
+                        const unsigned long long *ext_perim, int64_t river_thr, void *acc, int acc64,
                         int8_t *river, int *status = nullptr);
 size_t dt_flowhand_tiled_scratch(int64_t H, int64_t W);
 int dt_launch_fh_local(hipStream_t s, const DtWin &w, const uint8_t *fdr, const int8_t *river, void *scratch,
                        size_t scratch_bytes);
-int dt_launch_fh_summary(hipStream_t s, const DtWin &w, void *scratch, const float *dem, const int32_t *acc32,
-                         uint8_t *kind, int32_t *ref, int32_t *nc, int32_t *nd, float *zr, int32_t *ar);
+int dt_launch_fh_summary(hipStream_t s, const DtWin &w, void *scratch, const float *dem, const void *acc, int acc64,
+                         uint8_t *kind, int32_t *ref, int32_t *nc, int32_t *nd, float *zr, long long *ar);
 int dt_launch_fh_finish(hipStream_t s, const DtWin &w, const float *dem, const uint8_t *fdr,
-                        const int8_t *river, const int32_t *acc32, double px, void *scratch,
+                        const int8_t *river, const void *acc, int acc64, double px, void *scratch,
                         const uint8_t *res_ok, const int32_t *res_nc, const int32_t *res_nd,
-                        const long long *rem_gidx, const float *rem_zr, const int32_t *rem_ar, float *fdist,
-                        int32_t *idx32, long long *idx64, float *hand, int32_t *a_river, float *gfi = nullptr,
+                        const long long *rem_gidx, const float *rem_zr, const long long *rem_ar, float *fdist,
+                        int32_t *idx32, long long *idx64, float *hand, void *a_river, float *gfi = nullptr,
                         float *lnhlh = nullptr, double n_gfi = 0.0, double b_gfi = 1.0, double size = 1.0);
-int dt_launch_gfi_both(hipStream_t s, const float *hand, const int32_t *a_river, const int32_t *fac,
+int dt_launch_gfi_both(hipStream_t s, const float *hand, const void *a_river, const void *fac, int acc64,
                        int64_t n, double expo, double b, double size, float *gfi, float *lnhlh);
 int dt_launch_unique_extremes(hipStream_t s, const float *x, int64_t n, uint32_t *work4, float *out3);
 int dt_launch_minmax_scale(hipStream_t s, const float *x, int64_t n, float mn, float mx, float nodata,
@@ -83,7 +83,7 @@ int dt_launch_rank_solve_flowacc(hipStream_t s, int ty, int tx, const int64_t *h
 int dt_launch_rank_solve_flowhand(hipStream_t s, int ty, int tx, const int64_t *heights, const int64_t *widths,
                                   int64_t Pmax, const void *rows, int64_t rowbytes, const int64_t *offs, int rank,
                                   int64_t P_rank, void *scratch, uint8_t *res_ok, int32_t *res_nc,
-                                  int32_t *res_nd, long long *gidx, float *zr, int32_t *ar);
+                                  int32_t *res_nd, long long *gidx, float *zr, long long *ar);
 
 // hydrological conditioning (dt_hydro.hip): depression filling + flat resolution; synchronous
 size_t dt_hydro_scratch(int64_t H, int64_t W);

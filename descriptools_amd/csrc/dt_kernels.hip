@@ -368,9 +368,22 @@ __global__ __launch_bounds__(256) void k_gfi(const float *__restrict__ hand,
   out[i] = (float)(c0 + expo * la - dt_log_sel((double)h + 0.01, s_tab));
 }
 // 4 cells per thread with 16-byte loads / stores, grid-stride (the table is staged once per workgroup)
+template <typename AccT>
+__device__ __forceinline__ void gfi_load4(const AccT *p, AccT (&v)[4]);
+template <>
+__device__ __forceinline__ void gfi_load4<int32_t>(const int32_t *p, int32_t (&v)[4]) {
+  const int4 q = *reinterpret_cast<const int4 *>(p);
+  v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+}
+template <>
+__device__ __forceinline__ void gfi_load4<long long>(const long long *p, long long (&v)[4]) {
+  const longlong2 a = *reinterpret_cast<const longlong2 *>(p), b = *reinterpret_cast<const longlong2 *>(p + 2);
+  v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+}
+template <typename AccT>
 __global__ __launch_bounds__(256) void k_gfi_both(const float *__restrict__ hand,
-                                                 const int32_t *__restrict__ a_river,
-                                                 const int32_t *__restrict__ fac, int64_t n, double expo,
+                                                 const AccT *__restrict__ a_river,
+                                                 const AccT *__restrict__ fac, int64_t n, double expo,
                                                  double c0, float *__restrict__ gfi,
                                                  float *__restrict__ lnhlh,
                                                  const DtLogEntry *__restrict__ g_tab, int vec_ok) {
@@ -381,13 +394,14 @@ __global__ __launch_bounds__(256) void k_gfi_both(const float *__restrict__ hand
   for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
     if (vec_ok && i + 3 < n) {
       float4 h = *reinterpret_cast<const float4 *>(hand + i);
-      int4 ar = *reinterpret_cast<const int4 *>(a_river + i);
-      int4 f = *reinterpret_cast<const int4 *>(fac + i);
+      AccT ar[4], f[4];
+      gfi_load4<AccT>(a_river + i, ar);
+      gfi_load4<AccT>(fac + i, f);
       float4 g, l;
-      dt_gfi_both_cell(h.x, ar.x, f.x, expo, c0, s_tab, g.x, l.x);
-      dt_gfi_both_cell(h.y, ar.y, f.y, expo, c0, s_tab, g.y, l.y);
-      dt_gfi_both_cell(h.z, ar.z, f.z, expo, c0, s_tab, g.z, l.z);
-      dt_gfi_both_cell(h.w, ar.w, f.w, expo, c0, s_tab, g.w, l.w);
+      dt_gfi_both_cell(h.x, ar[0], f[0], expo, c0, s_tab, g.x, l.x);
+      dt_gfi_both_cell(h.y, ar[1], f[1], expo, c0, s_tab, g.y, l.y);
+      dt_gfi_both_cell(h.z, ar[2], f[2], expo, c0, s_tab, g.z, l.z);
+      dt_gfi_both_cell(h.w, ar[3], f[3], expo, c0, s_tab, g.w, l.w);
       *reinterpret_cast<float4 *>(gfi + i) = g;
       *reinterpret_cast<float4 *>(lnhlh + i) = l;
     } else {
@@ -400,14 +414,20 @@ __global__ __launch_bounds__(256) void k_gfi_both(const float *__restrict__ hand
     }
   }
 }
-int dt_launch_gfi_both(hipStream_t s, const float *hand, const int32_t *a_river, const int32_t *fac,
+// a_river / fac: int32_t* rasters, or int64_t* with acc64 != 0
+int dt_launch_gfi_both(hipStream_t s, const float *hand, const void *a_river, const void *fac, int acc64,
                        int64_t n, double expo, double b, double size, float *gfi, float *lnhlh) {
   if (n == 0) return DT_OK;
   int vec_ok = (((uintptr_t)hand | (uintptr_t)a_river | (uintptr_t)fac | (uintptr_t)gfi | (uintptr_t)lnhlh) & 15) == 0;
   int64_t blocks = (n + 1023) / 1024;
   if (blocks > 256 * 16) blocks = 256 * 16;
-  hipLaunchKernelGGL(k_gfi_both, dim3((unsigned)blocks), dim3(256), 0, s, hand, a_river, fac, n, expo,
-                     log(b) + expo * log(size * size), gfi, lnhlh, dt_math_device_table(s), vec_ok);
+  const double c0 = log(b) + expo * log(size * size);
+  if (acc64)
+    hipLaunchKernelGGL(k_gfi_both<long long>, dim3((unsigned)blocks), dim3(256), 0, s, hand, (const long long *)a_river,
+                       (const long long *)fac, n, expo, c0, gfi, lnhlh, dt_math_device_table(s), vec_ok);
+  else
+    hipLaunchKernelGGL(k_gfi_both<int32_t>, dim3((unsigned)blocks), dim3(256), 0, s, hand, (const int32_t *)a_river,
+                       (const int32_t *)fac, n, expo, c0, gfi, lnhlh, dt_math_device_table(s), vec_ok);
   return DT_OK;
 }
 

@@ -178,7 +178,8 @@ __device__ __forceinline__ double dt_log_sel(double x, const DtLogEntry *s_tab) 
 // The indices cross zero inside ordinary terrain (8 % of the cells of the benchmark DEM lie within 0.25 of a
 // zero), where a relative tolerance needs float64 logarithms: all three are the table logarithm above on exact
 // integer -> float64 conversions of the areas; no fast / slow split, no divergence.
-__device__ __forceinline__ void dt_gfi_both_cell(float h, int32_t ar, int32_t f, double expo, double c0,
+template <typename IT>  // int32_t or long long areas: both convert to float64 exactly (< 2^53)
+__device__ __forceinline__ void dt_gfi_both_cell(float h, IT ar, IT f, double expo, double c0,
                                                  const DtLogEntry *s_tab, float &g_out, float &l_out) {
   const double lh = c0 - dt_log_sel((double)h + 0.01, s_tab);
   const double g = lh + expo * dt_log_sel((double)ar, s_tab);

@@ -133,6 +133,7 @@ __device__ __forceinline__ void sd_tile_origin(int b, int tiles_x, int tiles_y, 
 // stage (SD_TY + 2) x (SD_TX + 2) cells; outside the GLOBAL raster = -100 ring (slope.py:175); cells outside
 // the core but inside the global raster come from the halo of the window.  nodata (and everything outside
 // the raster) is staged as +inf: see dt_slope_cell.  The caller synchronises.
+template <int TX = SD_TX, int TY = SD_TY>
 __device__ __forceinline__ void sd_stage(float *t, const float *__restrict__ dem, const DtWin &w, int x0, int y0,
                                          int vec_ok) {
   const int H = w.H, W = w.W;
@@ -143,39 +144,39 @@ __device__ __forceinline__ void sd_stage(float *t, const float *__restrict__ dem
   // before the first use (five 16-byte loads and one halo value in flight per thread).  The guarded loop below
   // waits for each load before the next: five dependent memory round trips per workgroup, which made every
   // stencil kernel latency-bound (the D8-only kernel took as long as the 8 B/cell slope kernel).
-  if (vec_ok && y0 - 1 >= ylo && y0 + SD_TY + 1 <= yhi && x0 - 1 >= xlo && x0 + SD_TX + 1 <= xhi) {
-    constexpr int NV = ((SD_TY + 2) * (SD_TX / 4) + 255) / 256;  // 5
+  if (vec_ok && y0 - 1 >= ylo && y0 + TY + 1 <= yhi && x0 - 1 >= xlo && x0 + TX + 1 <= xhi) {
+    constexpr int NV = ((TY + 2) * (TX / 4) + 255) / 256;  // 5
     float4 v[NV];
     const float *base = dem + (long long)(y0 - 1) * w.ld + x0;
 #pragma unroll
     for (int u = 0; u < NV; u++) {
       const int i = threadIdx.x + 256 * u;
-      if (i < (SD_TY + 2) * (SD_TX / 4)) {
-        const int r = i / (SD_TX / 4), c4 = i - r * (SD_TX / 4);
+      if (i < (TY + 2) * (TX / 4)) {
+        const int r = i / (TX / 4), c4 = i - r * (TX / 4);
         v[u] = *reinterpret_cast<const float4 *>(base + (long long)r * w.ld + c4 * 4);
       }
     }
     float hv = 0.0f;
     const int hr = threadIdx.x >> 1, hside = threadIdx.x & 1;
-    if (threadIdx.x < (SD_TY + 2) * 2) hv = base[(long long)hr * w.ld + (hside ? SD_TX : -1)];
+    if (threadIdx.x < (TY + 2) * 2) hv = base[(long long)hr * w.ld + (hside ? TX : -1)];
 #pragma unroll
     for (int u = 0; u < NV; u++) {
       const int i = threadIdx.x + 256 * u;
-      if (i < (SD_TY + 2) * (SD_TX / 4)) {
-        const int r = i / (SD_TX / 4), c4 = i - r * (SD_TX / 4);
+      if (i < (TY + 2) * (TX / 4)) {
+        const int r = i / (TX / 4), c4 = i - r * (TX / 4);
         float4 q = v[u];
         q.x = q.x == DT_NODATA ? pinf : q.x;
         q.y = q.y == DT_NODATA ? pinf : q.y;
         q.z = q.z == DT_NODATA ? pinf : q.z;
         q.w = q.w == DT_NODATA ? pinf : q.w;
-        *reinterpret_cast<float4 *>(&t[r * SD_LDW + 4 + c4 * 4]) = q;
+        *reinterpret_cast<float4 *>(&t[r * (TX + 8) + 4 + c4 * 4]) = q;
       }
     }
-    if (threadIdx.x < (SD_TY + 2) * 2) t[hr * SD_LDW + (hside ? 4 + SD_TX : 3)] = hv == DT_NODATA ? pinf : hv;
+    if (threadIdx.x < (TY + 2) * 2) t[hr * (TX + 8) + (hside ? 4 + TX : 3)] = hv == DT_NODATA ? pinf : hv;
     return;
   }
-  for (int i = threadIdx.x; i < (SD_TY + 2) * (SD_TX / 4); i += 256) {
-    int r = i / (SD_TX / 4), c4 = i - r * (SD_TX / 4);
+  for (int i = threadIdx.x; i < (TY + 2) * (TX / 4); i += 256) {
+    int r = i / (TX / 4), c4 = i - r * (TX / 4);
     int gy = y0 - 1 + r, gx = x0 + c4 * 4;
     float4 v = make_float4(DT_NODATA, DT_NODATA, DT_NODATA, DT_NODATA);
     if (gy >= ylo && gy < yhi) {
@@ -193,14 +194,14 @@ __device__ __forceinline__ void sd_stage(float *t, const float *__restrict__ dem
     v.y = v.y == DT_NODATA ? pinf : v.y;
     v.z = v.z == DT_NODATA ? pinf : v.z;
     v.w = v.w == DT_NODATA ? pinf : v.w;
-    *reinterpret_cast<float4 *>(&t[r * SD_LDW + 4 + c4 * 4]) = v;
+    *reinterpret_cast<float4 *>(&t[r * (TX + 8) + 4 + c4 * 4]) = v;
   }
-  for (int i = threadIdx.x; i < (SD_TY + 2) * 2; i += 256) {
+  for (int i = threadIdx.x; i < (TY + 2) * 2; i += 256) {
     int r = i >> 1, side = i & 1;
-    int gy = y0 - 1 + r, gx = side ? x0 + SD_TX : x0 - 1;
+    int gy = y0 - 1 + r, gx = side ? x0 + TX : x0 - 1;
     float v = DT_NODATA;
     if (gy >= ylo && gy < yhi && gx >= xlo && gx < xhi) v = dem[(long long)gy * w.ld + gx];
-    t[r * SD_LDW + (side ? 4 + SD_TX : 3)] = v == DT_NODATA ? pinf : v;
+    t[r * (TX + 8) + (side ? 4 + TX : 3)] = v == DT_NODATA ? pinf : v;
   }
 }
 
@@ -352,11 +353,14 @@ __device__ __forceinline__ bool sd_slope_fast(float c, float nw, float n, float 
 // (Example/example.py:63), a perturbation of <= 4e-7 absolute for angles <= 1.19 (q <= 2.5); steeper cells, a
 // negative or non-finite q and fac < 0 are flagged.  Returns true when the cell must be redone exactly
 // (fac <= -100, the nodata of topoindexes.py:252, is handled by the caller).
-__device__ __forceinline__ bool sd_twi_fast(int32_t fac, float q, double n, double lnpx2, double nlnpx2, float &ti,
+template <typename AccT>
+__device__ __forceinline__ bool sd_twi_fast(AccT fac, float q, double n, double lnpx2, double nlnpx2, float &ti,
                                             float &mti) {
   const float TAN001 = 0.010000333346667207f;
   const float u = q + TAN001, v = fmaf(-q, TAN001, 1.0f);
-  const float ff = (float)(fac > 1 ? fac : 1);  // fac == 0 -> 1 (topoindexes.py:256): ln 1 = 1 + log2(0.5) = 0
+  // fac == 0 -> 1 (topoindexes.py:256): ln 1 = 1 + log2(0.5) = 0.  (An accumulation above 2^24 is rounded to float32
+  // here, 6e-8 relative: within the fast path's error budget for either width.)
+  const float ff = (float)(fac > 1 ? fac : (AccT)1);
   const float lf = __log2f(__builtin_amdgcn_frexp_mantf(ff));
   const float l1 = __log2f(__builtin_amdgcn_frexp_mantf(u));
   const float l2 = __log2f(__builtin_amdgcn_frexp_mantf(v));
@@ -372,39 +376,51 @@ __device__ __forceinline__ bool sd_twi_fast(int32_t fac, float q, double n, doub
 
 typedef float sd_v4f __attribute__((ext_vector_type(4)));
 typedef int sd_v4i __attribute__((ext_vector_type(4)));
-template <bool NT>
+typedef long long sd_v2l __attribute__((ext_vector_type(2)));
+// Cache policy of the fused stencil's streams (POL; DT_DBG_TWI_PLAIN selects it for A/B runs):
+//   0 plain loads, plain stores      1 nt loads, nt stores (the default)      2 nt loads, plain stores
+//   3 nt loads, sc1 stores (write-through: the bytes leave L2 in issue order instead of eviction order)
+//   4 nt loads, sc0 sc1 stores       5 plain loads, nt stores
+template <int POL>
 __device__ __forceinline__ void sd_store4(float *p, float a, float b, float c, float d) {
   sd_v4f v = {a, b, c, d};
-  if (NT) __builtin_nontemporal_store(v, reinterpret_cast<sd_v4f *>(p));
+  if (POL == 1 || POL == 5) __builtin_nontemporal_store(v, reinterpret_cast<sd_v4f *>(p));
+  else if (POL == 3) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+  else if (POL == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
   else *reinterpret_cast<sd_v4f *>(p) = v;
 }
 
-template <bool W_SLOPE, bool W_RAD, bool NT>
-__global__ __launch_bounds__(256, 8) void k_slope_twi(const float *__restrict__ dem, DtWin w, double kc, double kd,
+// WX = waves of a workgroup side by side: the tile is 256 WX columns x 16 / WX rows (256 x 16, 512 x 8 or 1024 x 4;
+// always 4096 cells, one 4 x 4 patch per lane, a wave = 256 columns x 4 rows).  AccT = width of the accumulation raster.
+template <bool W_SLOPE, bool W_RAD, int POL, typename AccT, int WX>
+__global__ __launch_bounds__(256, WX == 1 ? 8 : (WX == 2 ? 7 : 6)) void k_slope_twi(const float *__restrict__ dem, DtWin w, double kc, double kd,
                                                      float *__restrict__ slope, float *__restrict__ slope_rad,
-                                                     const int32_t *__restrict__ acc32, double n_top, double lnpx2,
+                                                     const AccT *__restrict__ acc32, double n_top, double lnpx2,
                                                      float *__restrict__ ti, float *__restrict__ mti, int tiles_x,
                                                      int tiles_y, int vec_ok, uint8_t *__restrict__ tile_mark,
                                                      uint16_t *__restrict__ lane_mask, uint32_t flag_all) {
-  __shared__ __attribute__((aligned(16))) float t[(SD_TY + 2) * SD_LDW];
+  constexpr int TX = SD_TX * WX, TY = SD_TY / WX, LDW = TX + 8;
+  constexpr bool NT = POL >= 1 && POL <= 4;  // non-temporal loads of the accumulation raster
+  __shared__ __attribute__((aligned(16))) float t[(TY + 2) * LDW];
   const double nlnpx2 = n_top * lnpx2;
   // (tried: identity and row-interleaved block -> tile maps instead of one band per XCD: 2 % slower)
   const int tile = sd_tile_of_block(blockIdx.x, tiles_x * tiles_y);
   const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
-  const int x0 = txi * SD_TX, y0 = tyi * SD_TY;
+  const int x0 = txi * TX, y0 = tyi * TY;
   const int H = w.H, W = w.W;
   const float pinf = __builtin_inff();
-  sd_stage(t, dem, w, x0, y0, vec_ok);
+  sd_stage<TX, TY>(t, dem, w, x0, y0, vec_ok);
   __syncthreads();
 
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int cx = tx * 4, ry = ty * 4;  // tile column / row of the lane's 4 x 4 patch; a wave = 4 whole tile rows
+  const int tx = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wx0 = (wv % WX) * 256;              // tile column of the wave's first cell
+  const int cx = wx0 + tx * 4, ry = (wv / WX) * 4;  // tile column / row of the lane's 4 x 4 patch
   const int gx = x0 + cx;
   // every lane stays active to the end (its neighbours' DPP reads need it); stores are guarded
   auto load_row = [&](int lr, float *dst) {
-    const float *row = &t[lr * SD_LDW];
+    const float *row = &t[lr * LDW];
     float4 m = *reinterpret_cast<const float4 *>(row + 4 + cx);
-    float lh = row[3], rh = row[4 + SD_TX];  // halo columns of the tile: wave-uniform address (broadcast)
+    float lh = row[3 + wx0], rh = row[4 + wx0 + 256];  // columns beside the wave: wave-uniform address (broadcast)
     dst[0] = sd_from_prev_lane(lh, m.w);
     dst[1] = m.x;
     dst[2] = m.y;
@@ -421,18 +437,22 @@ __global__ __launch_bounds__(256, 8) void k_slope_twi(const float *__restrict__ 
   for (int j = 0; j < 4; j++) {
     const int gy = y0 + ry + j;
     const long long o = (long long)gy * w.ld + gx;
-    int4 fv = make_int4(-100, -100, -100, -100);
+    AccT fv[4] = {(AccT)-100, (AccT)-100, (AccT)-100, (AccT)-100};
     if (gy < H) {
-      const int32_t *pf = acc32 + o;
-      if (full) {
+      const AccT *pf = acc32 + o;
+      if (full && sizeof(AccT) == 8) {
+        const sd_v2l *p2 = reinterpret_cast<const sd_v2l *>(pf);
+        sd_v2l a2 = NT ? __builtin_nontemporal_load(p2) : p2[0], b2 = NT ? __builtin_nontemporal_load(p2 + 1) : p2[1];
+        fv[0] = (AccT)a2.x; fv[1] = (AccT)a2.y; fv[2] = (AccT)b2.x; fv[3] = (AccT)b2.y;
+      } else if (full) {
         sd_v4i f4 = NT ? __builtin_nontemporal_load(reinterpret_cast<const sd_v4i *>(pf))
                        : *reinterpret_cast<const sd_v4i *>(pf);
-        fv = make_int4(f4.x, f4.y, f4.z, f4.w);
+        fv[0] = (AccT)f4.x; fv[1] = (AccT)f4.y; fv[2] = (AccT)f4.z; fv[3] = (AccT)f4.w;
       } else {
-        if (gx < W) fv.x = pf[0];
-        if (gx + 1 < W) fv.y = pf[1];
-        if (gx + 2 < W) fv.z = pf[2];
-        if (gx + 3 < W) fv.w = pf[3];
+        if (gx < W) fv[0] = pf[0];
+        if (gx + 1 < W) fv[1] = pf[1];
+        if (gx + 2 < W) fv[2] = pf[2];
+        if (gx + 3 < W) fv[3] = pf[3];
       }
     }
     load_row(ry + 2 + j, cc);
@@ -452,8 +472,8 @@ __global__ __launch_bounds__(256, 8) void k_slope_twi(const float *__restrict__ 
         rad = rnod ? DT_NODATA : (float)dt_atanf_pos(q);
         flag = flag || (!rnod && !(q >= 0.0f && q < 1e30f));
       }
-      const int32_t f = k == 0 ? fv.x : (k == 1 ? fv.y : (k == 2 ? fv.z : fv.w));
-      const bool tnod = f <= -100;  // topoindexes.py:252
+      const AccT f = fv[k];
+      const bool tnod = f <= (AccT)-100;  // topoindexes.py:252
       flag = (sd_twi_fast(f, q, n_top, lnpx2, nlnpx2, tv, mv) && !tnod) || flag;
       so[k] = sl;
       ro[k] = rad;
@@ -463,10 +483,10 @@ __global__ __launch_bounds__(256, 8) void k_slope_twi(const float *__restrict__ 
     }
     if (gy < H) {
       if (full) {
-        if (W_SLOPE) sd_store4<NT>(slope + o, so[0], so[1], so[2], so[3]);
-        if (W_RAD) sd_store4<NT>(slope_rad + o, ro[0], ro[1], ro[2], ro[3]);
-        sd_store4<NT>(ti + o, tio[0], tio[1], tio[2], tio[3]);
-        sd_store4<NT>(mti + o, mtio[0], mtio[1], mtio[2], mtio[3]);
+        if (W_SLOPE) sd_store4<POL>(slope + o, so[0], so[1], so[2], so[3]);
+        if (W_RAD) sd_store4<POL>(slope_rad + o, ro[0], ro[1], ro[2], ro[3]);
+        sd_store4<POL>(ti + o, tio[0], tio[1], tio[2], tio[3]);
+        sd_store4<POL>(mti + o, mtio[0], mtio[1], mtio[2], mtio[3]);
       } else {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -495,14 +515,16 @@ __global__ __launch_bounds__(256, 8) void k_slope_twi(const float *__restrict__ 
 }
 
 // the cold half: exact recomputation of the flagged cells (a handful per raster)
+template <typename AccT, int WX>
 __global__ __launch_bounds__(256) void k_slope_twi_fix(const float *__restrict__ dem, DtWin w, double px,
                                                       float *__restrict__ slope, float *__restrict__ slope_rad,
-                                                      const int32_t *__restrict__ acc32, double n_top, double lnpx2,
+                                                      const AccT *__restrict__ acc32, double n_top, double lnpx2,
                                                       float *__restrict__ ti, float *__restrict__ mti, int tiles_x,
                                                       int tiles_y, int vec_ok, const uint8_t *__restrict__ tile_mark,
                                                       const uint16_t *__restrict__ lane_mask,
                                                       const DtLogEntry *__restrict__ g_tab) {
-  __shared__ __attribute__((aligned(16))) float t[(SD_TY + 2) * SD_LDW];
+  constexpr int TX = SD_TX * WX, TY = SD_TY / WX, LDW = TX + 8;
+  __shared__ __attribute__((aligned(16))) float t[(TY + 2) * LDW];
   const int ntiles = tiles_x * tiles_y;
   const double dcard = px, ddiag = px * sqrt(2.0);
   const double inv_card = 1.0 / dcard, inv_diag = 1.0 / ddiag;
@@ -519,22 +541,23 @@ __global__ __launch_bounds__(256) void k_slope_twi_fix(const float *__restrict__
       if (!s_mark[i]) continue;  // block-uniform
       const int tile = chunk * 256 + i;
       const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
-      const int x0 = txi * SD_TX, y0 = tyi * SD_TY;
+      const int x0 = txi * TX, y0 = tyi * TY;
       __syncthreads();  // the previous tile's readers are done with t
-      sd_stage(t, dem, w, x0, y0, vec_ok);
+      sd_stage<TX, TY>(t, dem, w, x0, y0, vec_ok);
       __syncthreads();
       uint32_t mask = lane_mask[(size_t)tile * 256 + threadIdx.x];
-      const int cx = (threadIdx.x & 63) * 4, ry = (threadIdx.x >> 6) * 4;
+      const int wv = threadIdx.x >> 6;
+      const int cx = (wv % WX) * 256 + (threadIdx.x & 63) * 4, ry = (wv / WX) * 4;
       while (mask) {
         const int bit = __ffs((int)mask) - 1;
         mask &= mask - 1u;
         const int j = bit >> 2, k = bit & 3;
         const int gy = y0 + ry + j, gx = x0 + cx + k;
         if (gy >= w.H || gx >= w.W) continue;
-        const float *p = &t[(ry + j + 1) * SD_LDW + 4 + cx + k];  // the centre in the staged tile
+        const float *p = &t[(ry + j + 1) * LDW + 4 + cx + k];  // the centre in the staged tile
         const float cz = p[0] == pinf ? DT_NODATA : p[0];
-        SlopeCell sc = dt_slope_cell<false, true>(cz, p[-SD_LDW - 1], p[-SD_LDW], p[-SD_LDW + 1], p[-1], p[1],
-                                                  p[SD_LDW - 1], p[SD_LDW], p[SD_LDW + 1], inv_card, inv_diag, dcard,
+        SlopeCell sc = dt_slope_cell<false, true>(cz, p[-LDW - 1], p[-LDW], p[-LDW + 1], p[-1], p[1],
+                                                  p[LDW - 1], p[LDW], p[LDW + 1], inv_card, inv_diag, dcard,
                                                   ddiag);
         const long long o = (long long)gy * w.ld + gx;
         const float rad = dt_slope_rad(sc.slope, cz);
@@ -717,12 +740,62 @@ __global__ __launch_bounds__(256) void k_d8_fix(const float *__restrict__ dem, D
 
 // bytes of the mark / mask workspace of the fused slope + TI + MTI launch for an H x W window
 size_t dt_stencil_aux_bytes(int64_t H, int64_t W) {
-  int64_t ntiles = ((W + SD_TX - 1) / SD_TX) * ((H + SD_TY - 1) / SD_TY);
+  int64_t ntiles = 0;  // the largest tile count of the three tile geometries (they differ on ragged rasters)
+  for (int wx = 1; wx <= 4; wx *= 2) {
+    const int64_t tx = SD_TX * wx, ty = SD_TY / wx, n = ((W + tx - 1) / tx) * ((H + ty - 1) / ty);
+    ntiles = n > ntiles ? n : ntiles;
+  }
   return dt_align256((size_t)ntiles) + (size_t)ntiles * 512;
 }
 
+// the fused slope + TI + MTI pair (hot kernel + fix-up of the flagged cells) for one tile geometry / accumulation width
+template <typename AccT, int WX>
+static int launch_slope_twi(hipStream_t s, const DtWin &w, const float *dem, double px, float *slope, float *slope_rad,
+                            const AccT *acc, double n_top, float *ti, float *mti, void *aux, int vec_ok) {
+  constexpr int TX = SD_TX * WX, TY = SD_TY / WX;
+  const int tiles_x = (int)((w.W + TX - 1) / TX), tiles_y = (int)((w.H + TY - 1) / TY);
+  const int64_t ntiles = (int64_t)tiles_x * tiles_y;
+  DT_REQUIRE(ntiles < (1ll << 31), "raster too large for one launch");
+  DT_REQUIRE(aux != nullptr, "fused TWI needs its mark / mask workspace");
+  dim3 g((unsigned)ntiles), b(256);
+  const bool ws = slope != nullptr, wr = slope_rad != nullptr;
+  uint8_t *mark = (uint8_t *)aux;
+  uint16_t *lmask = (uint16_t *)((char *)aux + dt_align256((size_t)ntiles));
+  const double kc = 100.0 / px, kd = 100.0 / (px * sqrt(2.0)), lnpx2 = log(px * px);
+  const DtLogEntry *g_tab = dt_math_device_table(s);
+#define DT_HOT(S, R, N)                                                                                             \
+  hipLaunchKernelGGL((k_slope_twi<S, R, N, AccT, WX>), g, b, 0, s, dem, w, kc, kd, slope, slope_rad, acc, n_top, lnpx2, \
+                     ti, mti, tiles_x, tiles_y, vec_ok, mark, lmask, dt_debug_get(DT_DBG_TWI_FLAG_ALL) ? 0xFFFFu : 0u)
+  // non-temporal loads of the accumulation raster and stores of the outputs (each byte is touched once):
+  // 0.86 instead of 0.92 ms at 16384^2; the knob selects another cache policy (sd_store4) for A/B runs of the
+  // benchmark's form of the kernel (slope + TI + MTI, int32 accumulation, 256 x 16 tiles)
+  const int pol = dt_debug_get(DT_DBG_TWI_PLAIN);
+  bool done = false;
+  if constexpr (WX == 1 && sizeof(AccT) == 4) {
+    if (ws && !wr && pol >= 1 && pol <= 5) {
+      if (pol == 1) DT_HOT(true, false, 0);
+      else if (pol == 2) DT_HOT(true, false, 2);
+      else if (pol == 3) DT_HOT(true, false, 3);
+      else if (pol == 4) DT_HOT(true, false, 4);
+      else DT_HOT(true, false, 5);
+      done = true;
+    }
+  }
+  if (done) {
+  } else if (ws && wr) DT_HOT(true, true, 1);
+  else if (ws) DT_HOT(true, false, 1);
+  else if (wr) DT_HOT(false, true, 1);
+  else DT_HOT(false, false, 1);
+#undef DT_HOT
+  unsigned fix_blocks = (unsigned)((ntiles + 255) / 256 < 1024 ? (ntiles + 255) / 256 : 1024);
+  hipLaunchKernelGGL((k_slope_twi_fix<AccT, WX>), dim3(fix_blocks), b, 0, s, dem, w, px, slope, slope_rad, acc, n_top,
+                     lnpx2, ti, mti, tiles_x, tiles_y, vec_ok, mark, lmask, g_tab);
+  return DT_OK;
+}
+
+// `acc` (fused TI / MTI only): int32_t* raster, or int64_t* with acc64 != 0
 int dt_launch_stencil(hipStream_t s, const DtWin &w, const float *dem, double px, float *slope,
-                      uint8_t *fdr, float *slope_rad, const int32_t *acc32, double n_top, float *ti,
+                      uint8_t *fdr, float *slope_rad, const void *acc, int acc64, double n_top, float *ti,
                       float *mti, void *aux) {
   const int64_t H = w.H, W = w.W;
   if (H == 0 || W == 0) return DT_OK;
@@ -732,33 +805,28 @@ int dt_launch_stencil(hipStream_t s, const DtWin &w, const float *dem, double px
   // 16-byte vector path needs W % 4 == 0 and 16-byte aligned bases
   int vec_ok = (W % 4 == 0) && (w.ld % 4 == 0) && (((uintptr_t)dem & 15) == 0) && (!slope || ((uintptr_t)slope & 15) == 0) &&
                (!slope_rad || ((uintptr_t)slope_rad & 15) == 0) && (!ti || ((uintptr_t)ti & 15) == 0) &&
-               (!mti || ((uintptr_t)mti & 15) == 0) && (!fdr || ((uintptr_t)fdr & 3) == 0);
+               (!mti || ((uintptr_t)mti & 15) == 0) && (!fdr || ((uintptr_t)fdr & 3) == 0) &&
+               (!acc || ((uintptr_t)acc & 15) == 0);
   dim3 g((unsigned)ntiles), b(256);
   bool ws = slope != nullptr, wf = fdr != nullptr, wr = slope_rad != nullptr, wt = ti != nullptr;
-  const DtLogEntry *g_tab = wt ? dt_math_device_table(s) : nullptr;
 #define DT_GO(S, F, R) \
   hipLaunchKernelGGL((k_stencil<S, F, R>), g, b, 0, s, dem, w, px, slope, fdr, slope_rad, tiles_x, tiles_y, vec_ok)
   if (wt) {
-    DT_REQUIRE(acc32 && mti, "fused TWI needs acc32, ti and mti");
-    DT_REQUIRE(aux != nullptr, "fused TWI needs its mark / mask workspace");
-    uint8_t *mark = (uint8_t *)aux;
-    uint16_t *lmask = (uint16_t *)((char *)aux + dt_align256((size_t)ntiles));
-    const double kc = 100.0 / px, kd = 100.0 / (px * sqrt(2.0)), lnpx2 = log(px * px);
-#define DT_HOT(S, R, N)                                                                                          \
-  hipLaunchKernelGGL((k_slope_twi<S, R, N>), g, b, 0, s, dem, w, kc, kd, slope, slope_rad, acc32, n_top, lnpx2, ti, \
-                     mti, tiles_x, tiles_y, vec_ok, mark, lmask, dt_debug_get(DT_DBG_TWI_FLAG_ALL) ? 0xFFFFu : 0u)
-    // non-temporal loads of the accumulation raster and stores of the outputs (each byte is touched once):
-    // 0.86 instead of 0.92 ms at 16384^2; the knob switches back to the default cache policy for A/B runs
-    const bool plain = dt_debug_get(DT_DBG_TWI_PLAIN) != 0;
-    if (ws && !wr && plain) DT_HOT(true, false, false);
-    else if (ws && wr) DT_HOT(true, true, true);
-    else if (ws) DT_HOT(true, false, true);
-    else if (wr) DT_HOT(false, true, true);
-    else DT_HOT(false, false, true);
-#undef DT_HOT
-    unsigned fix_blocks = (unsigned)((ntiles + 255) / 256 < 1024 ? (ntiles + 255) / 256 : 1024);
-    hipLaunchKernelGGL(k_slope_twi_fix, dim3(fix_blocks), b, 0, s, dem, w, px, slope, slope_rad, acc32, n_top, lnpx2,
-                       ti, mti, tiles_x, tiles_y, vec_ok, mark, lmask, g_tab);
+    DT_REQUIRE(acc && mti, "fused TWI needs the accumulation raster, ti and mti");
+    // tile geometry (DT_DBG_TWI_WX: 1, 2 or 4 waves side by side; 0 = default), narrowed for narrow rasters
+    int wx = dt_debug_get(DT_DBG_TWI_WX);
+    if (wx != 1 && wx != 2 && wx != 4) wx = DT_TWI_WX_DEFAULT;
+    while (wx > 1 && W < (int64_t)SD_TX * wx) wx >>= 1;
+    if (acc64) {
+      const long long *a = (const long long *)acc;
+      if (wx == 4) return launch_slope_twi<long long, 4>(s, w, dem, px, slope, slope_rad, a, n_top, ti, mti, aux, vec_ok);
+      if (wx == 2) return launch_slope_twi<long long, 2>(s, w, dem, px, slope, slope_rad, a, n_top, ti, mti, aux, vec_ok);
+      return launch_slope_twi<long long, 1>(s, w, dem, px, slope, slope_rad, a, n_top, ti, mti, aux, vec_ok);
+    }
+    const int32_t *a = (const int32_t *)acc;
+    if (wx == 4) return launch_slope_twi<int32_t, 4>(s, w, dem, px, slope, slope_rad, a, n_top, ti, mti, aux, vec_ok);
+    if (wx == 2) return launch_slope_twi<int32_t, 2>(s, w, dem, px, slope, slope_rad, a, n_top, ti, mti, aux, vec_ok);
+    return launch_slope_twi<int32_t, 1>(s, w, dem, px, slope, slope_rad, a, n_top, ti, mti, aux, vec_ok);
   } else if (ws && wf && wr) DT_GO(true, true, true);
   else if (ws && wf) DT_GO(true, true, false);
   else if (ws && wr) DT_GO(true, false, true);

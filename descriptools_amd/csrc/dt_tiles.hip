@@ -420,13 +420,17 @@ __global__ __launch_bounds__(256) void k_fa_poison(const unsigned long long *__r
 // pass 3: the inflow that enters the tile at a perimeter cell p (ext[p], resolved by pass 2) drains
 // through every cell of p's in-tile path: one lane per entry cell walks that path adding ext[p] to
 // an LDS delta raster (integer adds: order-free), then delta is added to pass 1's in-tile counts.
-template <bool HAS_DEM, bool W_RIVER>
-__global__ __launch_bounds__(256, 6) void k_fa_tile3(const uint8_t *__restrict__ fdr,
+// AccT = int32_t: the accumulation raster of a raster below 2^31 cells (a value that could reach 2^31 raises the
+// context's overflow status instead of wrapping); AccT = int64_t: the reference's own dtype (Example/example.py:39),
+// selected for multi-rank rasters of >= 2^31 cells, where a basin can exceed 32 bits.
+template <bool HAS_DEM, bool W_RIVER, typename AccT>
+__global__ __launch_bounds__(256, sizeof(AccT) == 8 ? 4 : 6) void k_fa_tile3(const uint8_t *__restrict__ fdr,
                                                     const float *__restrict__ dem, DtWin w, int tiles_x,
                                                     const unsigned long long *__restrict__ ext,
                                                     const uint16_t *__restrict__ loc16,
-                                                    int32_t *__restrict__ acc32, int32_t river_thr,
+                                                    AccT *__restrict__ acc32, AccT river_thr,
                                                     int8_t *__restrict__ river, int *__restrict__ status) {
+  constexpr bool WIDE = sizeof(AccT) == 8;
   // 25.5 KiB of LDS: six tiles per CU (the kernel is a latency chain of LDS walks).  The direction codes are
   // staged through the delta array; bit 31 of a delta (real inflow < 2^31) marks the cells of a cycle
   // spanning tiles.  Both arrays are indexed with rows 68 cells apart (P3 below): with 64, a step north or south
@@ -478,17 +482,20 @@ __global__ __launch_bounds__(256, 6) void k_fa_tile3(const uint8_t *__restrict__
     }
   }
   dt_tile_put16(s_fdr, v_fdr);
-  // The accumulation raster is int32 (a device tile has < 2^31 cells), but across ranks a basin can reach 2^31
-  // cells.  No value of this tile can exceed the inflow entering it plus its own 4096 cells: a tile whose entries
-  // bring in >= 2^31 - 4096 in total raises the context's overflow status (dt_ctx_status) instead of wrapping
-  // silently.  Only such a tile pays for the 64-bit sum.
+  // No value of this tile can exceed the inflow entering it plus its own 4096 cells.  A tile whose entries bring in
+  // >= 2^31 - 4096 in total is "big" (only tiles with an entry of >= 2^22 pay for the 64-bit sum that decides it):
+  // with the int32 raster it raises the context's overflow status (dt_ctx_status) instead of wrapping silently;
+  // with the int64 raster its inflow is carried through the 32-bit LDS delta raster in two limbs (below).
+  bool big = false;
   if (__syncthreads_or(!(e & FA_CYCLE) && FA_VALUE(e) >= (1ull << 22))) {
     __shared__ unsigned long long s_in;
     if (threadIdx.x == 0) s_in = 0ull;
     __syncthreads();
     if (e != 0ull && !(e & FA_CYCLE)) atomicAdd(&s_in, FA_VALUE(e));
     __syncthreads();
-    if (threadIdx.x == 0 && s_in >= (1ull << 31) - (unsigned long long)NT && status) atomicOr(status, DT_STATUS_ACC_OVERFLOW);
+    const bool over = s_in >= (1ull << 31) - (unsigned long long)NT;
+    if (WIDE) big = over;
+    else if (threadIdx.x == 0 && over && status) atomicOr(status, DT_STATUS_ACC_OVERFLOW);
   }
   uint32_t nx[CPT];
   if (dt_tile_interior(w, y0, x0)) {
@@ -510,15 +517,17 @@ __global__ __launch_bounds__(256, 6) void k_fa_tile3(const uint8_t *__restrict__
     s_delta[P3(c)] = 0u;
   }
   __syncthreads();
-  if (e != 0ull) {
+  // one lane per entry cell walks its in-tile path.  Limbs of a big tile (int64 raster only): the low 23 bits of
+  // every inflow in a first sweep, the rest in a second one over the same (cleared) delta raster -- a path collects
+  // at most 252 entries, so neither sweep can reach bit 31, which stays the cycle mark.
+  constexpr uint32_t LIMB = 23;
+  auto walk = [&](uint32_t add, bool cyc) {
     int ly, lx;
     dt_cell_of_slot(threadIdx.x, ly, lx);
     uint32_t c = P3(ly * TW + lx);
-    // fed by a D8 cycle spanning tiles: the path IS the cycle; else the real inflow (< 2^31)
-    const uint32_t add = (e & FA_CYCLE) ? 0x80000000u : (uint32_t)e;
-    if (e & FA_CYCLE) {
+    if (cyc) {  // fed by a D8 cycle spanning tiles: the path IS the cycle
       for (int it = 0; it < NT && c < NT3; it++) {
-        atomicOr(&s_delta[c], add);
+        atomicOr(&s_delta[c], 0x80000000u);
         c = s_nxt[c];
       }
     } else {
@@ -527,13 +536,41 @@ __global__ __launch_bounds__(256, 6) void k_fa_tile3(const uint8_t *__restrict__
         c = s_nxt[c];
       }
     }
+  };
+  // the lane's 16 cells in the order of the stores below
+  auto cell_of = [&](int i) -> int { return vec ? 4 * ((int)threadIdx.x + 256 * (i >> 2)) + (i & 3) : (int)threadIdx.x + 256 * i; };
+  uint32_t dlo[WIDE ? CPT : 1];
+  if (e != 0ull) {
+    const bool cyc = (e & FA_CYCLE) != 0ull;
+    const uint32_t add = (WIDE && big) ? (uint32_t)(FA_VALUE(e) & ((1ull << LIMB) - 1ull)) : (uint32_t)e;
+    if (cyc || add) walk(add, cyc);
   }
   __syncthreads();
-  auto finish = [&](uint32_t l16, uint32_t d, float z) -> int32_t {
-    int32_t v = l16 == 0xFFFFu ? -100 : (int32_t)l16;
-    if (v != -100) v += (int32_t)(d & 0x7FFFFFFFu);
-    if (d & 0x80000000u) v = -100;
-    if (HAS_DEM && z <= DT_NODATA) v = -100;
+  if (WIDE && big) {  // block-uniform
+#pragma unroll
+    for (int i = 0; i < CPT; i++) dlo[WIDE ? i : 0] = s_delta[P3(cell_of(i))];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < CPT; i++) s_delta[P3(cell_of(i))] = 0u;
+    __syncthreads();
+    if (e != 0ull && !(e & FA_CYCLE) && (FA_VALUE(e) >> LIMB) != 0ull) walk((uint32_t)(FA_VALUE(e) >> LIMB), false);
+    __syncthreads();
+  }
+  // inflow of cell i of this lane (and its cycle mark) from the delta raster word d
+  auto inflow = [&](int i, uint32_t d, bool &cyc) -> unsigned long long {
+    if (WIDE && big) {
+      const uint32_t lo = dlo[WIDE ? i : 0];
+      cyc = (lo & 0x80000000u) != 0u;
+      return ((unsigned long long)d << LIMB) + (unsigned long long)(lo & 0x7FFFFFFFu);
+    }
+    cyc = (d & 0x80000000u) != 0u;
+    return (unsigned long long)(d & 0x7FFFFFFFu);
+  };
+  auto finish = [&](uint32_t l16, unsigned long long d, bool cyc, float z) -> AccT {
+    AccT v = l16 == 0xFFFFu ? (AccT)-100 : (AccT)l16;
+    if (v != (AccT)-100) v += (AccT)d;
+    if (cyc) v = (AccT)-100;
+    if (HAS_DEM && z <= DT_NODATA) v = (AccT)-100;
     return v;
   };
   if (vec) {
@@ -544,12 +581,20 @@ __global__ __launch_bounds__(256, 6) void k_fa_tile3(const uint8_t *__restrict__
       if (y >= w.H) continue;
       long long o = (long long)y * w.ld + x0 + c % TW;
       uint4 d = *reinterpret_cast<const uint4 *>(&s_delta[P3(c)]);
-      int4 v = make_int4(finish(l4[u].x & 0xFFFFu, d.x, z4[u].x), finish(l4[u].x >> 16, d.y, z4[u].y),
-                         finish(l4[u].y & 0xFFFFu, d.z, z4[u].z), finish(l4[u].y >> 16, d.w, z4[u].w));
-      *reinterpret_cast<int4 *>(acc32 + o) = v;
+      bool c0, c1, c2, c3;
+      const unsigned long long i0 = inflow(4 * u, d.x, c0), i1 = inflow(4 * u + 1, d.y, c1),
+                               i2 = inflow(4 * u + 2, d.z, c2), i3 = inflow(4 * u + 3, d.w, c3);
+      const AccT vx = finish(l4[u].x & 0xFFFFu, i0, c0, z4[u].x), vy = finish(l4[u].x >> 16, i1, c1, z4[u].y),
+                 vz = finish(l4[u].y & 0xFFFFu, i2, c2, z4[u].z), vw = finish(l4[u].y >> 16, i3, c3, z4[u].w);
+      if (WIDE) {
+        *reinterpret_cast<longlong2 *>(acc32 + o) = make_longlong2((long long)vx, (long long)vy);
+        *reinterpret_cast<longlong2 *>(acc32 + o + 2) = make_longlong2((long long)vz, (long long)vw);
+      } else {
+        *reinterpret_cast<int4 *>(acc32 + o) = make_int4((int)vx, (int)vy, (int)vz, (int)vw);
+      }
       if (W_RIVER) {
-        uint32_t r = (v.x > river_thr ? 1u : 0u) | (v.y > river_thr ? 0x100u : 0u) |
-                     (v.z > river_thr ? 0x10000u : 0u) | (v.w > river_thr ? 0x1000000u : 0u);
+        uint32_t r = (vx > river_thr ? 1u : 0u) | (vy > river_thr ? 0x100u : 0u) |
+                     (vz > river_thr ? 0x10000u : 0u) | (vw > river_thr ? 0x1000000u : 0u);
         *reinterpret_cast<uint32_t *>(river + o) = r;
       }
     }
@@ -561,7 +606,9 @@ __global__ __launch_bounds__(256, 6) void k_fa_tile3(const uint8_t *__restrict__
     int y = y0 + c / TW, x = x0 + c % TW;
     if (y >= w.H || x >= w.W) continue;
     long long o = (long long)y * w.ld + x;
-    int32_t v = finish(av[j] == -100 ? 0xFFFFu : (uint32_t)av[j], s_delta[P3(c)], zv[j]);
+    bool cy;
+    const unsigned long long in = inflow(j, s_delta[P3(c)], cy);
+    AccT v = finish(av[j] == -100 ? 0xFFFFu : (uint32_t)av[j], in, cy, zv[j]);
     acc32[o] = v;
     if (W_RIVER) river[o] = v > river_thr ? 1 : 0;
   }
@@ -720,8 +767,19 @@ int dt_launch_fa_summary(hipStream_t s, const DtWin &w, void *scratch, int64_t *
 
 // phase 2: optional inflow from other ranks, carried along the entry successor lists of phase 1
 // (dt_launch_fa_local with rank_level), then the final tile pass.
+template <typename AccT>
+static void fa_launch_tile3(hipStream_t s, dim3 gt, const DtWin &w, const uint8_t *fdr, const float *dem,
+                            const FaScratch &f, AccT *acc, AccT thr, int8_t *river, int *status) {
+  dim3 b(256);
+  if (dem && river) hipLaunchKernelGGL((k_fa_tile3<true, true, AccT>), gt, b, 0, s, fdr, dem, w, f.tiles_x, f.ext, f.loc16, acc, thr, river, status);
+  else if (dem) hipLaunchKernelGGL((k_fa_tile3<true, false, AccT>), gt, b, 0, s, fdr, dem, w, f.tiles_x, f.ext, f.loc16, acc, thr, river, status);
+  else if (river) hipLaunchKernelGGL((k_fa_tile3<false, true, AccT>), gt, b, 0, s, fdr, dem, w, f.tiles_x, f.ext, f.loc16, acc, thr, river, status);
+  else hipLaunchKernelGGL((k_fa_tile3<false, false, AccT>), gt, b, 0, s, fdr, dem, w, f.tiles_x, f.ext, f.loc16, acc, thr, river, status);
+}
+
+// `acc` is int32_t* (acc64 == 0) or int64_t* (acc64 != 0: rasters of >= 2^31 cells split over ranks)
 int dt_launch_fa_finish(hipStream_t s, const DtWin &w, const uint8_t *fdr, const float *dem, void *scratch,
-                        const unsigned long long *ext_perim, int64_t river_thr, int32_t *acc32,
+                        const unsigned long long *ext_perim, int64_t river_thr, void *acc, int acc64,
                         int8_t *river, int *status) {
   if (w.H == 0 || w.W == 0) return DT_OK;
   FaScratch f = fa_layout(w, scratch);
@@ -732,11 +790,12 @@ int dt_launch_fa_finish(hipStream_t s, const DtWin &w, const uint8_t *fdr, const
                        ext_perim, P, f.ext);
   }
   hipLaunchKernelGGL(k_fa_poison, gn, b, 0, s, f.rec, f.nnodes, f.entry_of, f.state, f.ext);
-  int32_t thr = river_thr > 2147483647ll ? 2147483647 : (river_thr < -2147483647ll ? -2147483647 : (int32_t)river_thr);
-  if (dem && river) hipLaunchKernelGGL((k_fa_tile3<true, true>), gt, b, 0, s, fdr, dem, w, f.tiles_x, f.ext, f.loc16, acc32, thr, river, status);
-  else if (dem) hipLaunchKernelGGL((k_fa_tile3<true, false>), gt, b, 0, s, fdr, dem, w, f.tiles_x, f.ext, f.loc16, acc32, thr, river, status);
-  else if (river) hipLaunchKernelGGL((k_fa_tile3<false, true>), gt, b, 0, s, fdr, dem, w, f.tiles_x, f.ext, f.loc16, acc32, thr, river, status);
-  else hipLaunchKernelGGL((k_fa_tile3<false, false>), gt, b, 0, s, fdr, dem, w, f.tiles_x, f.ext, f.loc16, acc32, thr, river, status);
+  if (acc64) {
+    fa_launch_tile3<long long>(s, gt, w, fdr, dem, f, (long long *)acc, (long long)river_thr, river, status);
+  } else {
+    int32_t thr = river_thr > 2147483647ll ? 2147483647 : (river_thr < -2147483647ll ? -2147483647 : (int32_t)river_thr);
+    fa_launch_tile3<int32_t>(s, gt, w, fdr, dem, f, (int32_t *)acc, thr, river, status);
+  }
   return DT_OK;
 }
 
@@ -1188,13 +1247,14 @@ __global__ __launch_bounds__(256) void k_fh_node_jump(unsigned long long *__rest
 // rank level: one row per core-ring cell describing the path that ENTERS the rank there:
 //   kind 1 river (ref = core-local flat index, zr / ar = its height / accumulation), 2 dead,
 //   4 leaves the rank again through ring cell `ref` after (nc, nd) moves INCLUDING the crossing step
+template <typename AccT>
 __global__ __launch_bounds__(256) void k_fh_rank_summary(DtWin w, int tiles_x, uint32_t nnodes,
                                                         const unsigned long long *__restrict__ nodes,
                                                         const float *__restrict__ dem,
-                                                        const int32_t *__restrict__ acc32, int64_t P,
+                                                        const AccT *__restrict__ acc32, int64_t P,
                                                         uint8_t *__restrict__ kind, int32_t *__restrict__ ref,
                                                         int32_t *__restrict__ nc, int32_t *__restrict__ nd,
-                                                        float *__restrict__ zr, int32_t *__restrict__ ar) {
+                                                        float *__restrict__ zr, long long *__restrict__ ar) {
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= P) return;
   int y, x;
@@ -1206,14 +1266,14 @@ __global__ __launch_bounds__(256) void k_fh_rank_summary(DtWin w, int tiles_x, u
   uint8_t k = (uint8_t)K_DEAD;
   int32_t r = -1;
   float z = DT_NODATA;
-  int32_t a = 0;
+  long long a = 0;
   if (ncf & FHT_DONE) {
     if (ptr != FHT_DEAD) {
       k = (uint8_t)K_RIVER;
       r = (int32_t)ptr;
       long long o = (long long)(ptr / (uint32_t)w.W) * w.ld + (ptr % (uint32_t)w.W);
       if (dem) z = dem[o];
-      if (acc32) a = acc32[o];
+      if (acc32) a = (long long)acc32[o];
     }
   } else if (ptr >= nnodes) {  // parked on a ghost: leaves the rank
     k = (uint8_t)K_REXIT;
@@ -1252,7 +1312,36 @@ struct FhGfi {
 struct FhRemote {  // payload of rank exits (multi-GPU), all indexed by core-ring index; NULL when unused
   const long long *gidx;
   const float *zr;
-  const int32_t *ar;
+  const long long *ar;  // 64 bits whatever the raster's width: a river of another rank may carry >= 2^31 cells
+};
+// per exit slot of a tile: height and accumulation of the river cell the exit resolves to.  One 64-bit LDS word with
+// the int32 accumulation raster, two arrays with the int64 one.
+template <typename AccT>
+struct FhPay;
+template <>
+struct FhPay<int32_t> {
+  unsigned long long v[PS];
+  __device__ __forceinline__ void set(int i, float z, int32_t a) {
+    v[i] = ((unsigned long long)(uint32_t)a << 32) | (unsigned long long)__float_as_uint(z);
+  }
+  __device__ __forceinline__ void get(int i, float &z, int32_t &a) const {
+    const unsigned long long p = v[i];
+    z = __uint_as_float((uint32_t)p);
+    a = (int32_t)(uint32_t)(p >> 32);
+  }
+};
+template <>
+struct FhPay<long long> {
+  long long av[PS];
+  float zv[PS];
+  __device__ __forceinline__ void set(int i, float z, long long a) {
+    av[i] = a;
+    zv[i] = z;
+  }
+  __device__ __forceinline__ void get(int i, float &z, long long &a) const {
+    z = zv[i];
+    a = av[i];
+  }
 };
 
 typedef float fh_v4f __attribute__((ext_vector_type(4)));
@@ -1265,25 +1354,31 @@ __device__ __forceinline__ void fh_store4(int32_t *p, int32_t a, int32_t b, int3
   fh_v4i v = {a, b, c, d};
   __builtin_nontemporal_store(v, reinterpret_cast<fh_v4i *>(p));
 }
+typedef long long fh_v2l __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void fh_store4(long long *p, long long a, long long b, long long c, long long d) {
+  fh_v2l v0 = {a, b}, v1 = {c, d};
+  __builtin_nontemporal_store(v0, reinterpret_cast<fh_v2l *>(p));
+  __builtin_nontemporal_store(v1, reinterpret_cast<fh_v2l *>(p + 2));
+}
 
 // RANKED: the multi-GPU form (rank-exit payloads `rem`, ghost nodes, global int64 river indices); the
 // single-raster form leaves all of that out of the register budget
-template <bool RANKED, int VH, int MINW>
+template <bool RANKED, int VH, int MINW, typename AccT>
 __global__ __launch_bounds__(256, MINW) void k_fh_tile3(const uint8_t *__restrict__ fdr,
                                                  const float *__restrict__ dem,
-                                                 const int32_t *__restrict__ acc32, DtWin w, int tiles_x,
+                                                 const AccT *__restrict__ acc32, DtWin w, int tiles_x,
                                                  uint32_t nnodes, const unsigned long long *__restrict__ nodes,
                                                  const unsigned long long *__restrict__ cache,
                                                  const uint8_t *__restrict__ cache_wide,
                                                  FhRemote rem, double px, float *__restrict__ fdist,
                                                  int32_t *__restrict__ idx32, long long *__restrict__ idx64,
-                                                 float *__restrict__ hand, int32_t *__restrict__ a_river,
+                                                 float *__restrict__ hand, AccT *__restrict__ a_river,
                                                  FhGfi G) {
   // per exit slot: the resolved word of the node the exit cell steps onto (+ the step), and the payload
   // {river height, river accumulation} of the river cell it resolves to.  4 KiB of LDS: the kernel streams
   // 28 B/cell and needs the occupancy, not a 32 KiB per-cell table.
   __shared__ unsigned long long s_x[PS];
-  __shared__ unsigned long long s_pay[PS];
+  __shared__ FhPay<AccT> s_pay;
   __shared__ DtLogEntry s_tab[DT_LOGTAB_N];  // 2 KiB: the GFI epilogue's logarithm table
   if (G.gfi) dt_math_stage(G.tab, s_tab);  // before the barrier every path below passes
   const int tile = dt_tile_of_block((int)blockIdx.x, (int)gridDim.x);
@@ -1298,7 +1393,7 @@ __global__ __launch_bounds__(256, MINW) void k_fh_tile3(const uint8_t *__restric
     uint32_t sp = (uint32_t)(s >> 32);
     unsigned long long o = fht_pack(FHT_DEAD, 0, FHT_DONE);
     float zr = DT_NODATA;
-    int32_t ar = -100;
+    AccT ar = -100;
     // only exit cells (a finished word pointing at itself with kind EXIT / REXIT) are looked up
     bool ex = sp == ((uint32_t)f | (K_EXIT << 12)), rex = sp == ((uint32_t)f | (K_REXIT << 12));
     if (ex || rex) {
@@ -1315,9 +1410,12 @@ __global__ __launch_bounds__(256, MINW) void k_fh_tile3(const uint8_t *__restric
         unsigned long long gs = nodes[nptr];
         uint32_t gncf = (uint32_t)(gs & 0xFFFFu);
         nnd += (uint32_t)((gs >> 16) & 0xFFFFu);
-        nncf += gncf & 0x7FFFu;
+        // the two cardinal counts are <= 20000 each: their sum can exceed the word's 15-bit field, so the cap is
+        // tested on the full sum before anything is packed again (a wrapped count once passed the test: a path of
+        // 32800 moves across two ranks came out as 32 moves, tests/test_gpu_acc64.py)
+        const uint32_t cnt = (nncf & 0x7FFFu) + (gncf & 0x7FFFu);
         nptr = (uint32_t)(gs >> 32);
-        if ((gncf & FHT_DONE) && nptr != FHT_DEAD && (nncf & 0x7FFFu) + nnd <= FHT_CAP) nncf |= FHT_DONE;
+        if ((gncf & FHT_DONE) && nptr != FHT_DEAD && cnt + nnd <= FHT_CAP) nncf = cnt | FHT_DONE;
         else nptr = FHT_DEAD;
       }
       bool diag = dy != 0 && dx != 0;
@@ -1326,7 +1424,7 @@ __global__ __launch_bounds__(256, MINW) void k_fh_tile3(const uint8_t *__restric
         o = fht_pack(nptr, nnd + (diag ? 1u : 0u), ((nncf & 0x7FFFu) + (diag ? 0u : 1u)) | FHT_DONE);
         if (RANKED && (nptr & FHT_REMOTE)) {
           zr = rem.zr[nptr & ~FHT_REMOTE];
-          ar = rem.ar[nptr & ~FHT_REMOTE];
+          ar = (AccT)rem.ar[nptr & ~FHT_REMOTE];
         } else {
           long long ro = (long long)(nptr / (uint32_t)w.W) * w.ld + (nptr % (uint32_t)w.W);
           if (dem) zr = dem[ro];
@@ -1335,7 +1433,7 @@ __global__ __launch_bounds__(256, MINW) void k_fh_tile3(const uint8_t *__restric
       }
     }
     s_x[threadIdx.x] = o;
-    s_pay[threadIdx.x] = ((unsigned long long)(uint32_t)ar << 32) | (unsigned long long)__float_as_uint(zr);
+    s_pay.set((int)threadIdx.x, zr, ar);
   }
   // block-uniform: whole 64-cell rows of this tile are inside the core and every raster row is 16-byte
   // aligned -> each lane handles 4 consecutive cells with 16-byte loads and stores
@@ -1347,7 +1445,8 @@ __global__ __launch_bounds__(256, MINW) void k_fh_tile3(const uint8_t *__restric
   const double dcard = px, ddiag = px * sqrt(2.0);
   struct CellOut {
     float fd, h;
-    int32_t i32, ar;
+    int32_t i32;
+    AccT ar;
     long long i64;
   };
   // one cell: its pass-1 word s, own height z -> outputs (needs s_x / s_pay: call after the barrier)
@@ -1357,7 +1456,8 @@ __global__ __launch_bounds__(256, MINW) void k_fh_tile3(const uint8_t *__restric
     uint32_t kind = (ptr >> 12) & 7u, f = ptr & 0xFFFu;
     bool ok = false;
     uint32_t ridx = 0;  // core-local flat index of the river cell, or FHT_REMOTE | ring index
-    unsigned long long pay = 0ull;
+    float pz = 0.0f;  // the river cell's height and accumulation
+    AccT pa = 0;
     if (ncf & FHT_DONE) {
       if (kind == K_RIVER) {
         // the path ends on a river cell of this tile: its own height / accumulation (a gather inside the
@@ -1365,9 +1465,8 @@ __global__ __launch_bounds__(256, MINW) void k_fh_tile3(const uint8_t *__restric
         ok = true;
         ridx = (uint32_t)((y0 + (int)f / TW) * w.W + x0 + (int)f % TW);
         long long ro = (long long)(y0 + (int)f / TW) * w.ld + x0 + (int)f % TW;
-        float zr = dem ? dem[ro] : DT_NODATA;
-        int32_t ar = acc32 ? acc32[ro] : -100;
-        pay = ((unsigned long long)(uint32_t)ar << 32) | (unsigned long long)__float_as_uint(zr);
+        pz = dem ? dem[ro] : DT_NODATA;
+        pa = acc32 ? acc32[ro] : (AccT)-100;
       } else if (kind == K_EXIT || kind == K_REXIT) {
         int slot = dt_slot_of((int)f / TW, (int)f % TW);
         unsigned long long xs = s_x[slot];
@@ -1377,7 +1476,7 @@ __global__ __launch_bounds__(256, MINW) void k_fh_tile3(const uint8_t *__restric
           nd += (uint32_t)((xs >> 16) & 0xFFFFu);
           ok = nc + nd <= FHT_CAP;  // flowhand.py:834-837
           ridx = xptr;
-          pay = s_pay[slot];
+          s_pay.get(slot, pz, pa);
         }
       }
     }
@@ -1395,12 +1494,12 @@ __global__ __launch_bounds__(256, MINW) void k_fh_tile3(const uint8_t *__restric
     }
     o.h = DT_NODATA;
     if (z != DT_NODATA && ok) {  // flowhand.py:436
-      o.h = z - __uint_as_float((uint32_t)pay);
+      o.h = z - pz;
       if (o.h < 0.0f && o.h != DT_NODATA) o.h = 0.0f;  // flowhand.py:438
     }
     // A_river = fac[idx] carried as payload; cells without a river cell get -100 (GFI is -100 there
     // anyway: their hand is -100, gfi.py:289)
-    o.ar = ok ? (int32_t)(uint32_t)(pay >> 32) : -100;
+    o.ar = ok ? pa : (AccT)-100;
     return o;
   };
   if (vec) {
@@ -1450,16 +1549,25 @@ __global__ __launch_bounds__(256, MINW) void k_fh_tile3(const uint8_t *__restric
         if (hand) fh_store4(hand + o, r0.h, r1.h, r2.h, r3.h);
         if (a_river) fh_store4(a_river + o, r0.ar, r1.ar, r2.ar, r3.ar);
         if (G.gfi) {
-          int4 f = *reinterpret_cast<const int4 *>(acc32 + o);  // own accumulation (aligned like the outputs)
+          // own accumulation (aligned like the outputs)
+          AccT fx, fy, fz, fw;
+          if (sizeof(AccT) == 8) {
+            const longlong2 fa = *reinterpret_cast<const longlong2 *>(acc32 + o);
+            const longlong2 fb = *reinterpret_cast<const longlong2 *>(acc32 + o + 2);
+            fx = (AccT)fa.x; fy = (AccT)fa.y; fz = (AccT)fb.x; fw = (AccT)fb.y;
+          } else {
+            const int4 f = *reinterpret_cast<const int4 *>(acc32 + o);
+            fx = (AccT)f.x; fy = (AccT)f.y; fz = (AccT)f.z; fw = (AccT)f.w;
+          }
           float4 g, l;
           // one cell after the other (the scheduler would interleave the four float64 chains: 105 VGPRs)
-          dt_gfi_both_cell(r0.h, r0.ar, f.x, G.expo, G.c0, s_tab, g.x, l.x);
+          dt_gfi_both_cell(r0.h, r0.ar, fx, G.expo, G.c0, s_tab, g.x, l.x);
           __builtin_amdgcn_sched_barrier(0);
-          dt_gfi_both_cell(r1.h, r1.ar, f.y, G.expo, G.c0, s_tab, g.y, l.y);
+          dt_gfi_both_cell(r1.h, r1.ar, fy, G.expo, G.c0, s_tab, g.y, l.y);
           __builtin_amdgcn_sched_barrier(0);
-          dt_gfi_both_cell(r2.h, r2.ar, f.z, G.expo, G.c0, s_tab, g.z, l.z);
+          dt_gfi_both_cell(r2.h, r2.ar, fz, G.expo, G.c0, s_tab, g.z, l.z);
           __builtin_amdgcn_sched_barrier(0);
-          dt_gfi_both_cell(r3.h, r3.ar, f.w, G.expo, G.c0, s_tab, g.w, l.w);
+          dt_gfi_both_cell(r3.h, r3.ar, fw, G.expo, G.c0, s_tab, g.w, l.w);
           fh_store4(G.gfi + o, g.x, g.y, g.z, g.w);
           fh_store4(G.lnhlh + o, l.x, l.y, l.z, l.w);
         }
@@ -1540,21 +1648,27 @@ int dt_launch_fh_local(hipStream_t s, const DtWin &w, const uint8_t *fdr, const 
   return DT_OK;
 }
 
-int dt_launch_fh_summary(hipStream_t s, const DtWin &w, void *scratch, const float *dem, const int32_t *acc32,
-                         uint8_t *kind, int32_t *ref, int32_t *nc, int32_t *nd, float *zr, int32_t *ar) {
+int dt_launch_fh_summary(hipStream_t s, const DtWin &w, void *scratch, const float *dem, const void *acc, int acc64,
+                         uint8_t *kind, int32_t *ref, int32_t *nc, int32_t *nd, float *zr, long long *ar) {
   FhScratch f = fh_layout(w, scratch);
   if (f.P == 0) return DT_OK;
-  hipLaunchKernelGGL(k_fh_rank_summary, dim3((unsigned)((f.P + 255) / 256)), dim3(256), 0, s, w, f.tiles_x,
-                     (uint32_t)f.nnodes, f.nodes, dem, acc32, f.P, kind, ref, nc, nd, zr, ar);
+  dim3 g((unsigned)((f.P + 255) / 256)), b(256);
+  if (acc64)
+    hipLaunchKernelGGL(k_fh_rank_summary<long long>, g, b, 0, s, w, f.tiles_x, (uint32_t)f.nnodes, f.nodes, dem,
+                       (const long long *)acc, f.P, kind, ref, nc, nd, zr, ar);
+  else
+    hipLaunchKernelGGL(k_fh_rank_summary<int32_t>, g, b, 0, s, w, f.tiles_x, (uint32_t)f.nnodes, f.nodes, dem,
+                       (const int32_t *)acc, f.P, kind, ref, nc, nd, zr, ar);
   return DT_OK;
 }
 
 // phase 2: optional rank-exit results (res_* and rem_* indexed by core-ring index), final tile pass
+// `acc` / `a_river` are int32_t* (acc64 == 0) or int64_t* rasters; rem_ar is 64-bit either way
 int dt_launch_fh_finish(hipStream_t s, const DtWin &w, const float *dem, const uint8_t *fdr,
-                        const int8_t *river, const int32_t *acc32, double px, void *scratch,
+                        const int8_t *river, const void *acc, int acc64, double px, void *scratch,
                         const uint8_t *res_ok, const int32_t *res_nc, const int32_t *res_nd,
-                        const long long *rem_gidx, const float *rem_zr, const int32_t *rem_ar, float *fdist,
-                        int32_t *idx32, long long *idx64, float *hand, int32_t *a_river, float *gfi,
+                        const long long *rem_gidx, const float *rem_zr, const long long *rem_ar, float *fdist,
+                        int32_t *idx32, long long *idx64, float *hand, void *a_river, float *gfi,
                         float *lnhlh, double n_gfi, double b_gfi, double size) {
   if (w.H == 0 || w.W == 0) return DT_OK;
   FhScratch f = fh_layout(w, scratch);
@@ -1567,16 +1681,22 @@ int dt_launch_fh_finish(hipStream_t s, const DtWin &w, const float *dem, const u
   FhRemote rem{rem_gidx, rem_zr, rem_ar};
   FhGfi G{nullptr, nullptr, 0.0, 0.0, nullptr};
   if (gfi && lnhlh) {
-    DT_REQUIRE(dem && acc32, "fused GFI needs dem and the accumulation raster");
+    DT_REQUIRE(dem && acc, "fused GFI needs dem and the accumulation raster");
     G = FhGfi{gfi, lnhlh, n_gfi, log(b_gfi) + n_gfi * log(size * size), dt_math_device_table(s)};
   }
   (void)river;
-  if (res_ok || idx64)
-    hipLaunchKernelGGL((k_fh_tile3<true, 1, 5>), gt, b, 0, s, fdr, dem, acc32, w, f.tiles_x, (uint32_t)f.nnodes, f.nodes,
-                       f.cache, f.cache_wide, rem, px, fdist, idx32, idx64, hand, a_river, G);
-  else
-    hipLaunchKernelGGL((k_fh_tile3<false, 1, 5>), gt, b, 0, s, fdr, dem, acc32, w, f.tiles_x, (uint32_t)f.nnodes, f.nodes,
-                       f.cache, f.cache_wide, rem, px, fdist, idx32, idx64, hand, a_river, G);
+  const bool ranked = res_ok || idx64;
+#define FH_GO(R, MW, T)                                                                                                \
+  hipLaunchKernelGGL((k_fh_tile3<R, 1, MW, T>), gt, b, 0, s, fdr, dem, (const T *)acc, w, f.tiles_x, (uint32_t)f.nnodes, \
+                     f.nodes, f.cache, f.cache_wide, rem, px, fdist, idx32, idx64, hand, (T *)a_river, G)
+  if (acc64) {
+    if (ranked) FH_GO(true, 4, long long);
+    else FH_GO(false, 4, long long);
+  } else {
+    if (ranked) FH_GO(true, 5, int32_t);
+    else FH_GO(false, 5, int32_t);
+  }
+#undef FH_GO
   return DT_OK;
 }
 
@@ -1747,7 +1867,7 @@ int dt_launch_rank_solve_flowacc(hipStream_t s, int ty, int tx, const int64_t *h
   return DT_OK;
 }
 
-// ---- HAND: rows = {ref int32, nc int32, nd int32, zr float, ar int32, kind uint8, ringcode uint8} ----
+// ---- HAND: rows = {ref int32, nc int32, nd int32, zr float, ar int64, kind uint8, ringcode uint8} ----
 __global__ __launch_bounds__(256) void k_rk_fh_build(RkLayout L, RkRows R, unsigned long long *__restrict__ nodes) {
   long long n = (long long)blockIdx.x * 256 + threadIdx.x;
   if (n >= (long long)L.nranks * L.Pmax) return;
@@ -1768,12 +1888,12 @@ __global__ __launch_bounds__(256) void k_rk_fh_result(RkLayout L, RkRows R, cons
                                                      int rank, long long P_rank, uint8_t *__restrict__ res_ok,
                                                      int32_t *__restrict__ res_nc, int32_t *__restrict__ res_nd,
                                                      long long *__restrict__ gidx, float *__restrict__ zr,
-                                                     int32_t *__restrict__ ar) {
+                                                     long long *__restrict__ ar) {
   long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= P_rank) return;
   uint8_t ok = 0;
-  int32_t c = 0, d = 0, a = 0;
-  long long g = -100;
+  int32_t c = 0, d = 0;
+  long long g = -100, a = 0;
   float z = DT_NODATA;
   long long e = rk_step_target(L, rank, i, rk_get<uint8_t>(R, 6, rank, i));
   if (e >= 0) {
@@ -1790,7 +1910,7 @@ __global__ __launch_bounds__(256) void k_rk_fh_result(RkLayout L, RkRows R, cons
       int ref = rk_get<int32_t>(R, 0, rt, it);  // core-local flat index of the river cell
       g = (long long)(y0 + ref / W) * L.Wg + x0 + ref % W;
       z = rk_get<float>(R, 3, rt, it);
-      a = rk_get<int32_t>(R, 4, rt, it);
+      a = rk_get<long long>(R, 4, rt, it);
     }
   }
   res_ok[i] = ok;
@@ -1804,7 +1924,7 @@ __global__ __launch_bounds__(256) void k_rk_fh_result(RkLayout L, RkRows R, cons
 int dt_launch_rank_solve_flowhand(hipStream_t s, int ty, int tx, const int64_t *heights, const int64_t *widths,
                                   int64_t Pmax, const void *rows, int64_t rowbytes, const int64_t *offs, int rank,
                                   int64_t P_rank, void *scratch, uint8_t *res_ok, int32_t *res_nc,
-                                  int32_t *res_nd, long long *gidx, float *zr, int32_t *ar) {
+                                  int32_t *res_nd, long long *gidx, float *zr, long long *ar) {
   RkLayout L;
   DT_TRY(rk_make_layout(ty, tx, heights, widths, Pmax, &L));
   RkRows R;

@@ -15,8 +15,12 @@ class PinnedPool:
     gets it.  chain.run_host's rasters come from here."""
 
     def __init__(self):
+        import os
         self._free = {}   # bytes (size class) -> [address]
-        self._live = 0
+        self._idle = 0    # bytes sitting in _free
+        # idle blocks beyond this budget are unlocked and freed when they come back (DT_PINNED_CACHE_MB, default
+        # 4096; 0 = recycle nothing): one run_host on a 16384^2 DEM would otherwise leave ~20 GiB page-locked
+        self.budget = max(int(os.environ.get("DT_PINNED_CACHE_MB", "4096")), 0) << 20
 
     @staticmethod
     def _klass(nbytes):
@@ -30,6 +34,7 @@ class PinnedPool:
         lst = self._free.get(k)
         if lst:
             addr = lst.pop()
+            self._idle -= k
         else:
             out = C.c_void_p()
             check(_lib.lib().dt_host_alloc(k, C.byref(out)))
@@ -40,12 +45,17 @@ class PinnedPool:
         return arr
 
     def _give_back(self, k, addr):
+        if self._idle + k > self.budget:
+            _lib.lib().dt_host_free(C.c_void_p(addr))
+            return
         self._free.setdefault(k, []).append(addr)
+        self._idle += k
 
     def trim(self):
         for k, lst in self._free.items():
             while lst:
                 check(_lib.lib().dt_host_free(C.c_void_p(lst.pop())))
+        self._idle = 0
 
 
 PINNED = PinnedPool()
@@ -129,3 +139,11 @@ class Context:
         if self.h:
             check(_lib.lib().dt_ctx_destroy(self.h))
             self.h = None
+
+
+def trim():
+    """Release what the package caches between calls: the host tier's idle device blocks (dt_host_trim) and the
+    idle page-locked host blocks behind run_host's arrays.  Both caches are bounded anyway (DT_HOST_CACHE_MB,
+    DT_PINNED_CACHE_MB)."""
+    check(_lib.lib().dt_host_trim())
+    PINNED.trim()

@@ -196,7 +196,9 @@ def evaluate_resident(ctx, x_ptr, flood_ptr, n, under='under', nodata=-100.0, de
         # NaN wherever the first cell is nodata -- NaN never compares equal, so pass NaN
         first = np.empty(1, np.float64)
         check(L.dt_dev_d2h(ctx.h, first.ctypes.data_as(C.c_void_p), desc_ptr, 8))
-        nod_val = float(first[0]) if nodata_first is None else nodata_first
+        # (a callable nodata_first is evaluated here, after the extremes are known: a rank that does not own the
+        # global cell [0, 0] learns its scaled value with the extremes exchange)
+        nod_val = float(first[0]) if nodata_first is None else (nodata_first() if callable(nodata_first) else nodata_first)
         under_i = 1 if under == 'under' else 0
 
         def count(ths):

@@ -55,8 +55,9 @@ class Layout:
         # at the core origin); only the last row / column of ranks may be ragged
         assert all(h % 64 == 0 for h in self.heights[:-1]) and all(w % 64 == 0 for w in self.widths[:-1]), \
             "rank tile heights / widths must be multiples of 64 (except the last row / column)"
-        # accumulation rasters are int32 on the device: a rank tile must stay below 2^31 cells; a GLOBAL raster of
-        # >= 2^31 cells is allowed, and a basin that reaches 2^31 cells is detected at run time
+        # a rank tile must stay below 2^31 cells (32-bit in-rank indices).  A GLOBAL raster of >= 2^31 cells is
+        # allowed: its ranks keep the flow accumulation as int64 rasters (RankTile(acc64=...), the reference's own
+        # dtype) -- with int32 rasters a basin that reaches 2^31 cells is detected at run time
         # (DT_STATUS_ACC_OVERFLOW, RankTile.check_status)
         assert all(h * w < 2 ** 31 for h in self.heights for w in self.widths), "a rank tile must have < 2^31 cells"
 
@@ -185,9 +186,9 @@ def solve_flowacc(layout, summaries, max_iter=4096):
 
 
 def solve_flowhand(layout, summaries, ring_codes):
-    """summaries[r] = (kind u8, ref i32, nc i32, nd i32, zr f32, ar i32)[P_r] from
+    """summaries[r] = (kind u8, ref i32, nc i32, nd i32, zr f32, ar i64)[P_r] from
     dt_dev_flowhand_local_w; ring_codes[r] = D8 codes of rank r's ring cells.  Returns per rank
-    (res_ok u8, res_nc i32, res_nd i32, gidx i64, zr f32, ar i32)[P_r] for dt_dev_flowhand_finish_w."""
+    (res_ok u8, res_nc i32, res_nd i32, gidx i64, zr f32, ar i64)[P_r] for dt_dev_flowhand_finish_w."""
     P = [len(s[0]) for s in summaries]
     offs = np.concatenate([[0], np.cumsum(P)]).astype(np.int64)
     n = int(offs[-1])
@@ -195,7 +196,7 @@ def solve_flowhand(layout, summaries, ring_codes):
     nc = np.concatenate([np.asarray(s[2], np.int64) for s in summaries]) if n else np.zeros(0, np.int64)
     nd = np.concatenate([np.asarray(s[3], np.int64) for s in summaries]) if n else np.zeros(0, np.int64)
     zr = np.concatenate([np.asarray(s[4], np.float32) for s in summaries]) if n else np.zeros(0, np.float32)
-    ar = np.concatenate([np.asarray(s[5], np.int32) for s in summaries]) if n else np.zeros(0, np.int32)
+    ar = np.concatenate([np.asarray(s[5], np.int64) for s in summaries]) if n else np.zeros(0, np.int64)
     gidx = np.full(n, -100, np.int64)
     step_tgt = np.full(n, -1, np.int64)  # entry node a ring cell's own D8 step lands on (other rank)
     for r, s in enumerate(summaries):
@@ -241,7 +242,7 @@ def solve_flowhand(layout, summaries, ring_codes):
         tm = term[tt]
         out.append((ok.astype(np.uint8), np.where(ok, nc[tt], 0).astype(np.int32),
                     np.where(ok, nd[tt], 0).astype(np.int32), np.where(ok, gidx[tm], -100).astype(np.int64),
-                    np.where(ok, zr[tm], -100).astype(np.float32), np.where(ok, ar[tm], 0).astype(np.int32)))
+                    np.where(ok, zr[tm], -100).astype(np.float32), np.where(ok, ar[tm], 0).astype(np.int64)))
     return out
 
 
@@ -252,15 +253,18 @@ def solve_flowhand(layout, summaries, ring_codes):
 FA_FIELDS = (("A", "int64", 0), ("xr", "int32", 8), ("code", "uint8", 12), ("ring", "uint8", 13))
 FA_ROW_BYTES = 16
 FH_FIELDS = (("ref", "int32", 0), ("nc", "int32", 4), ("nd", "int32", 8), ("zr", "float32", 12),
-             ("ar", "int32", 16), ("kind", "uint8", 20), ("ring", "uint8", 21))
-FH_ROW_BYTES = 24
+             ("ar", "int64", 16), ("kind", "uint8", 24), ("ring", "uint8", 25))
+FH_ROW_BYTES = 32
 
 
 class RankTile:
     """Extended rasters ((H + 2*HALO) x (W + 2*HALO)) of one rank and the windowed library calls."""
 
     def __init__(self, layout, rank, device=0, stream=None, px=10.0, n_top=0.1, n_gfi=0.4, b=0.1, dz=5.0,
-                 river_threshold=None, halo=HALO, idx64=None):
+                 river_threshold=None, halo=HALO, idx64=None, acc64=None, rasters=None):
+        """acc64: flow accumulation (and the river accumulation payload) as int64 rasters, the reference's dtype --
+        the default for a global raster of >= 2^31 cells, where a basin can exceed 32 bits; int32 rasters otherwise
+        (exact below 2^31 cells, half the bytes).  rasters: names of the rasters to allocate (default: all)."""
         import torch
         from . import _lib
         from .device import Context
@@ -285,15 +289,28 @@ class RankTile:
             idx64 = layout.Hg * layout.Wg > 2 ** 31
         assert idx64 or layout.Hg * layout.Wg <= 2 ** 31
         self.idx_dtype = torch.int64 if idx64 else torch.int32
+        if acc64 is None:
+            acc64 = layout.Hg * layout.Wg >= 2 ** 31
+        self.acc64 = bool(acc64)
+        self.acc_dtype = torch.int64 if self.acc64 else torch.int32
+        sfx = "_a64" if self.acc64 else ""
+        L = self.L
+        self._f_fa_finish = getattr(L, "dt_dev_flowacc_finish_w" + sfx)
+        self._f_slope_twi = getattr(L, "dt_dev_slope_twi_w" + sfx)
+        self._f_fh_local = getattr(L, "dt_dev_flowhand_local_w" + sfx)
+        self._f_fh_finish = getattr(L, "dt_dev_flowhand_finish_w" + sfx)
+        self._f_fh_gfi_finish = getattr(L, "dt_dev_flowhand_gfi_finish_w" + sfx)
+        self._f_gfi_lnhlh = getattr(L, "dt_dev_gfi_lnhlh" + sfx)
         t = {}
         self._on_ts = torch.cuda.stream(self.ts)
         self._on_ts.__enter__()
-        for name, dt in (("dem", torch.float32), ("fdr", torch.uint8), ("fac", torch.int32),
+        for name, dt in (("dem", torch.float32), ("fdr", torch.uint8), ("fac", self.acc_dtype),
                          ("river", torch.int8), ("fdist", torch.float32), ("idx", self.idx_dtype),
-                         ("hand", torch.float32), ("a_river", torch.int32), ("slope", torch.float32),
+                         ("hand", torch.float32), ("a_river", self.acc_dtype), ("slope", torch.float32),
                          ("ti", torch.float32), ("mti", torch.float32), ("gfi", torch.float32),
                          ("lnhlh", torch.float32), ("down", torch.float32)):
-            t[name] = torch.zeros((self.He, self.We), dtype=dt, device=self.dev)
+            if rasters is None or name in rasters:
+                t[name] = torch.zeros((self.He, self.We), dtype=dt, device=self.dev)
         self.t = t
         self.n_unres = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self.win = _lib.Window(self.H, self.W, self.We, self.gy0, self.gx0, layout.Hg, layout.Wg, halo)
@@ -317,7 +334,7 @@ class RankTile:
                      torch.zeros(max(self.P, 1), dtype=torch.int32, device=self.dev),
                      torch.zeros(max(self.P, 1), dtype=torch.int64, device=self.dev),
                      torch.zeros(max(self.P, 1), dtype=torch.float32, device=self.dev),
-                     torch.zeros(max(self.P, 1), dtype=torch.int32, device=self.dev))
+                     torch.zeros(max(self.P, 1), dtype=torch.int64, device=self.dev))
         self._on_ts.__exit__(None, None, None)
         self.ctx.sync()  # the buffers exist and are zero before anybody (any stream) touches them
 
@@ -336,7 +353,9 @@ class RankTile:
 
     # pointer of raster `name` at the core origin
     def p(self, name):
-        t = self.t[name]
+        t = self.t.get(name)
+        if t is None:  # a raster this tile was built without (RankTile(rasters=...))
+            return None
         return t.data_ptr() + (self.halo * self.We + self.halo) * t.element_size()
 
     def core(self, name):
@@ -404,9 +423,9 @@ class RankTile:
         with self.on_stream():
             e = tc.as_tensor(ext.view(np.int64), device=self.dev) if ext is not None else None
         self._keep = e
-        self._chk(self.L.dt_dev_flowacc_finish_w(self.ctx.h, C.byref(self.win), self.p("fdr"), self.p("dem"),
-                                                 e.data_ptr() if e is not None else None,
-                                                 self.river_threshold, self.p("fac"), self.p("river")))
+        self._chk(self._f_fa_finish(self.ctx.h, C.byref(self.win), self.p("fdr"), self.p("dem"),
+                                    e.data_ptr() if e is not None else None,
+                                    self.river_threshold, self.p("fac"), self.p("river")))
 
     def fill_ring_codes(self):
         """D8 codes of the ring cells into both summary rows (the rank-level solves step across ranks with them)."""
@@ -423,13 +442,21 @@ class RankTile:
                                                    self._widths, self.pmax, rows.data_ptr(),
                                                    FA_ROW_BYTES * self.pmax, self._fa_offs, self.rank, self.P,
                                                    self._ext.data_ptr()))
-        self._chk(self.L.dt_dev_flowacc_finish_w(self.ctx.h, C.byref(self.win), self.p("fdr"), self.p("dem"),
-                                                 self._ext.data_ptr(), self.river_threshold, self.p("fac"),
-                                                 self.p("river")))
+        self._chk(self._f_fa_finish(self.ctx.h, C.byref(self.win), self.p("fdr"), self.p("dem"),
+                                    self._ext.data_ptr(), self.river_threshold, self.p("fac"), self.p("river")))
 
     def _idx_args(self):
         """(idx32, idx64) of the windowed HAND calls: the one of the two that matches the idx raster's dtype"""
         return (self.p("idx"), None) if self.idx_dtype == self.torch.int32 else (None, self.p("idx"))
+
+    def free(self):
+        """release the rasters and both contexts"""
+        self.side_ctx.sync()
+        self.ctx.sync()
+        self.t, self._keep, self._keep2, self._keep_rows, self._keep_rows2 = {}, None, None, None, None
+        self.fa_row = self.fh_row = self._ext = self._res = self._fa_v = self._fh_v = None
+        self.side_ctx.close()
+        self.ctx.close()
 
     def fh_solve_finish(self, rows, fuse_gfi=False, want_a_river=True):
         """rank-level HAND solve on the GPU, then pass 3; fuse_gfi: GFI and ln(hl/H) in the same pass (the
@@ -441,23 +468,23 @@ class RankTile:
                                                     FH_ROW_BYTES * self.pmax, self._fh_offs, self.rank, self.P,
                                                     *[a.data_ptr() for a in r]))
         if fuse_gfi:
-            self._chk(self.L.dt_dev_flowhand_gfi_finish_w(
+            self._chk(self._f_fh_gfi_finish(
                 self.ctx.h, C.byref(self.win), self.p("dem"), self.p("fdr"), self.p("river"), self.p("fac"),
                 self.px, self.n_gfi, self.b, *[a.data_ptr() for a in r], self.p("fdist"), *self._idx_args(),
                 self.p("hand"), self.p("a_river") if want_a_river else None, self.p("gfi"), self.p("lnhlh")))
         else:
-            self._chk(self.L.dt_dev_flowhand_finish_w(self.ctx.h, C.byref(self.win), self.p("dem"), self.p("fdr"),
-                                                      self.p("river"), self.p("fac"), self.px,
-                                                      *[a.data_ptr() for a in r], self.p("fdist"),
-                                                      *self._idx_args(), self.p("hand"), self.p("a_river")))
+            self._chk(self._f_fh_finish(self.ctx.h, C.byref(self.win), self.p("dem"), self.p("fdr"),
+                                        self.p("river"), self.p("fac"), self.px,
+                                        *[a.data_ptr() for a in r], self.p("fdist"),
+                                        *self._idx_args(), self.p("hand"), self.p("a_river")))
 
     def fh_local(self, sync=True):
         v = self._fh_v
         kind, ref, nc, nd, zr, ar = v["kind"], v["ref"], v["nc"], v["nd"], v["zr"], v["ar"]
-        self._chk(self.L.dt_dev_flowhand_local_w(self.ctx.h, C.byref(self.win), self.p("dem"), self.p("fdr"),
-                                                 self.p("river"), self.p("fac"), kind.data_ptr(),
-                                                 ref.data_ptr(), nc.data_ptr(), nd.data_ptr(), zr.data_ptr(),
-                                                 ar.data_ptr()))
+        self._chk(self._f_fh_local(self.ctx.h, C.byref(self.win), self.p("dem"), self.p("fdr"),
+                                   self.p("river"), self.p("fac"), kind.data_ptr(),
+                                   ref.data_ptr(), nc.data_ptr(), nd.data_ptr(), zr.data_ptr(),
+                                   ar.data_ptr()))
         if sync:
             self.ctx.sync()
         return kind, ref, nc, nd, zr, ar
@@ -469,22 +496,22 @@ class RankTile:
             with self.on_stream():
                 self._keep2 = [tc.as_tensor(np.ascontiguousarray(a), device=self.dev) for a in res]
             ptrs = [a.data_ptr() for a in self._keep2]
-        self._chk(self.L.dt_dev_flowhand_finish_w(self.ctx.h, C.byref(self.win), self.p("dem"), self.p("fdr"),
-                                                  self.p("river"), self.p("fac"), self.px, ptrs[0], ptrs[1],
-                                                  ptrs[2], ptrs[3], ptrs[4], ptrs[5], self.p("fdist"),
-                                                  *self._idx_args(), self.p("hand"), self.p("a_river")))
+        self._chk(self._f_fh_finish(self.ctx.h, C.byref(self.win), self.p("dem"), self.p("fdr"),
+                                    self.p("river"), self.p("fac"), self.px, ptrs[0], ptrs[1],
+                                    ptrs[2], ptrs[3], ptrs[4], ptrs[5], self.p("fdist"),
+                                    *self._idx_args(), self.p("hand"), self.p("a_river")))
 
     def slope_twi(self):
         """fused slope + TI + MTI on the core window (needs fac)."""
-        self._chk(self.L.dt_dev_slope_twi_w(self.ctx.h, C.byref(self.win), self.p("dem"), self.p("fac"), self.px,
-                                            self.n_top, self.p("slope"), None, self.p("ti"), self.p("mti")))
+        self._chk(self._f_slope_twi(self.ctx.h, C.byref(self.win), self.p("dem"), self.p("fac"), self.px,
+                                    self.n_top, self.p("slope"), None, self.p("ti"), self.p("mti")))
 
     def gfi(self):
         """GFI + ln(hl/H) over the flat extended rasters (halo cells hold zeros and are never read back)."""
         t, n = self.t, self.He * self.We
-        self._chk(self.L.dt_dev_gfi_lnhlh(self.ctx.h, t["hand"].data_ptr(), t["a_river"].data_ptr(),
-                                          t["fac"].data_ptr(), n, self.n_gfi, self.b, self.px,
-                                          t["gfi"].data_ptr(), t["lnhlh"].data_ptr()))
+        self._chk(self._f_gfi_lnhlh(self.ctx.h, t["hand"].data_ptr(), t["a_river"].data_ptr(),
+                                    t["fac"].data_ptr(), n, self.n_gfi, self.b, self.px,
+                                    t["gfi"].data_ptr(), t["lnhlh"].data_ptr()))
 
     def downslope(self, side=False):
         """downslope on the core window (needs only dem + fdr: independent of the exchanges).  side=True:
@@ -686,20 +713,57 @@ class Exchange:
             self._done = None
 
 
-def run_rank(tile, layout, exchange, overlap=False):
-    """One step of one rank.  The two all-gathers are the only communication; the independent kernels
-    (downslope; slope+TI+MTI) are queued between each gather's launch and the wait on it, so they overlap it.
-    overlap=True: downslope instead runs as a second compute branch on its own stream from the D8 kernel
-    to the end of the step (beside the flow kernels as well as the exchanges; chain.Chain's `overlap`).
-    Nothing in the step synchronises with the host."""
+# one rank's step as named stages in launch order: (name, algorithmic bytes per cell -- chain.OPS' definitions; 0 for
+# the exchanges --, what it covers)
+RANK_OPS = (
+    ("d8", 5), ("flowacc_local", 0), ("flowacc_gather", 0), ("downslope", 9), ("flowacc_solve_finish", 6),
+    ("flowhand_local", 2), ("flowhand_gather", 0), ("slope_twi", 20), ("flowhand_gfi_solve_finish", 28),
+)
+
+
+def rank_ops(tile, layout, exchange):
+    """The serial schedule of one rank's step as [(name, call)] in launch order -- what run_rank(overlap=False)
+    executes and bench.py times stage by stage.  The two all-gathers are the only communication; the independent
+    kernels (downslope; slope+TI+MTI) are queued between each gather's launch and the wait on it, so they overlap
+    the transfer.  Nothing synchronises with the host."""
+    st = {}
+
+    def fa_local():
+        tile.fa_local(sync=False)
+        tile.fill_ring_codes()
+
+    def fa_gather():
+        st["fa"] = exchange.gather(tile.fa_row, exchange.fa_all)
+
+    def fa_finish():
+        exchange.wait()
+        tile.fa_solve_finish(st["fa"])
+
+    def fh_gather():
+        st["fh"] = exchange.gather(tile.fh_row, exchange.fh_all)
+
+    def fh_finish():
+        exchange.wait()
+        tile.fh_solve_finish(st["fh"], fuse_gfi=True, want_a_river=False)
+
+    calls = (tile.d8, fa_local, fa_gather, tile.downslope, fa_finish, lambda: tile.fh_local(sync=False), fh_gather,
+             tile.slope_twi, fh_finish)
+    return [(name, fn) for (name, _), fn in zip(RANK_OPS, calls)]
+
+
+def run_rank(tile, layout, exchange, overlap=True):
+    """One step of one rank.  overlap=True (the default, as chain.Chain's): downslope runs as a second compute
+    branch on its own stream from the D8 kernel to the end of the step, beside the flow kernels as well as the
+    exchanges; overlap=False: the serial schedule of rank_ops().  Nothing in the step synchronises with the host."""
+    if not overlap:
+        for _, fn in rank_ops(tile, layout, exchange):
+            fn()
+        return
     tile.d8()
-    if overlap:
-        tile.downslope(side=True)
+    tile.downslope(side=True)
     tile.fa_local(sync=False)
     tile.fill_ring_codes()
     rows = exchange.gather(tile.fa_row, exchange.fa_all)
-    if not overlap:
-        tile.downslope()
     exchange.wait()
     tile.fa_solve_finish(rows)
     tile.fh_local(sync=False)
@@ -707,8 +771,7 @@ def run_rank(tile, layout, exchange, overlap=False):
     tile.slope_twi()
     exchange.wait()
     tile.fh_solve_finish(rows, fuse_gfi=True, want_a_river=False)
-    if overlap:
-        tile.join_side()
+    tile.join_side()
 
 
 def simulate(tiles, layout):
@@ -754,3 +817,85 @@ def simulate_dev(tiles, layout):
         t.fh_solve_finish(rows, fuse_gfi=True)
         t.slope_twi()
         t.downslope()
+
+
+# ---------------------------------------------------------------------------------------------------
+# evaluation of a tiled descriptor (BASELINE.json configs[4]: "full chain + evaluation.py flood-map classifier")
+# ---------------------------------------------------------------------------------------------------
+class DistComm:
+    """all_gather of small host arrays over torch.distributed (RCCL ranks gather through the CPU: the payloads are
+    3-96 numbers per calibration stage)"""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.rank, self.size = dist.get_rank(group), dist.get_world_size(group)
+
+    def all_gather(self, value):
+        out = [None] * self.size
+        self.dist.all_gather_object(out, np.asarray(value), group=self.group)
+        return out
+
+
+class LocalComm:
+    """the same between N logical ranks of ONE process, each running in its own thread (one-GPU rehearsals and
+    tests): gather() is a barrier-synchronised exchange through a shared list"""
+
+    class _Shared:
+        def __init__(self, n):
+            import threading
+            self.n, self.slots, self.barrier = n, [None] * n, threading.Barrier(n)
+
+    def __init__(self, shared, rank):
+        self.sh, self.rank, self.size = shared, rank, shared.n
+
+    @staticmethod
+    def create(n):
+        sh = LocalComm._Shared(n)
+        return [LocalComm(sh, r) for r in range(n)]
+
+    def all_gather(self, value):
+        self.sh.slots[self.rank] = np.asarray(value).copy()
+        self.sh.barrier.wait()
+        out = list(self.sh.slots)
+        self.sh.barrier.wait()  # everybody has read before the next exchange overwrites
+        return out
+
+
+def evaluate_rank(tile, flood_core, comm, name="hand", under="under", class_map=False):
+    """Example/example.py:113-147 on ONE rank's core window of a tiled descriptor raster (default: the HAND this
+    tile's step left in tile.t["hand"]), every rank calling it at the same time: the np.unique extremes are
+    all-gathered and combined (evaluation.combine_extremes), the confusion counts of every calibration stage summed
+    over ranks -- exact integers, so every rank finds the threshold evaluation.calibration finds on the whole raster.
+    flood_core: this rank's window of the benchmark flood map (int8 H x W device tensor, contiguous).  Returns
+    evaluation.evaluate_resident's dict (+ "class_map": int32 H x W device tensor when asked for)."""
+    from . import evaluation
+    tc = tile.torch
+    with tile.on_stream():
+        x = tile.core(name).contiguous()
+        klass = tc.empty((tile.H, tile.W), dtype=tc.int32, device=tile.dev) if class_map else None
+    tile.ctx.sync()
+    assert flood_core.is_contiguous() and flood_core.dtype == tc.int8 and tuple(flood_core.shape) == (tile.H, tile.W)
+    # binary_map's nodata is the scaled value at GLOBAL cell [0, 0] (evaluation.py:111): its owner passes it on
+    own00 = tile.gy0 == 0 and tile.gx0 == 0
+    h00 = float(x[0, 0].item()) if own00 else float("nan")
+    state = {}
+
+    def reduce_extremes(e):
+        rows = comm.all_gather(np.concatenate([np.asarray(e, np.float64), [h00, 1.0 if own00 else 0.0]]))
+        g = evaluation.combine_extremes([r[:3] for r in rows])
+        v00 = [r[3] for r in rows if r[4] == 1.0][0]
+        mn, mx = np.float32(g[1]), np.float32(g[2])
+        state["first"] = float("nan") if v00 == -100.0 or v00 != v00 else float((np.float32(v00) - mn) / (mx - mn))
+        return g
+
+    def reduce_counts(c):
+        return np.sum(comm.all_gather(np.asarray(c, np.int64)), axis=0)
+
+    res = evaluation.evaluate_resident(tile.ctx, x.data_ptr(), flood_core.data_ptr(), tile.H * tile.W, under,
+                                       reduce_extremes=reduce_extremes, reduce_counts=reduce_counts,
+                                       nodata_first=lambda: state["first"],
+                                       class_ptr=klass.data_ptr() if class_map else None)
+    if class_map:
+        res["class_map"] = klass
+    return res

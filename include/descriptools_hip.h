@@ -54,7 +54,8 @@ const char *dt_version(void);
 int dt_set_flow_impl(int impl);
 /* Test knobs, all 0 by default.  key 0 (DT_DBG_TWI_FLAG_ALL): the fused slope + TI + MTI stencil sends every
  * cell through its exact (cold) path as well as the fast one; key 1 (DT_DBG_TWI_PLAIN): default cache policy
- * instead of non-temporal loads / stores in that stencil (A/B timing). */
+ * instead of non-temporal loads / stores in that stencil (A/B timing); key 2 (DT_DBG_TWI_WX): tile geometry of that
+ * stencil, 1 / 2 / 4 = tiles of 256 x 16 / 512 x 8 / 1024 x 4 cells (0 = the default). */
 int dt_debug_set(int key, int value);
 
 /* Context = one device + one stream + grow-only scratch.  `stream` may be NULL (the context
@@ -83,8 +84,9 @@ int dt_ctx_capture_end(dt_ctx *ctx, dt_graph **out);
 int dt_graph_launch(dt_graph *graph, dt_ctx *ctx);
 int dt_graph_destroy(dt_graph *graph);
 /* Sticky status bits raised by kernels since the last call (synchronises the context's stream, clears them).
- * DT_STATUS_ACC_OVERFLOW: a flow accumulation value of a multi-rank raster may have reached 2^31 cells; the device
- * accumulation rasters are int32 (a device tile is < 2^31 cells), so the results of that step are not valid. */
+ * DT_STATUS_ACC_OVERFLOW: a flow accumulation value of a multi-rank raster may have reached 2^31 cells while the step
+ * ran with int32 accumulation rasters (the `_w` entry points; a device tile is < 2^31 cells), so its results are
+ * not valid: rasters of >= 2^31 cells go through the `_w_a64` entry points (int64 rasters), which never raise it. */
 #define DT_STATUS_ACC_OVERFLOW 1
 int dt_ctx_status(dt_ctx *ctx, int32_t *out);
 int64_t dt_ctx_scratch_bytes(dt_ctx *ctx);
@@ -249,7 +251,8 @@ int dt_dev_downslope_w(dt_ctx *ctx, const dt_window *win, const float *dem, cons
                        double elevation_difference, int raw, float *out, int32_t *n_unresolved_dev);
 /* phase 1: in-rank accumulation; per ring cell: A = cells of this rank draining OUT through it (0 unless
  * its D8 step leaves the core), code = that step's D8 code, xr = ring index of the rank exit reached by
- * a path ENTERING at this cell (-1 none, -2 cycle inside the rank) */
+ * a path ENTERING at this cell (-1 none, -2 cycle inside the rank).  acc32 is not touched by this phase (the raster
+ * is written by dt_dev_flowacc_finish_w / _w_a64) and may be NULL. */
 int dt_dev_flowacc_local_w(dt_ctx *ctx, const dt_window *win, const uint8_t *fdr, int32_t *acc32,
                            int64_t *A_perim, int32_t *xr_perim, uint8_t *code_perim);
 /* phase 2: ext_perim[i] = inflow arriving at ring cell i from other ranks (bit 63: fed by a D8 cycle
@@ -258,10 +261,11 @@ int dt_dev_flowacc_finish_w(dt_ctx *ctx, const dt_window *win, const uint8_t *fd
                             const uint64_t *ext_perim, int64_t threshold, int32_t *acc32, int8_t *river);
 /* phase 1: per ring cell, the path ENTERING the rank there: kind 1 = ends on river cell `ref` (core-local
  * flat index; zr / ar = its height / accumulation), 2 = dead, 4 = leaves the rank again through ring
- * cell `ref`; nc / nd = cardinal / diagonal moves (kind 4: including the step out of the rank) */
+ * cell `ref`; nc / nd = cardinal / diagonal moves (kind 4: including the step out of the rank).  Everything that
+ * crosses ranks carries accumulations as int64 (ar here, rem_ar below), whatever the rasters' width. */
 int dt_dev_flowhand_local_w(dt_ctx *ctx, const dt_window *win, const float *dem, const uint8_t *fdr,
                             const int8_t *river, const int32_t *acc32, uint8_t *kind, int32_t *ref,
-                            int32_t *nc, int32_t *nd, float *zr, int32_t *ar);
+                            int32_t *nc, int32_t *nd, float *zr, int64_t *ar);
 /* phase 2: for every ring cell whose step leaves the rank: res_ok != 0 -> that path ends on a river
  * cell after res_nc / res_nd further moves, global flat index rem_gidx, height rem_zr, accumulation
  * rem_ar (all NULL = no other ranks).  idx64 (may be NULL) receives GLOBAL flat indices; so does idx32 (may be NULL)
@@ -270,14 +274,42 @@ int dt_dev_flowhand_local_w(dt_ctx *ctx, const dt_window *win, const float *dem,
 int dt_dev_flowhand_finish_w(dt_ctx *ctx, const dt_window *win, const float *dem, const uint8_t *fdr,
                              const int8_t *river, const int32_t *acc32, double px, const uint8_t *res_ok,
                              const int32_t *res_nc, const int32_t *res_nd, const int64_t *rem_gidx,
-                             const float *rem_zr, const int32_t *rem_ar, float *fdist, int32_t *idx32,
+                             const float *rem_zr, const int64_t *rem_ar, float *fdist, int32_t *idx32,
                              int64_t *idx64, float *hand, int32_t *a_river);
 int dt_dev_flowhand_gfi_finish_w(dt_ctx *ctx, const dt_window *win, const float *dem, const uint8_t *fdr,
                                  const int8_t *river, const int32_t *acc32, double px, double n_gfi, double b,
                                  const uint8_t *res_ok, const int32_t *res_nc, const int32_t *res_nd,
-                                 const int64_t *rem_gidx, const float *rem_zr, const int32_t *rem_ar,
+                                 const int64_t *rem_gidx, const float *rem_zr, const int64_t *rem_ar,
                                  float *fdist, int32_t *idx32, int64_t *idx64, float *hand, int32_t *a_river,
                                  float *gfi, float *lnhlh);
+
+/* ---- the same steps on int64 accumulation rasters (`_a64`).  The reference's flow accumulation is int64 end to
+ * end (Example/example.py:39 reads it as int64; topoindexes.py:252-261, gfi.py:141-143 and :432-440 consume it).  On
+ * the device a raster below 2^31 cells keeps it as int32 (half the bytes, exact); a raster of >= 2^31 cells split
+ * over ranks -- BASELINE.json configs[4], 65536^2 -- can hold basins beyond 32 bits, and its ranks run these entry
+ * points instead: accumulation, river accumulation payload and every consumer (TI / MTI, HAND's river payload, GFI,
+ * ln(hl/H)) in 64 bits; DT_STATUS_ACC_OVERFLOW is never raised.  dt_dev_flowacc_local_w, the rank-level solves and
+ * dt_dev_downslope_w do not touch the accumulation raster and are shared. */
+int dt_dev_flowacc_finish_w_a64(dt_ctx *ctx, const dt_window *win, const uint8_t *fdr, const float *dem,
+                                const uint64_t *ext_perim, int64_t threshold, int64_t *acc64, int8_t *river);
+int dt_dev_slope_twi_w_a64(dt_ctx *ctx, const dt_window *win, const float *dem, const int64_t *acc64, double px,
+                           double n_top, float *slope, float *slope_rad, float *ti, float *mti);
+int dt_dev_flowhand_local_w_a64(dt_ctx *ctx, const dt_window *win, const float *dem, const uint8_t *fdr,
+                                const int8_t *river, const int64_t *acc64, uint8_t *kind, int32_t *ref,
+                                int32_t *nc, int32_t *nd, float *zr, int64_t *ar);
+int dt_dev_flowhand_finish_w_a64(dt_ctx *ctx, const dt_window *win, const float *dem, const uint8_t *fdr,
+                                 const int8_t *river, const int64_t *acc64, double px, const uint8_t *res_ok,
+                                 const int32_t *res_nc, const int32_t *res_nd, const int64_t *rem_gidx,
+                                 const float *rem_zr, const int64_t *rem_ar, float *fdist, int32_t *idx32,
+                                 int64_t *idx64, float *hand, int64_t *a_river64);
+int dt_dev_flowhand_gfi_finish_w_a64(dt_ctx *ctx, const dt_window *win, const float *dem, const uint8_t *fdr,
+                                     const int8_t *river, const int64_t *acc64, double px, double n_gfi, double b,
+                                     const uint8_t *res_ok, const int32_t *res_nc, const int32_t *res_nd,
+                                     const int64_t *rem_gidx, const float *rem_zr, const int64_t *rem_ar,
+                                     float *fdist, int32_t *idx32, int64_t *idx64, float *hand,
+                                     int64_t *a_river64, float *gfi, float *lnhlh);
+int dt_dev_gfi_lnhlh_a64(dt_ctx *ctx, const float *hand, const int64_t *a_river64, const int64_t *acc64, int64_t N,
+                         double n_gfi, double scale_factor, double size, float *gfi, float *lnhlh);
 
 /* evaluation on resident rasters.  out3_dev (device float[3]) = smallest,
  * second-smallest distinct and largest value of x, i.e. np.unique(x)[0], [1], [-1] as
@@ -309,7 +341,7 @@ int dt_dev_membench_copy(dt_ctx *ctx, const float *a, float *b, int64_t N, int b
  * entries.  heights / widths (host) describe the ty x tx rank grid.
  *   flow accumulation fields: {A int64, xr int32, code uint8} (the outputs of dt_dev_flowacc_local_w)
  *     -> ext_out_dev[P_rank] for dt_dev_flowacc_finish_w
- *   HAND fields: {ref int32, nc int32, nd int32, zr float, ar int32, kind uint8, ring D8 code uint8}
+ *   HAND fields: {ref int32, nc int32, nd int32, zr float, ar int64, kind uint8, ring D8 code uint8}
  *     -> the res_* / rem_* arrays [P_rank] for dt_dev_flowhand_finish_w */
 int dt_dev_rank_solve_flowacc(dt_ctx *ctx, int ty, int tx, const int64_t *heights, const int64_t *widths,
                               int64_t Pmax, const void *rows_dev, int64_t rowbytes,
@@ -318,7 +350,7 @@ int dt_dev_rank_solve_flowhand(dt_ctx *ctx, int ty, int tx, const int64_t *heigh
                                int64_t Pmax, const void *rows_dev, int64_t rowbytes,
                                const int64_t *field_offsets7, int rank, int64_t P_rank, uint8_t *res_ok,
                                int32_t *res_nc, int32_t *res_nd, int64_t *rem_gidx, float *rem_zr,
-                               int32_t *rem_ar);
+                               int64_t *rem_ar);
 
 /* widen / narrow helpers for the int64 API dtypes */
 int dt_dev_i32_to_i64(dt_ctx *ctx, const int32_t *src, int64_t N, int64_t *dst);

@@ -13,6 +13,9 @@ def test_config4_32768_tiled_2x2_equals_untiled():
     import torch
     from descriptools_amd import _lib, chain, tiling
     from descriptools_amd.device import Context
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
     free, total = torch.cuda.mem_get_info()
     if total < 200 * 2 ** 30:
         pytest.skip("needs an MI355X-sized HBM (288 GB)")
@@ -100,3 +103,7 @@ def test_config4_32768_tiled_2x2_equals_untiled():
         want = torch.where(li >= 0, gy * n + gx, li)
         assert gi.dtype == torch.int32  # 2^30 cells: the 32-bit global index
         assert torch.equal(gi.long(), want), (tl.rank, "idx")
+        tl.free()
+    del tiles, t, keep, dem
+    gc.collect()
+    torch.cuda.empty_cache()

@@ -65,3 +65,67 @@ def test_conditioning_reproduces_the_bundled_rasters_in_the_main():
           "median |ln ratio| where both > 100 cells: %.4f" % (a_all, a_flat, int(flat.sum()), eq, med))
     assert flat.sum() == 223054
     assert a_all > 0.96 and a_flat > 0.87 and eq > 0.74 and med < 0.02
+
+
+def _serpentine(H, W, walls=1):
+    """a channel that meanders through the whole raster between 1-cell walls: rows of channel alternate with rows of
+    wall, joined at alternating ends.  Returns the boolean channel mask and the order of its cells along the path."""
+    chan = np.zeros((H, W), bool)
+    order = []
+    left = True
+    for y in range(1, H - 1, 1 + walls):
+        xs = list(range(1, W - 1))
+        if not left:
+            xs.reverse()
+        for x in xs:
+            chan[y, x] = True
+            order.append((y, x))
+        left = not left
+        if y + 1 + walls < H - 1:  # the connector through the wall rows, at the end the row finished on
+            xe = xs[-1]
+            for k in range(1, 1 + walls):
+                chan[y + k, xe] = True
+                order.append((y + k, xe))
+    return chan, order
+
+
+def test_conditioning_serpentine_depression_across_many_tiles():
+    """the spill path of a depression may cross tile borders far more often than the raster has tiles.
+    A closed basin whose floor is a serpentine channel between high 1-cell walls (192 x 192 = 9 tiles; the channel
+    crosses a 64-cell tile border ~190 times), rising towards its single outlet: filling it is a chain of thousands
+    of dependent relaxations along the channel.  Must converge to the oracle's priority flood, bit for bit."""
+    H = W = 192
+    dem = np.full((H, W), 500.0, np.float32)  # walls and rim
+    chan, order = _serpentine(H, W)
+    n = len(order)
+    # the channel floor RISES along the path towards the outlet at its far end, with pits every 7 cells: every pit
+    # spills over the next sill, information travels the whole channel
+    for k, (y, x) in enumerate(order):
+        dem[y, x] = 10.0 + 0.01 * k - (3.0 if k % 7 == 3 else 0.0)
+    ye, xe = order[-1]
+    dem[ye:, xe] = np.minimum(dem[ye:, xe], 10.0 + 0.01 * n)  # cut the rim below the channel's end: the outlet
+    from descriptools_amd import _lib
+    import ctypes as C
+    fdr, filled, acc = _check(dem, 10.0)
+    assert (filled[chan] >= dem[chan]).all() and (filled[chan] > dem[chan]).sum() > n // 8
+    info = (C.c_int32 * 3)()
+    f2 = np.empty((H, W), np.uint8)
+    _lib.check(_lib.lib().dt_d8_conditioned_f32(_lib.ptr(np.ascontiguousarray(dem), _lib.c_f32p), H, W, 10.0,
+                                                _lib.ptr(f2, _lib.c_u8p), None, info))
+    print("serpentine depression: %d fill rounds, %d flat rounds for %d tiles" % (info[1], info[2], 9))
+    assert info[0] == 0 and np.array_equal(f2, fdr)
+
+
+def test_conditioning_spiral_flat_across_many_tiles():
+    """the same for the flat router: one perfectly flat serpentine channel (a single plateau 18,000 cells long, walls
+    higher) with its only lower neighbour at one end -- the hop distances grow along the whole channel, through every
+    tile many times."""
+    H = W = 192
+    dem = np.full((H, W), 500.0, np.float32)
+    chan, order = _serpentine(H, W)
+    dem[chan] = 100.0
+    ye, xe = order[-1]
+    dem[ye + 1:, xe] = 50.0  # below the channel's last cell: the plateau's only way out
+    fdr, filled, acc = _check(dem, 10.0)
+    assert np.array_equal(filled, dem)
+    assert acc[ye + 1, xe] >= len(order), "the whole plateau drains through the gap below its far end"

@@ -24,9 +24,11 @@ def _global_dem(seed, Hg, Wg, nod):
     ([128, 128, 128], [128, 256, 128], 2, 4),  # 3 x 3
     ([384], [512], 0, 5),                  # 1 x 1 through the windowed entry points
 ])
-def test_tiled_equals_untiled(heights, widths, nod, seed, solver):
+def test_tiled_equals_untiled(heights, widths, nod, seed, solver, acc64=None):
     """solver "device" = the product's rank-level solves (dt_dev_rank_solve_*), "numpy" = their host
-    restatement in tiling.py (test infrastructure for the gloo rehearsals)."""
+    restatement in tiling.py (test infrastructure for the gloo rehearsals).  acc64: the ranks keep the flow
+    accumulation as int64 rasters (what a global raster of >= 2^31 cells gets), forced here at small sizes."""
+    import torch
     from descriptools_amd import chain, tiling
     layout = tiling.Layout(heights, widths)
     Hg, Wg = layout.Hg, layout.Wg
@@ -39,7 +41,8 @@ def test_tiled_equals_untiled(heights, widths, nod, seed, solver):
     tiles = []
     for r in range(layout.size):
         # the river index raster in both widths (int64 is what a global raster beyond 2^31 cells gets)
-        t = tiling.RankTile(layout, r, device=0, px=px, river_threshold=thr, idx64=(seed % 2 == 0))
+        t = tiling.RankTile(layout, r, device=0, px=px, river_threshold=thr, idx64=(seed % 2 == 0), acc64=acc64)
+        assert t.t["fac"].dtype == (torch.int64 if acc64 else torch.int32)
         y0, x0 = layout.origin(r)
         t.set_dem_ext(pad[y0:y0 + t.He, x0:x0 + t.We])
         tiles.append(t)
@@ -249,6 +252,18 @@ def test_move_cap_through_tiles_and_ranks():
 ])
 def test_tiled_2x4_equals_untiled(heights, widths, nod, seed):
     test_tiled_equals_untiled(heights, widths, nod, seed, "device")
+
+
+@pytest.mark.parametrize("solver", ["device", "numpy"])
+@pytest.mark.parametrize("heights,widths,nod,seed", [
+    ([192, 192], [256, 256], 0, 1),
+    ([192, 130], [256, 200], 2, 6),                 # ragged, nodata
+    ([256, 150], [128, 128, 192, 100], 3, 9),       # 2 x 4
+    ([384], [512], 0, 5),                           # 1 x 1
+])
+def test_tiled_int64_accumulation_equals_untiled(heights, widths, nod, seed, solver):
+    """the int64 accumulation path (every `_a64` entry point) against the untiled chain, raster for raster"""
+    test_tiled_equals_untiled(heights, widths, nod, seed, solver, acc64=True)
 
 
 def test_tiled_2x4_flowacc_cycles_across_ranks():

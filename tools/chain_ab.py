@@ -52,7 +52,7 @@ p, c = ch.p, ctx.h
 full = _lib.Window(H, W, W, 0, 0, H, W, 0)
 P = int(L.dt_perim_cells(H, W))
 ring = [torch.empty(max(P, 1), dtype=d, device="cuda") for d in (torch.uint8, torch.int32, torch.int32, torch.int32,
-                                                                  torch.float32, torch.int32)]
+                                                                  torch.float32, torch.int64)]
 OPS = {
     "d8": lambda: L.dt_dev_slope_d8(c, dem.data_ptr(), H, W, 10.0, None, p("fdr"), None),
     "downslope": lambda: L.dt_dev_downslope(c, dem.data_ptr(), p("fdr"), H, W, 10.0, 5.0, 0, p("down")),
