@@ -47,6 +47,7 @@ _SIGS = {
     "dt_flowacc_u8": (ci, [c_u8p, c_f32p, i64, i64, c_i64p]),
     "dt_d8_conditioned_f32": (ci, [c_f32p, i64, i64, f64, c_u8p, c_f32p, c_i32p]),
     "dt_dev_condition_d8": (ci, [vp, vp, i64, i64, f64, vp, vp, c_i32p]),
+    "dt_dev_condition_d8_async": (ci, [vp, vp, i64, i64, f64, vp, vp, ci]),
     "dt_flowhand": (ci, [c_f32p, c_u8p, c_i8p, i64, i64, f64, c_f32p, c_i64p, c_f32p]),
     "dt_hand_f32": (ci, [c_f32p, c_i64p, i64, c_f32p]),
     "dt_twi": (ci, [c_i64p, c_f32p, i64, f64, f64, c_f32p, c_f32p]),
@@ -86,6 +87,7 @@ _SIGS = {
     "dt_dev_unique_extremes_f32": (ci, [vp, vp, i64, vp]),
     "dt_dev_minmax_scale_f32": (ci, [vp, vp, i64, C.c_float, C.c_float, C.c_float, vp]),
     "dt_dev_membench_copy": (ci, [vp, vp, vp, i64, ci]),
+    "dt_dev_membench_mix": (ci, [vp, vp, vp, vp, vp, vp, i64, ci, ci, ci]),
     "dt_dev_minmax_scale_f32_f64": (ci, [vp, vp, i64, f64, f64, f64, vp]),
     "dt_dev_classify": (ci, [vp, vp, vp, i64, f64, f64, ci, ci, vp, vp, vp]),
     "dt_minmax_scale": (ci, [vp, ci, i64, f64, f64, f64, vp]),
@@ -178,6 +180,33 @@ def as_c(a, dtype):
     return np.ascontiguousarray(a, dtype=dtype)
 
 
-def dem_f32(dem):
-    """DEM / HAND at the boundary: float32 (exact for int16 and for float32 input)."""
-    return np.ascontiguousarray(dem, dtype=np.float32)
+_EXACT_IN_F32 = (np.float32, np.float16, np.int8, np.uint8, np.int16, np.uint16, np.bool_)
+
+
+def dem_f32(dem, what="DEM"):
+    """DEM / HAND at the boundary: float32 on the device.
+
+    The reference takes height differences in the DEM's OWN dtype (slope.py:244-258 under Numba typing,
+    flowhand.py:436-438 `dem - dem[indices]`, downslope.py:468); the kernels take them in float32.  That is the same
+    arithmetic exactly when every height is a float32 value: int8 / int16 / float16 / float32 rasters always, wider
+    dtypes (float64, int32, int64) when their values happen to be representable -- a float64 array holding float32
+    values, integer heights below 2^24.  Anything else would silently lose the sub-float32 differences the reference
+    keeps, so it is refused with a ValueError (set DT_ALLOW_DEM_ROUNDING=1 to round to float32 knowingly)."""
+    a = np.asarray(dem)
+    d32 = np.ascontiguousarray(a, dtype=np.float32)
+    if a.dtype.type in _EXACT_IN_F32 or os.environ.get("DT_ALLOW_DEM_ROUNDING") == "1":
+        return d32
+    flat, f32 = a.reshape(-1), d32.reshape(-1)
+    step = 1 << 24  # blockwise: no second full-size temporary
+    for i in range(0, flat.size, step):
+        blk = flat[i:i + step]
+        back = f32[i:i + step].astype(a.dtype)
+        same = (back == blk) | ((back != back) & (blk != blk)) if a.dtype.kind == "f" else (back == blk)
+        if not same.all():
+            k = i + int(np.argmin(same))
+            raise ValueError(
+                "%s of dtype %s is not exactly representable in float32 (first at flat index %d: %r -> %r): the "
+                "reference computes height differences in the raster's own dtype, this library in float32.  Pass "
+                "float32-exact heights (or set DT_ALLOW_DEM_ROUNDING=1 to accept the rounding)"
+                % (what, a.dtype, k, flat[k].item(), f32[k].item()))
+    return d32

@@ -40,11 +40,18 @@ class Chain:
     """Owns the output rasters of one H x W tile on one device."""
 
     def __init__(self, H, W, ctx=None, px=10.0, n_top=0.1, n_gfi=0.4, b=0.1, dz=5.0,
-                 river_threshold=None, alloc=None, want_slope_rad=True, side_ctx=None, overlap=True):
+                 river_threshold=None, alloc=None, want_slope_rad=True, side_ctx=None, overlap=True,
+                 condition=False, condition_rounds=64):
         """overlap (the default): downslope runs as a second branch on its own stream (side_ctx, created on demand)
         beside the flow-accumulation / HAND kernels, whose latency chains leave most of the GPU idle: ~3-5 % faster
         end to end at 16384^2.  overlap=False: one stream, kernels back to back (what per-kernel timings need:
-        ops(serial=True) gives that order on a chain built either way)."""
+        ops(serial=True) gives that order on a chain built either way).
+        condition: the D8 codes come from the hydrologically conditioned surface (depressions filled, flats routed:
+        dt_dev_condition_d8_async) instead of the plain steepest descent, for DEMs with pits and
+        flats; the descriptors themselves keep using the DEM as given (as the reference's example does with a D8
+        raster from a GIS tool, Example/example.py:36).  Nothing synchronises: `condition_rounds` fill / flat rounds
+        are enqueued, and check_status() raises afterwards if that budget was too small for the raster."""
+        self.condition, self.condition_rounds = bool(condition), int(condition_rounds)
         self.want_slope_rad = want_slope_rad
         self.H, self.W, self.N = int(H), int(W), int(H) * int(W)
         self.ctx = ctx or Context()
@@ -56,7 +63,7 @@ class Chain:
         self.river_threshold = self.N // 512 if river_threshold is None else int(river_threshold)
         self.buf = {}
         self._graphs = []
-        for name, dt in OUTPUTS:
+        for name, dt in OUTPUTS + ((("filled", F32),) if self.condition else ()):
             self.buf[name] = alloc((H, W), dt) if alloc else self.ctx.empty((H, W), dt)
 
     def p(self, name):
@@ -77,8 +84,12 @@ class Chain:
             self._ring = [c.empty(P, dt) for dt in (np.uint8, np.int32, np.int32, np.int32, np.float32, np.int64)]
         full, ring = self._full, [r.ptr for r in self._ring]
         rad = p("slope_rad") if self.want_slope_rad else None
+        first = ("d8", c, lambda: L.dt_dev_slope_d8(c.h, dem_ptr, H, W, self.px, None, p("fdr"), None))
+        if self.condition:
+            first = ("condition_d8", c, lambda: L.dt_dev_condition_d8_async(c.h, dem_ptr, H, W, self.px, p("filled"),
+                                                                             p("fdr"), self.condition_rounds))
         return [
-            ("d8", c, lambda: L.dt_dev_slope_d8(c.h, dem_ptr, H, W, self.px, None, p("fdr"), None)),
+            first,
             ("downslope", side, lambda: L.dt_dev_downslope(side.h, dem_ptr, p("fdr"), H, W, self.px, self.dz, 0,
                                                            p("down"))),
             ("flowacc_river", c, lambda: L.dt_dev_flowacc_river(c.h, p("fdr"), dem_ptr, H, W, self.river_threshold,
@@ -102,6 +113,11 @@ class Chain:
             check(call())
         if self.side is not None:
             self.ctx.join(self.side)
+
+    def check_status(self):
+        """raise if a kernel of the steps so far flagged a condition that invalidates their rasters (conditioning out
+        of rounds); synchronises"""
+        self.ctx.raise_on_status()
 
     def capture(self, dem_ptr, want_a_river=True):
         """The step as a HIP graph: runs it once (workspaces, tables), records a second run, returns a `Graph` whose

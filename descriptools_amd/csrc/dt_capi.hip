@@ -399,6 +399,20 @@ extern "C" int dt_dev_condition_d8(dt_ctx *c, const float *dem, int64_t H, int64
   return DT_OK;
 }
 
+extern "C" int dt_dev_condition_d8_async(dt_ctx *c, const float *dem, int64_t H, int64_t W, double px, float *filled,
+                                         uint8_t *fdr, int rounds) {
+  DT_CTX(c);
+  DT_TRY(dt_check_hw(H, W));
+  DT_REQUIRE((dem && filled && fdr) || H * W == 0, "NULL raster");
+  size_t need = dt_hydro_scratch(H, W);
+  DT_TRY(dt_scratch_reset(c, need));
+  void *scr = dt_scratch_take(c, need);
+  DT_TRY(dt_side_reserve(c, &c->aux, &c->aux_bytes, dt_stencil_aux_bytes(H, W)));
+  DT_TRY(dt_launch_condition_async(c->stream, dem, H, W, px, filled, fdr, scr, rounds, c->status));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+
 extern "C" int dt_dev_flowacc(dt_ctx *c, const uint8_t *fdr, const float *dem, int64_t H, int64_t W,
                               int32_t *acc32) {
   DT_CTX(c);
@@ -607,6 +621,16 @@ extern "C" int dt_dev_membench_copy(dt_ctx *c, const float *a, float *b, int64_t
   DT_CTX(c);
   DT_REQUIRE(a && b && N >= 0 && blocks != 0, "bad arguments");
   DT_TRY(dt_launch_membench_copy(c->stream, a, b, N, blocks));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+
+extern "C" int dt_dev_membench_mix(dt_ctx *c, const float *r0, const float *r1, float *w0, float *w1, float *w2,
+                                   int64_t N, int n_reads, int n_writes, int nontemporal) {
+  DT_CTX(c);
+  DT_REQUIRE((n_reads < 1 || r0) && (n_reads < 2 || r1) && w0 && (n_writes < 2 || w1) && (n_writes < 3 || w2),
+             "NULL stream");
+  DT_TRY(dt_launch_membench_mix(c->stream, r0, r1, w0, w1, w2, N, n_reads, n_writes, nontemporal));
   DT_HIP(hipGetLastError());
   return DT_OK;
 }

@@ -61,9 +61,13 @@ __device__ __forceinline__ void hy_stage(T *s, const T *__restrict__ src, int H,
 }
 
 // one round of the fill: every tile to its local fixed point
+// `prev` (may be NULL): the previous round's flag -- a round that follows a quiet one has nothing to do and
+// returns at once (the asynchronous form enqueues a fixed budget of rounds and never asks the host)
 __global__ __launch_bounds__(256) void k_fill_relax(const float *__restrict__ dem, float *__restrict__ wsurf, int H,
-                                                   int W, int tiles_x, int *__restrict__ changed) {
+                                                   int W, int tiles_x, int *__restrict__ changed,
+                                                   const int *__restrict__ prev) {
   __shared__ float s_w[HLD * HLD];
+  if (prev && __hip_atomic_load(prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
   const int y0 = ty * HT, x0 = tx * HT;
   // outside the raster and nodata both read as +inf: they never lower a minimum (cells next to them are outlets
@@ -151,9 +155,11 @@ __global__ __launch_bounds__(256) void k_flat_init(const float *__restrict__ wsu
 
 // one round of the flat distances: d(c) = 1 + min d(n) over neighbours of the same filled height
 __global__ __launch_bounds__(256) void k_flat_relax(const float *__restrict__ wsurf, uint32_t *__restrict__ dist, int H,
-                                                   int W, int tiles_x, int *__restrict__ changed) {
+                                                   int W, int tiles_x, int *__restrict__ changed,
+                                                   const int *__restrict__ prev) {
   __shared__ float s_w[HLD * HLD];
   __shared__ uint32_t s_d[HLD * HLD];
+  if (prev && __hip_atomic_load(prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
   const int y0 = ty * HT, x0 = tx * HT;
   hy_stage<float>(s_w, wsurf, H, W, y0, x0, DT_NODATA);
@@ -223,7 +229,17 @@ __global__ __launch_bounds__(256) void k_flat_assign(const float *__restrict__ w
 }
 
 // scratch: flag words (256 B) + the distance raster
-size_t dt_hydro_scratch(int64_t H, int64_t W) { return 256 + dt_align256((size_t)H * W * 4); }
+// asynchronous form: the round flags (2 x up to DT_HYDRO_MAX_ASYNC_ROUNDS + the unresolved count) live in the
+// first 4 KiB
+#define DT_HYDRO_FLAG_BYTES 4096
+#define DT_HYDRO_MAX_ASYNC_ROUNDS 500
+size_t dt_hydro_scratch(int64_t H, int64_t W) { return DT_HYDRO_FLAG_BYTES + dt_align256((size_t)H * W * 4); }
+
+// raise the context's status when the budget of rounds did not reach the fixed point, or a flat cell got no code
+__global__ void k_hydro_verdict(const int *__restrict__ last_fill, const int *__restrict__ last_flat,
+                                const int *__restrict__ unresolved, int *__restrict__ status) {
+  if ((*last_fill != 0 || *last_flat != 0 || *unresolved != 0) && status) atomicOr(status, DT_STATUS_NOT_CONVERGED);
+}
 
 // iterate `round` (a launch of one relaxation round over all tiles) until a whole batch changes nothing
 // Termination: both relaxations are monotone (values only decrease) and every round contains at least one sweep over
@@ -259,20 +275,20 @@ int dt_launch_condition(hipStream_t s, const float *dem, int64_t H, int64_t W, d
   const int64_t n = H * W;
   if (n == 0) return DT_OK;
   int *flag = (int *)scratch;
-  uint32_t *dist = (uint32_t *)((char *)scratch + 256);
+  uint32_t *dist = (uint32_t *)((char *)scratch + DT_HYDRO_FLAG_BYTES);
   const int tiles_x = (int)((W + HT - 1) / HT), tiles_y = (int)((H + HT - 1) / HT);
   dim3 gc((unsigned)((n + 255) / 256)), gt((unsigned)(tiles_x * tiles_y)), b(256);
   hipLaunchKernelGGL(k_fill_init, gc, b, 0, s, dem, (int)H, (int)W, filled);
   int r1 = 0, r2 = 0;
   const int64_t max_rounds = n + 8;
-  DT_TRY(hy_iterate(s, flag, max_rounds, [&] { hipLaunchKernelGGL(k_fill_relax, gt, b, 0, s, dem, filled, (int)H, (int)W, tiles_x, flag); },
+  DT_TRY(hy_iterate(s, flag, max_rounds, [&] { hipLaunchKernelGGL(k_fill_relax, gt, b, 0, s, dem, filled, (int)H, (int)W, tiles_x, flag, (const int *)nullptr); },
                     &r1));
   if (fdr) {
     DtWin w;
     w.H = (int)H; w.W = (int)W; w.ld = W; w.gy0 = 0; w.gx0 = 0; w.Hg = (int)H; w.Wg = (int)W; w.halo = 0;
     DT_TRY(dt_launch_stencil(s, w, filled, px, nullptr, fdr, nullptr, nullptr, 0, 0.0, nullptr, nullptr));
     hipLaunchKernelGGL(k_flat_init, gc, b, 0, s, filled, fdr, (int)H, (int)W, dist);
-    DT_TRY(hy_iterate(s, flag, max_rounds, [&] { hipLaunchKernelGGL(k_flat_relax, gt, b, 0, s, filled, dist, (int)H, (int)W, tiles_x, flag); },
+    DT_TRY(hy_iterate(s, flag, max_rounds, [&] { hipLaunchKernelGGL(k_flat_relax, gt, b, 0, s, filled, dist, (int)H, (int)W, tiles_x, flag, (const int *)nullptr); },
                       &r2));
     DT_HIP(hipMemsetAsync(flag + 1, 0, sizeof(int), s));
     hipLaunchKernelGGL(k_flat_assign, gc, b, 0, s, filled, dist, (int)H, (int)W, fdr, flag + 1);
@@ -285,5 +301,40 @@ int dt_launch_condition(hipStream_t s, const float *dem, int64_t H, int64_t W, d
     rounds_host[0] = r1;
     rounds_host[1] = r2;
   }
+  return DT_OK;
+}
+
+// The same conditioning without a single host synchronisation (the resident chain's form): a fixed budget of `rounds`
+// fill rounds and `rounds` flat rounds is enqueued; every round records whether it changed anything, a round that
+// follows a quiet one returns at once (a few microseconds), and a last kernel raises DT_STATUS_NOT_CONVERGED on the
+// context when the budget ran out before the fixed point (or a flat cell was left without a code): the rasters are
+// then NOT the conditioned ones -- run again with a larger budget, or use the synchronous form, which iterates to
+// the fixed point whatever it takes.  The bundled Example raster needs 12 rounds, rough 4096^2 terrain a few dozen.
+int dt_launch_condition_async(hipStream_t s, const float *dem, int64_t H, int64_t W, double px, float *filled,
+                              uint8_t *fdr, void *scratch, int rounds, int *status) {
+  const int64_t n = H * W;
+  if (n == 0) return DT_OK;
+  DT_REQUIRE(fdr != nullptr, "the asynchronous conditioning writes the D8 codes");
+  DT_REQUIRE(rounds >= 1 && rounds <= DT_HYDRO_MAX_ASYNC_ROUNDS, "1..500 rounds");
+  int *flags = (int *)scratch;  // [0, rounds): fill rounds; [rounds, 2 rounds): flat rounds; [2 rounds]: unresolved
+  uint32_t *dist = (uint32_t *)((char *)scratch + DT_HYDRO_FLAG_BYTES);
+  const int tiles_x = (int)((W + HT - 1) / HT), tiles_y = (int)((H + HT - 1) / HT);
+  dim3 gc((unsigned)((n + 255) / 256)), gt((unsigned)(tiles_x * tiles_y)), b(256);
+  DT_HIP(hipMemsetAsync(flags, 0, DT_HYDRO_FLAG_BYTES, s));
+  hipLaunchKernelGGL(k_fill_init, gc, b, 0, s, dem, (int)H, (int)W, filled);
+  for (int r = 0; r < rounds; r++)
+    hipLaunchKernelGGL(k_fill_relax, gt, b, 0, s, dem, filled, (int)H, (int)W, tiles_x, flags + r,
+                       r ? (const int *)(flags + r - 1) : (const int *)nullptr);
+  DtWin w;
+  w.H = (int)H; w.W = (int)W; w.ld = W; w.gy0 = 0; w.gx0 = 0; w.Hg = (int)H; w.Wg = (int)W; w.halo = 0;
+  DT_TRY(dt_launch_stencil(s, w, filled, px, nullptr, fdr, nullptr, nullptr, 0, 0.0, nullptr, nullptr));
+  hipLaunchKernelGGL(k_flat_init, gc, b, 0, s, filled, fdr, (int)H, (int)W, dist);
+  int *fl2 = flags + rounds;
+  for (int r = 0; r < rounds; r++)
+    hipLaunchKernelGGL(k_flat_relax, gt, b, 0, s, filled, dist, (int)H, (int)W, tiles_x, fl2 + r,
+                       r ? (const int *)(fl2 + r - 1) : (const int *)nullptr);
+  hipLaunchKernelGGL(k_flat_assign, gc, b, 0, s, filled, dist, (int)H, (int)W, fdr, flags + 2 * rounds);
+  hipLaunchKernelGGL(k_hydro_verdict, dim3(1), dim3(1), 0, s, (const int *)(flags + rounds - 1),
+                     (const int *)(fl2 + rounds - 1), (const int *)(flags + 2 * rounds), status);
   return DT_OK;
 }

@@ -75,6 +75,8 @@ int dt_launch_classify_f32(hipStream_t s, const float *desc, const int32_t *bin_
                            float nodata, float th, int under, int remap, uint8_t *binary, int32_t *klass,
                            unsigned long long *counts4);
 int dt_launch_membench_copy(hipStream_t s, const float *a, float *b, int64_t n, int blocks);
+int dt_launch_membench_mix(hipStream_t s, const float *r0, const float *r1, float *w0, float *w1, float *w2, int64_t n,
+                           int nr, int nw, int nt);
 // rank-level solves on all-gathered summary rows (multi-GPU)
 size_t dt_rank_solve_scratch(int nranks, int64_t Pmax);
 int dt_launch_rank_solve_flowacc(hipStream_t s, int ty, int tx, const int64_t *heights, const int64_t *widths,
@@ -89,5 +91,7 @@ int dt_launch_rank_solve_flowhand(hipStream_t s, int ty, int tx, const int64_t *
 size_t dt_hydro_scratch(int64_t H, int64_t W);
 int dt_launch_condition(hipStream_t s, const float *dem, int64_t H, int64_t W, double px, float *filled, uint8_t *fdr,
                         void *scratch, int *unresolved_host, int *rounds_host);
+int dt_launch_condition_async(hipStream_t s, const float *dem, int64_t H, int64_t W, double px, float *filled,
+                              uint8_t *fdr, void *scratch, int rounds, int *status);
 
 int dt_flow_impl();  // 1 global kernels, 2 tile-hierarchical (default)

@@ -514,13 +514,12 @@ __global__ __launch_bounds__(256) void k_downslope(const float *__restrict__ dem
 // bit-identical to k_downslope.  75 KiB of LDS: two workgroups per CU; workgroups are banded per XCD so
 // overlapping margins come from L2.
 #define DW_CORE 64
-#define DW_M 24
-#define DW_WIN (DW_CORE + 2 * DW_M) /* 112 */
+// margin DW_M (template parameter: 24 by default; DT_DBG_DS_MARGIN tries 16 / 20), window DW_WIN = core + 2 margins
 // LDS row stride in cells.  Lanes that merged onto one flow path trail each other by a few cells; with a
 // stride of 112 dwords (= 16 mod 32 banks) two cells 2 rows apart in one column share a bank, the common
 // case on south-flowing terrain.  116 = 20 mod 32: same column conflicts only 8 rows apart, the diagonals
 // 32 apart; rows stay 16-byte aligned for the float4 staging stores.
-#define DW_LD 116
+// DW_LD = DW_WIN + 4 (116 for the 112-cell window)
 #define MW_OFF 0x3FFu
 #define MW_BIAS 512
 #define MW_DIAG 0x400u
@@ -529,11 +528,13 @@ __global__ __launch_bounds__(256) void k_downslope(const float *__restrict__ dem
 #define MW_RING 0x2000u
 #define MW_STOP 0x8000u
 
+template <int DW_M>
 __global__ __launch_bounds__(1024, 8) void k_downslope_win(const float *__restrict__ dem,
                                                        const uint8_t *__restrict__ fdr, DtWin w,
                                                        double px, double dz, float dzf, int raw,
                                                        float *__restrict__ out, int tiles_x, int ntiles,
                                                        int *__restrict__ n_unresolved) {
+  constexpr int DW_WIN = DW_CORE + 2 * DW_M, DW_LD = DW_WIN + 4;
   // one LDS block: heights at byte 0, move words at byte DW_LD*DW_WIN*4 (the walk reads both from one
   // address register)
   __shared__ __attribute__((aligned(16))) unsigned char smem[DW_LD * DW_WIN * 6];
@@ -835,8 +836,17 @@ int dt_launch_downslope(hipStream_t s, const DtWin &w, const float *dem, const u
   // (double)drop < dz  <=>  drop < dzf with dzf the smallest float >= dz
   float dzf = (float)dz;
   if ((double)dzf < dz) dzf = nextafterf(dzf, INFINITY);
-  hipLaunchKernelGGL(k_downslope_win, dim3((unsigned)ntiles), dim3(1024), 0, s, dem, fdr, w, px, dz, dzf, raw,
-                     out, tiles_x, (int)ntiles, n_unresolved);
+  // margin of the LDS window around the 64 x 64 core: walks that reach the window's ring carry on in global memory
+  const int m = dt_debug_get(DT_DBG_DS_MARGIN);
+  if (m == 16)
+    hipLaunchKernelGGL(k_downslope_win<16>, dim3((unsigned)ntiles), dim3(1024), 0, s, dem, fdr, w, px, dz, dzf, raw,
+                       out, tiles_x, (int)ntiles, n_unresolved);
+  else if (m == 20)
+    hipLaunchKernelGGL(k_downslope_win<20>, dim3((unsigned)ntiles), dim3(1024), 0, s, dem, fdr, w, px, dz, dzf, raw,
+                       out, tiles_x, (int)ntiles, n_unresolved);
+  else
+    hipLaunchKernelGGL(k_downslope_win<24>, dim3((unsigned)ntiles), dim3(1024), 0, s, dem, fdr, w, px, dz, dzf, raw,
+                       out, tiles_x, (int)ntiles, n_unresolved);
   return DT_OK;
 }
 int dt_launch_downslope_v1(hipStream_t s, const float *dem, const uint8_t *fdr, int64_t H, int64_t W,
@@ -1162,6 +1172,50 @@ __global__ __launch_bounds__(256) void k_membench_patch(const float *__restrict_
   for (int r = 0; r < PH; r++)
     *reinterpret_cast<float4 *>(b + (long long)(py * PH + r) * RL + px * PW + threadIdx.x * 4) = v[r];
 }
+// NR read streams summed into NW write streams, the same 1024 x 4 patches: what the memory system gives a given
+// read / write mix with no arithmetic in the way (the fused slope + TI + MTI stencil is 2 reads + 3 writes)
+typedef float mb_v4f __attribute__((ext_vector_type(4)));
+template <int NR, int NW, bool NT>
+__global__ __launch_bounds__(256) void k_membench_mix(const float *__restrict__ r0, const float *__restrict__ r1,
+                                                     float *__restrict__ w0, float *__restrict__ w1,
+                                                     float *__restrict__ w2, int patches_x) {
+  constexpr int RL = 16384, PW = 1024, PH = 4;
+  const int py = blockIdx.x / patches_x, px = blockIdx.x - py * patches_x;
+  mb_v4f v[PH];
+#pragma unroll
+  for (int r = 0; r < PH; r++) {
+    const long long o = (long long)(py * PH + r) * RL + px * PW + threadIdx.x * 4;
+    mb_v4f a = {1.0f, 2.0f, 3.0f, 4.0f};
+    if (NR >= 1) a = NT ? __builtin_nontemporal_load(reinterpret_cast<const mb_v4f *>(r0 + o)) : *reinterpret_cast<const mb_v4f *>(r0 + o);
+    if (NR >= 2) a += NT ? __builtin_nontemporal_load(reinterpret_cast<const mb_v4f *>(r1 + o)) : *reinterpret_cast<const mb_v4f *>(r1 + o);
+    v[r] = a;
+  }
+#pragma unroll
+  for (int r = 0; r < PH; r++) {
+    const long long o = (long long)(py * PH + r) * RL + px * PW + threadIdx.x * 4;
+    float *ws[3] = {w0, w1, w2};
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+      if (NT) __builtin_nontemporal_store(v[r], reinterpret_cast<mb_v4f *>(ws[k] + o));
+      else *reinterpret_cast<mb_v4f *>(ws[k] + o) = v[r];
+    }
+  }
+}
+int dt_launch_membench_mix(hipStream_t s, const float *r0, const float *r1, float *w0, float *w1, float *w2, int64_t n,
+                           int nr, int nw, int nt) {
+  DT_REQUIRE(n % (16384 * 4) == 0 && n > 0, "the mix benchmark needs a multiple of 4 rows of 16384 floats");
+  DT_REQUIRE(nr >= 0 && nr <= 2 && nw >= 1 && nw <= 3, "0-2 read streams, 1-3 write streams");
+  dim3 g((unsigned)(n / 4096)), b(256);
+#define MB_GO(R, W)                                                                                        \
+  if (nr == R && nw == W) {                                                                                \
+    if (nt) hipLaunchKernelGGL((k_membench_mix<R, W, true>), g, b, 0, s, r0, r1, w0, w1, w2, 16);          \
+    else hipLaunchKernelGGL((k_membench_mix<R, W, false>), g, b, 0, s, r0, r1, w0, w1, w2, 16);            \
+  }
+  MB_GO(0, 1) MB_GO(0, 2) MB_GO(0, 3) MB_GO(1, 1) MB_GO(1, 2) MB_GO(1, 3) MB_GO(2, 1) MB_GO(2, 2) MB_GO(2, 3)
+#undef MB_GO
+  return DT_OK;
+}
+
 int dt_launch_membench_copy(hipStream_t s, const float *a, float *b, int64_t n, int blocks) {
   int64_t n4 = n / 4;
   if (n4 == 0) return DT_OK;

@@ -123,6 +123,39 @@ __device__ __forceinline__ int sd_tile_of_block(int b, int ntiles) {
   int k = j + xcd * (n >> 3);
   return base + (k >= n ? k - n : k);
 }
+// Experimental workgroup -> tile maps of the fused stencil (DT_DBG_TWI_MAP = mode | param << 8), for the placement
+// study of DESIGN.md 6: the band map above makes the eight XCDs sweep eight 4-MiB windows per raster that stay a
+// fixed distance apart; the others change which parts of the rasters are written at the same time.
+//   1  bands without the stagger            2  tile rows dealt round-robin to the XCDs (one moving front per raster)
+//   3  groups of `param` tile rows per XCD, round-robin        4  bands, stagger of xcd * param tiles
+//   5  bands walked in chunks of 256 tiles in a scrambled order (chunk * 5 + 3 xcd mod chunks)
+__device__ __forceinline__ int sd_tile_of_block_x(int b, int tiles_x, int tiles_y, int mode_param) {
+  const int ntiles = tiles_x * tiles_y, mode = mode_param & 0xFF, param = mode_param >> 8;
+  const int xcd = b & 7, j = b >> 3, q = ntiles >> 3;
+  if ((ntiles & 7) != 0 || mode == 0) return sd_tile_of_block(b, ntiles);
+  if (mode == 1) return xcd * q + j;
+  if (mode == 2 || mode == 3) {
+    const int G = mode == 2 ? 1 : (param > 0 ? param : 2);
+    if (tiles_y % (8 * G) != 0) return sd_tile_of_block(b, ntiles);
+    const int jr = j / tiles_x, jc = j - jr * tiles_x;
+    const int row = ((jr / G) * 8 + xcd) * G + jr % G;
+    return row * tiles_x + jc;
+  }
+  if (mode == 4) {
+    int k = j + xcd * param;
+    k %= q;
+    return xcd * q + k;
+  }
+  if (mode == 5) {
+    const int nch = q >> 8;
+    if (nch < 2 || (q & 255) != 0) return sd_tile_of_block(b, ntiles);
+    const int ch = j >> 8, in = j & 255;
+    const int ch2 = (int)(((unsigned)ch * 5u + 3u * (unsigned)xcd) % (unsigned)nch);
+    return xcd * q + ch2 * 256 + in;
+  }
+  return sd_tile_of_block(b, ntiles);
+}
+
 __device__ __forceinline__ void sd_tile_origin(int b, int tiles_x, int tiles_y, int &x0, int &y0) {
   int tile = sd_tile_of_block(b, tiles_x * tiles_y);
   int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
@@ -398,13 +431,15 @@ __global__ __launch_bounds__(256, WX == 1 ? 8 : (WX == 2 ? 7 : 6)) void k_slope_
                                                      const AccT *__restrict__ acc32, double n_top, double lnpx2,
                                                      float *__restrict__ ti, float *__restrict__ mti, int tiles_x,
                                                      int tiles_y, int vec_ok, uint8_t *__restrict__ tile_mark,
-                                                     uint16_t *__restrict__ lane_mask, uint32_t flag_all) {
+                                                     uint16_t *__restrict__ lane_mask, uint32_t flag_all,
+                                                     int map_mode) {
   constexpr int TX = SD_TX * WX, TY = SD_TY / WX, LDW = TX + 8;
   constexpr bool NT = POL >= 1 && POL <= 4;  // non-temporal loads of the accumulation raster
   __shared__ __attribute__((aligned(16))) float t[(TY + 2) * LDW];
   const double nlnpx2 = n_top * lnpx2;
   // (tried: identity and row-interleaved block -> tile maps instead of one band per XCD: 2 % slower)
-  const int tile = sd_tile_of_block(blockIdx.x, tiles_x * tiles_y);
+  const int tile = map_mode ? sd_tile_of_block_x(blockIdx.x, tiles_x, tiles_y, map_mode)
+                            : sd_tile_of_block(blockIdx.x, tiles_x * tiles_y);
   const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
   const int x0 = txi * TX, y0 = tyi * TY;
   const int H = w.H, W = w.W;
@@ -765,7 +800,8 @@ static int launch_slope_twi(hipStream_t s, const DtWin &w, const float *dem, dou
   const DtLogEntry *g_tab = dt_math_device_table(s);
 #define DT_HOT(S, R, N)                                                                                             \
   hipLaunchKernelGGL((k_slope_twi<S, R, N, AccT, WX>), g, b, 0, s, dem, w, kc, kd, slope, slope_rad, acc, n_top, lnpx2, \
-                     ti, mti, tiles_x, tiles_y, vec_ok, mark, lmask, dt_debug_get(DT_DBG_TWI_FLAG_ALL) ? 0xFFFFu : 0u)
+                     ti, mti, tiles_x, tiles_y, vec_ok, mark, lmask, dt_debug_get(DT_DBG_TWI_FLAG_ALL) ? 0xFFFFu : 0u, \
+                     dt_debug_get(DT_DBG_TWI_MAP))
   // non-temporal loads of the accumulation raster and stores of the outputs (each byte is touched once):
   // 0.86 instead of 0.92 ms at 16384^2; the knob selects another cache policy (sd_store4) for A/B runs of the
   // benchmark's form of the kernel (slope + TI + MTI, int32 accumulation, 256 x 16 tiles)

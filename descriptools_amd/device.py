@@ -122,6 +122,10 @@ class Context:
         if st & 1:
             raise OverflowError("flow accumulation reached 2^31 cells: the int32 accumulation rasters of this "
                                 "step are not valid (DT_STATUS_ACC_OVERFLOW)")
+        if st & 2:
+            raise RuntimeError("hydrological conditioning did not reach its fixed point within the budget of rounds "
+                               "(DT_STATUS_NOT_CONVERGED): the rasters of this step are not valid -- raise "
+                               "Chain(condition_rounds=...) or use flowdir.d8_conditioned, which iterates to the end")
 
     def fork(self, child):
         """`child`'s stream waits (on the device) for everything enqueued so far on this context's stream."""

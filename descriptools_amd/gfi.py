@@ -15,7 +15,7 @@ def river_accumulation(flow_accumulation, indices):
 
 
 def _area_index(hand, area, expoent, scale_factor, size, zero_guard):
-    h = dem_f32(hand)
+    h = dem_f32(hand, "HAND")
     a = np.ascontiguousarray(area, np.int64)
     out = np.empty(h.shape, np.float32)
     check(_lib.lib().dt_gfi_area(ptr(h, c_f32p), ptr(a, c_i64p), h.size, float(expoent), float(scale_factor),
@@ -32,7 +32,7 @@ def geomorphic_flood_index_cpu(hand, river_flow_accumulation, expoent, scale_fac
 def gfi_calculator(hand, flow_accumulation, indices, n_gfi, scale_factor, size, division_column=0,
                    division_row=0):
     """gfi.py:150-207 -> float64 raster holding float32 values."""
-    h = dem_f32(hand)
+    h = dem_f32(hand, "HAND")
     fac = np.ascontiguousarray(flow_accumulation, np.int64)
     idx = np.ascontiguousarray(indices, np.int64)
     out = np.empty(h.shape, np.float32)

@@ -88,6 +88,9 @@ int dt_graph_destroy(dt_graph *graph);
  * ran with int32 accumulation rasters (the `_w` entry points; a device tile is < 2^31 cells), so its results are
  * not valid: rasters of >= 2^31 cells go through the `_w_a64` entry points (int64 rasters), which never raise it. */
 #define DT_STATUS_ACC_OVERFLOW 1
+/* DT_STATUS_NOT_CONVERGED: dt_dev_condition_d8_async's budget of rounds ran out before the fixed point (or a flat
+ * cell was left without a code): the conditioned rasters of that step are not valid. */
+#define DT_STATUS_NOT_CONVERGED 2
 int dt_ctx_status(dt_ctx *ctx, int32_t *out);
 int64_t dt_ctx_scratch_bytes(dt_ctx *ctx);
 
@@ -200,6 +203,11 @@ int dt_dev_slope_twi(dt_ctx *ctx, const float *dem, const int32_t *acc32, int64_
 /* dt_d8_conditioned_f32 on device rasters; synchronous (the fixed-point iterations read a flag back). */
 int dt_dev_condition_d8(dt_ctx *ctx, const float *dem, int64_t H, int64_t W, double px, float *filled, uint8_t *fdr,
                         int32_t *info3);
+/* The same without any host synchronisation (the resident chain's form, chain.Chain(condition=True)): `rounds`
+ * fill rounds and `rounds` flat rounds are enqueued (1..500), a round that follows a quiet one returns at once, and
+ * DT_STATUS_NOT_CONVERGED is raised on the context (dt_ctx_status) when the budget did not reach the fixed point. */
+int dt_dev_condition_d8_async(dt_ctx *ctx, const float *dem, int64_t H, int64_t W, double px, float *filled,
+                              uint8_t *fdr, int rounds);
 /* acc32: int32 accumulation (H*W < 2^31); dem may be NULL. */
 int dt_dev_flowacc(dt_ctx *ctx, const uint8_t *fdr, const float *dem, int64_t H, int64_t W,
                    int32_t *acc32);
@@ -335,6 +343,11 @@ int dt_dev_classify(dt_ctx *ctx, const double *desc, int8_t *flood, int64_t N, d
  * floats in 1024 x 4 patches, one per workgroup (N a multiple of 65536) -- the faster of the two forms on
  * MI355X (6.1 vs 5.4 TB/s), bench.py reports the better one */
 int dt_dev_membench_copy(dt_ctx *ctx, const float *a, float *b, int64_t N, int blocks);
+/* The same patches with n_reads (0-2) read streams summed into n_writes (1-3) write streams, optionally with
+ * non-temporal loads / stores: the rate the memory system gives a read / write MIX with no arithmetic in the way.
+ * The fused slope + TI + MTI stencil is 2 reads + 3 writes (60 % of its bytes are written). */
+int dt_dev_membench_mix(dt_ctx *ctx, const float *r0, const float *r1, float *w0, float *w1, float *w2, int64_t N,
+                        int n_reads, int n_writes, int nontemporal);
 
 /* Rank-level solves on the GPU (multi-GPU): `rows_dev` holds one all-gathered byte row per rank
  * (rowbytes apart); field k of rank r starts at rows_dev + r * rowbytes + field_offsets[k] and has Pmax

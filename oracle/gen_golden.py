@@ -111,6 +111,26 @@ def case_synth():
              dz=5.0, **out)
 
 
+def case_f64():
+    """A genuinely float64 DEM (heights that are NOT float32 values: the synthetic terrain plus a smooth float64
+    ripple; no float64 <- float32 copy): the reference takes every height difference in float64 here (slope.py:244-258,
+    flowhand.py:436-438, downslope.py:468).  D8 / accumulation inputs come from the float32-rounded terrain's oracle run
+    (they are INPUTS of the reference).  Pins what the float32 boundary of the build gives up on such a raster."""
+    print("f64", flush=True)
+    H, W, px, thr = 80, 96, 10.0, 25
+    dem32 = oracle.synth_dem(5, 1024, 1024, 400, 100, H, W, 4)
+    yy, xx = np.mgrid[0:H, 0:W]
+    ripple = 1e-3 * np.sin(0.37 * yy + 0.11 * xx) + 1e-6 * np.cos(1.3 * xx)   # sub-float32-ulp structure at ~200 m
+    dem64 = np.where(dem32 == -100, -100.0, dem32.astype(np.float64) + ripple)
+    assert (dem64.astype(np.float32).astype(np.float64) != dem64).sum() > 0.9 * (dem32 != -100).sum()
+    _, fdr = oracle.slope_d8(dem64.astype(np.float32), px)
+    fac = oracle.flowacc(fdr, dem64.astype(np.float32))
+    river = (fac > thr).astype(np.int8)
+    out = run_chain(dem64, fdr, fac, river, px)
+    assert out["hand"].dtype == np.float64
+    save("f64", dem=dem64, fdr=fdr, fac=fac, river=river, px=px, n_top=0.1, n_gfi=0.4, b=0.1, dz=5.0, **out)
+
+
 def case_example_windows():
     """G-ex: windows of the bundled Example rasters (int16 DEM), each run as its own raster."""
     dem, fdr, fac, flood, _ = load_example()
@@ -424,7 +444,7 @@ def case_example_descriptors():
     save("example_desc", **res)
 
 
-CASES = {"shims": case_shims, "example_descriptors": case_example_descriptors, "synth": case_synth, "example_windows": case_example_windows, "edge": case_edge,
+CASES = {"f64": case_f64, "shims": case_shims, "example_descriptors": case_example_descriptors, "synth": case_synth, "example_windows": case_example_windows, "edge": case_edge,
          "eval": case_eval, "example_full": case_example_full}
 
 if __name__ == "__main__":

@@ -129,3 +129,72 @@ def test_conditioning_spiral_flat_across_many_tiles():
     fdr, filled, acc = _check(dem, 10.0)
     assert np.array_equal(filled, dem)
     assert acc[ye + 1, xe] >= len(order), "the whole plateau drains through the gap below its far end"
+
+
+def _rough(H, W, seed):
+    rng = np.random.default_rng(seed)
+    dem = oracle.synth_dem(seed, 2048, 2048, 11, 17, H, W, 3)
+    nod = dem == -100
+    dem = np.floor(dem + rng.normal(0, 6.0, dem.shape)).astype(np.float32)
+    dem[rng.random(dem.shape) < 0.02] -= 40
+    dem[10:30, 5:35] = dem[10:30, 5:35].min()
+    dem[nod] = -100
+    return dem
+
+
+def test_async_conditioning_equals_the_synchronous_form_and_reports_an_exhausted_budget():
+    """dt_dev_condition_d8_async: a fixed budget of rounds enqueued without a host synchronisation; same rasters as
+    the synchronous form when the budget suffices, DT_STATUS_NOT_CONVERGED on the context when it does not"""
+    from descriptools_amd import _lib, flowdir
+    from descriptools_amd.device import Context
+    L = _lib.lib()
+    H, W, px = 300, 417, 10.0
+    dem = _rough(H, W, 7)
+    fdr_s, filled_s = flowdir.d8_conditioned(dem, px, return_filled=True)
+    ctx = Context()
+    d_dem, d_fill, d_fdr = ctx.to_device(dem), ctx.empty((H, W), np.float32), ctx.empty((H, W), np.uint8)
+    _lib.check(L.dt_dev_condition_d8_async(ctx.h, d_dem.ptr, H, W, px, d_fill.ptr, d_fdr.ptr, 64))
+    assert ctx.status() == 0
+    assert np.array_equal(d_fill.to_host(), filled_s) and np.array_equal(d_fdr.to_host(), fdr_s)
+    _lib.check(L.dt_dev_condition_d8_async(ctx.h, d_dem.ptr, H, W, px, d_fill.ptr, d_fdr.ptr, 1))  # one round: not enough
+    with pytest.raises(RuntimeError, match="NOT_CONVERGED"):
+        ctx.raise_on_status()
+    assert ctx.status() == 0  # reading clears it
+    for b in (d_dem, d_fill, d_fdr):
+        b.free()
+    ctx.close()
+
+
+def test_chain_with_conditioning():
+    """Chain(condition=True): the step's D8 codes are the conditioned ones (oracle.condition_d8), the accumulation has
+    no cycle and no undrained pit, and every downstream raster is what the stand-alone API gives with that D8 raster."""
+    from descriptools_amd import chain, downslope, flowhand
+    from descriptools_amd.device import Context
+    H, W, px = 384, 512, 10.0
+    dem = _rough(H, W, 9)
+    thr = H * W // 512
+    ctx = Context()
+    ch = chain.Chain(H, W, ctx=ctx, px=px, river_threshold=thr, condition=True)
+    d_dem = ctx.to_device(dem)
+    ch.run(d_dem.ptr)
+    ch.check_status()
+    out = {k: ch.buf[k].to_host() for k in ("fdr", "fac", "river", "fdist", "idx", "hand", "down", "filled", "slope")}
+    fdr_o, filled_o = oracle.condition_d8(dem, px)
+    assert np.array_equal(out["fdr"], fdr_o) and np.array_equal(out["filled"], filled_o)
+    acc_o = oracle.flowacc(fdr_o, dem)
+    valid = dem != -100
+    assert np.array_equal(out["fac"], acc_o) and (acc_o[valid] >= 0).all()
+    assert np.array_equal(out["river"], (acc_o > thr).astype(np.int8))
+    fd, idx, hand = flowhand.flow_hand_index(dem, fdr_o, out["river"], px)
+    assert np.array_equal(out["idx"], idx) and np.array_equal(out["hand"], hand) and np.array_equal(out["fdist"], fd)
+    assert np.array_equal(out["down"], downslope.downsloper(dem, fdr_o, px, 5.0))
+    assert np.array_equal(out["slope"], oracle.slope_d8(dem, px)[0])  # the slope is the raw DEM's
+    # a budget that is too small is reported, not silently wrong
+    ch2 = chain.Chain(H, W, ctx=ctx, px=px, river_threshold=thr, condition=True, condition_rounds=1)
+    ch2.run(d_dem.ptr)
+    with pytest.raises(RuntimeError, match="NOT_CONVERGED"):
+        ch2.check_status()
+    ch.free()
+    ch2.free()
+    d_dem.free()
+    ctx.close()
