@@ -27,7 +27,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r2", "pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r3", "pmc_traffic.json")
 
 
 def pmc_traffic(kernels, size):
@@ -71,7 +71,7 @@ def per_op_table(events, ops, cells, size, steps):
     # the dominant KERNEL: ops that are one (hot) kernel are timed by their events; the kernels of the multi-kernel
     # ops (flow accumulation, HAND's first phase) are <= 1.4 ms each (profiles/)
     single = [k for k in per_op if per_op[k]["algo_bytes_per_cell"] > 0 and
-              len([x for x in per_op[k]["kernels"] if not x.endswith("_fix")]) == 1]
+              len([x for x in per_op[k]["kernels"] if "_fix" not in x]) == 1]
     dom = max(single, key=lambda k: per_op[k]["ms"])
     roof = {"kernel": per_op[dom]["kernels"][0], "op": dom, "bound": "hbm",
             "achieved": per_op[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--cpu-n", type=int, default=3072, help="edge of the CPU baseline's DEM (a bounded sample: ~20 s "
                     "on one thread)")
     ap.add_argument("--no-verify", action="store_true", help="skip the cross-check of the timed step's rasters")
+    ap.add_argument("--no-placement", action="store_true", help="rasters in allocation order (no placement tuning)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end_to_end block (host-tier API, PCIe included)")
     ap.add_argument("--e2e-size", type=int, default=8192, help="edge of the host DEM of the end_to_end block")
     ap.add_argument("--graph", action="store_true", help="N = 1: the headline loop replays the step as one HIP graph "
@@ -161,18 +162,26 @@ def main():
                np.int32: torch.int32}[dt]
         return torch.empty(shape, dtype=tdt, device=dev)
 
-    bufs = {}
+    bufs = {}  # device pointer -> tensor
 
     def alloc_ptr(shape, dt):
         t = alloc(shape, dt)
-        bufs[len(bufs)] = t
+        bufs[t.data_ptr()] = t
         return t.data_ptr()
+
+    def release_ptr(q):
+        del bufs[q]
 
     dem = alloc((H, W), np.float32)
     _lib.check(L.dt_dev_synth_dem(ctx.h, args.seed, H, W, 0, 0, H, W, 0, dem.data_ptr()))
-    ch = chain.Chain(H, W, ctx=ctx, px=10.0, river_threshold=(H * W) // 512, alloc=alloc_ptr,
-                     side_ctx=ctx2 if args.overlap else None, overlap=args.overlap, want_slope_rad=False)
-    rasters = {name: bufs[i] for i, (name, _) in enumerate(chain.OUTPUTS)}
+    # the chain hands its blocks to the rasters by measured write-conflict class (descriptools_amd/placement.py): the
+    # rasters one kernel writes together must not all lie in one class of the device's memory
+    ch = chain.Chain(H, W, ctx=ctx, px=10.0, river_threshold=(H * W) // 512, alloc=alloc_ptr, release=release_ptr,
+                     side_ctx=ctx2 if args.overlap else None, overlap=args.overlap, want_slope_rad=False,
+                     tune_placement=not args.no_placement)
+    torch.cuda.empty_cache()  # the candidates the chain did not keep go back to the device
+    tdt = {np.float32: torch.float32, np.uint8: torch.uint8, np.int8: torch.int8, np.int32: torch.int32}
+    rasters = {name: bufs[ch.p(name)].view(tdt[dt]) for name, dt in chain.OUTPUTS}
     N = H * W
 
     def barrier():
@@ -253,7 +262,8 @@ def main():
                                "downslope), device-resident" % (S, S),
                    "global_dem": "%dx%d" % (H, W), "px": 10.0, "river_threshold_cells": ch.river_threshold,
                    "parallelism": "single GPU; " + sched
-                                  + ("; the step replayed as one HIP graph (--graph)" if args.graph else "")},
+                                  + ("; the step replayed as one HIP graph (--graph)" if args.graph else ""),
+                   "placement": ch.placement},
         "ms_per_step_serial": round(dt_serial / args.steps * 1e3, 3),
         "roofline": roof,
         "per_op": per_op,
@@ -375,7 +385,7 @@ def main_tiled(args, torch, dist, world, rank, local_rank, dev):
     torch.cuda.set_stream(stream)
     layout = tiling.Layout.uniform(world, S, S)
     tile = tiling.RankTile(layout, rank, device=local_rank, stream=stream.cuda_stream, px=10.0,
-                           river_threshold=(layout.Hg * layout.Wg) // 512)
+                           river_threshold=(layout.Hg * layout.Wg) // 512, tune_placement=not args.no_placement)
     tile.synth_dem(args.seed)
 
     use_dist = world > 1 or args.force_dist
@@ -415,8 +425,8 @@ def main_tiled(args, torch, dist, world, rank, local_rank, dev):
     for name, bpc in tiling.RANK_OPS:
         k = {"d8": kern["d8"], "downslope": kern["downslope"], "slope_twi": kern["slope_twi"],
              "flowacc_local": ["k_fa_tile1", "k_fa_reduce", "k_fa_nxt_init", "k_fa_rank_summary"],
-             "flowacc_solve_finish": ["k_rk_fa_*", "k_fa_propagate", "k_fa_poison", "k_fa_tile3"],
-             "flowhand_local": kern["flowhand_local"],
+             "flowacc_finish_flowhand_local": ["k_rk_fa_*", "k_fa_propagate", "k_fa_poison", "k_fa3fh1", "k_fh_tile1",
+                                               "k_fh_ghost_init", "k_fh_node_jump", "k_fh_rank_summary"],
              "flowhand_gfi_solve_finish": ["k_rk_fh_*", "k_fh_ghost_set", "k_fh_tile3"]}.get(name, [])
         op_defs.append((name, bpc, k))
     ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in ops]
@@ -451,6 +461,7 @@ def main_tiled(args, torch, dist, world, rank, local_rank, dev):
                    "global_dem": "%dx%d" % (layout.Hg, layout.Wg), "px": 10.0,
                    "river_threshold_cells": tile.river_threshold,
                    "accumulation_dtype": "int64" if tile.acc64 else "int32",
+                   "placement": tile.placement,
                    "parallelism": "%dx%d rank tiles, 64-cell halo, 2 %s all-gathers of ring summaries per "
                                   "step (flow accumulation inflow, HAND rank exits); %s"
                                   % (layout.ty, layout.tx, "gloo (CPU rehearsal)" if cpu_red else "RCCL", sched)},

@@ -109,6 +109,9 @@ _SIGS = {
     "dt_dev_flowhand_gfi_finish_w_a64": (ci, [vp, vp, vp, vp, vp, vp, f64, f64, f64, vp, vp, vp, vp, vp,
                                               vp, vp, vp, vp, vp, vp, vp, vp]),
     "dt_dev_gfi_lnhlh_a64": (ci, [vp, vp, vp, vp, i64, f64, f64, f64, vp, vp]),
+    "dt_dev_flowacc_river_flowhand_local": (ci, [vp, vp, vp, i64, i64, i64, vp, vp]),
+    "dt_dev_flowacc_finish_flowhand_local_w": (ci, [vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "dt_dev_flowacc_finish_flowhand_local_w_a64": (ci, [vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp]),
     "dt_dev_i32_to_i64": (ci, [vp, vp, i64, vp]),
     "dt_dev_i64_to_i32": (ci, [vp, vp, i64, vp]),
 }

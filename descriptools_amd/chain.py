@@ -6,7 +6,7 @@ import ctypes as C
 
 import numpy as np
 
-from . import _lib
+from . import _lib, placement
 from ._lib import check
 from .device import Context
 
@@ -20,19 +20,24 @@ OUTPUTS = (("slope", F32), ("fdr", U8), ("fac", I32), ("river", I8), ("fdist", F
 # mask 5, HAND 18, TI+MTI 16, GFI 12, ln(hl/H) 12, downslope 9.
 ALGO_BYTES_PER_CELL = 90
 
+# rasters that one kernel writes together (placement.py: such a group must not sit in a single conflict class); the
+# single-role "groups" just take what is left
+WRITE_GROUPS = (("slope", "ti", "mti"), ("fdist", "idx", "hand", "gfi", "lnhlh"), ("fac",), ("a_river",),
+                ("slope_rad",), ("down",))
+
 # The ops of one step in launch order: (name, compulsory bytes per cell of the op AS FUSED HERE, kernels behind it
-# as rocprofv3 names them).  HAND + GFI + ln(hl/H) is one fused op issued as its two phases (the windowed entry
-# points with the whole raster as the window -- the same kernels as dt_dev_flowhand_gfi plus a 5 us ring summary)
-# so that its last pass, one kernel, has a duration of its own: phase 1 reads fdr 1 + river 1, the last pass reads
-# dem 4 + fac 4 and writes fdist, idx, hand, gfi, lnhlh (20).  "d8" writes fdr only: slope comes out of the fused
-# slope+TI+MTI stencil (dem 4 + fac 4 read, slope 4 + TI 4 + MTI 4 written = the north_star's 20 B/cell).
+# as rocprofv3 names them).  Flow accumulation + river mask + HAND's first phase is one op: the last accumulation tile
+# pass and HAND's first tile pass are one kernel (k_fa3fh1: fdr 1 read, acc 4 + river 1 written; then the perimeter
+# node doubling, 2 B/cell by the unfused definition fdr 1 + river 1).  HAND's last pass with the fused GFI + ln(hl/H)
+# epilogue reads dem 4 + fac 4 and writes fdist, idx, hand, gfi, lnhlh (20).  "d8" writes fdr only: slope comes out of
+# the fused slope+TI+MTI stencil (dem 4 + fac 4 read, slope 4 + TI 4 + MTI 4 written = the north_star's 20 B/cell).
 OPS = (
     ("d8", 5, ["k_d8<false>", "k_d8_fix"]),
-    ("downslope", 9, ["k_downslope_win"]),
-    ("flowacc_river", 5 + 1, ["k_fa_tile1", "k_fa_reduce", "k_fa_poison", "k_fa_tile3<true, true>"]),
-    ("flowhand_local", 2, ["k_fh_tile1n", "k_fh_tile1", "k_fh_ghost_init", "k_fh_node_jump", "k_fh_rank_summary"]),
-    ("flowhand_gfi_finish", 28, ["k_fh_tile3<false, 1, 5>"]),
-    ("slope_twi", 20, ["k_slope_twi<true, false, true>", "k_slope_twi_fix"]),
+    ("downslope", 9, ["k_downslope_win<24>"]),
+    ("flowacc_flowhand_local", 5 + 1 + 2, ["k_fa_tile1", "k_fa_reduce", "k_fa_poison", "k_fa3fh1<true>", "k_fh_tile1",
+                                           "k_fh_ghost_init", "k_fh_node_jump"]),
+    ("flowhand_gfi_finish", 28, ["k_fh_tile3<false, 1, 5, int>"]),
+    ("slope_twi", 20, ["k_slope_twi<true, false, 1, int, 1>", "k_slope_twi_fix<int, 1>"]),
 )
 
 
@@ -41,7 +46,7 @@ class Chain:
 
     def __init__(self, H, W, ctx=None, px=10.0, n_top=0.1, n_gfi=0.4, b=0.1, dz=5.0,
                  river_threshold=None, alloc=None, want_slope_rad=True, side_ctx=None, overlap=True,
-                 condition=False, condition_rounds=64):
+                 condition=False, condition_rounds=64, tune_placement=True, release=None):
         """overlap (the default): downslope runs as a second branch on its own stream (side_ctx, created on demand)
         beside the flow-accumulation / HAND kernels, whose latency chains leave most of the GPU idle: ~3-5 % faster
         end to end at 16384^2.  overlap=False: one stream, kernels back to back (what per-kernel timings need:
@@ -52,6 +57,7 @@ class Chain:
         raster from a GIS tool, Example/example.py:36).  Nothing synchronises: `condition_rounds` fill / flat rounds
         are enqueued, and check_status() raises afterwards if that budget was too small for the raster."""
         self.condition, self.condition_rounds = bool(condition), int(condition_rounds)
+        self._alloc, self._release = alloc, release
         self.want_slope_rad = want_slope_rad
         self.H, self.W, self.N = int(H), int(W), int(H) * int(W)
         self.ctx = ctx or Context()
@@ -65,6 +71,45 @@ class Chain:
         self._graphs = []
         for name, dt in OUTPUTS + ((("filled", F32),) if self.condition else ()):
             self.buf[name] = alloc((H, W), dt) if alloc else self.ctx.empty((H, W), dt)
+        self.placement = {"tuned": False, "why": "tune_placement=False"}
+        if tune_placement:
+            self._tune_placement()
+
+    def _tune_placement(self):
+        """hand the 4-byte rasters to their roles so that no group of rasters written by one kernel lies in a single
+        conflict class of the device's memory (placement.py; measured with ~100 timed launches of a write-only kernel
+        at set-up, skipped for rasters below 64 MiB).  With the chain's own allocator, or an `alloc` that comes with
+        a `release`, further candidate blocks are tried when the first twelve are all alike."""
+        four = [name for name, dt in OUTPUTS if np.dtype(dt).itemsize == 4]
+        objs = {}
+        for name in four:
+            b = self.buf[name]
+            objs[int(b.ptr.value if hasattr(b, "ptr") else b)] = b
+
+        def extra_alloc():
+            b = self._alloc((self.H, self.W), F32) if self._alloc else self.ctx.empty((self.H, self.W), F32)
+            q = int(b.ptr.value if hasattr(b, "ptr") else b)
+            objs[q] = b
+            return q
+
+        def extra_release(q):
+            b = objs.pop(q)
+            if hasattr(b, "free"):
+                b.free()
+            elif self._release is not None:
+                self._release(q)
+        can_grow = self._alloc is None or self._release is not None
+        roles, info = placement.assign(self.ctx, self.N * 4, list(objs), [list(g) for g in WRITE_GROUPS],
+                                       extra_alloc if can_grow else None, extra_release if can_grow else None)
+        self.placement = info
+        if roles is None:
+            return
+        dts = dict(OUTPUTS)
+        for name, q in roles.items():
+            b = objs[q]
+            if hasattr(b, "dtype"):
+                b.dtype = np.dtype(dts[name])  # a block is just memory: it takes the dtype of the role it serves
+            self.buf[name] = b
 
     def p(self, name):
         b = self.buf[name]
@@ -78,11 +123,9 @@ class Chain:
         L, c, H, W = _lib.lib(), self.ctx, self.H, self.W
         p = self.p
         side = self.side if (self.side is not None and not serial) else c
-        if getattr(self, "_ring", None) is None:
-            P = max(int(L.dt_perim_cells(H, W)), 1)
+        if getattr(self, "_full", None) is None:
             self._full = _lib.Window(H, W, W, 0, 0, H, W, 0)
-            self._ring = [c.empty(P, dt) for dt in (np.uint8, np.int32, np.int32, np.int32, np.float32, np.int64)]
-        full, ring = self._full, [r.ptr for r in self._ring]
+        full = self._full
         rad = p("slope_rad") if self.want_slope_rad else None
         first = ("d8", c, lambda: L.dt_dev_slope_d8(c.h, dem_ptr, H, W, self.px, None, p("fdr"), None))
         if self.condition:
@@ -92,10 +135,8 @@ class Chain:
             first,
             ("downslope", side, lambda: L.dt_dev_downslope(side.h, dem_ptr, p("fdr"), H, W, self.px, self.dz, 0,
                                                            p("down"))),
-            ("flowacc_river", c, lambda: L.dt_dev_flowacc_river(c.h, p("fdr"), dem_ptr, H, W, self.river_threshold,
-                                                                p("fac"), p("river"))),
-            ("flowhand_local", c, lambda: L.dt_dev_flowhand_local_w(c.h, C.byref(full), dem_ptr, p("fdr"), p("river"),
-                                                                    p("fac"), *ring)),
+            ("flowacc_flowhand_local", c, lambda: L.dt_dev_flowacc_river_flowhand_local(
+                c.h, p("fdr"), dem_ptr, H, W, self.river_threshold, p("fac"), p("river"))),
             ("flowhand_gfi_finish", c, lambda: L.dt_dev_flowhand_gfi_finish_w(
                 c.h, C.byref(full), dem_ptr, p("fdr"), p("river"), p("fac"), self.px, self.n_gfi, self.b, None, None,
                 None, None, None, None, p("fdist"), p("idx"), None, p("hand"),
@@ -153,10 +194,10 @@ class Chain:
         if self._own_side:
             self.side.close()
             self.side, self._own_side = None, False
-        for b in list(self.buf.values()) + list(getattr(self, "_ring", None) or []):
+        for b in list(self.buf.values()):
             if hasattr(b, "free"):
                 b.free()
-        self.buf, self._ring = {}, None
+        self.buf = {}
 
 
 class Graph:

@@ -60,6 +60,7 @@ extern "C" int dt_ctx_create(int device, void *stream, dt_ctx **out) {
   c->scratch_used = 0;
   c->scratch_owner = 0;
   c->owner_h = c->owner_w = 0;
+  c->owner_ptr = c->owner_ptr2 = nullptr;
   c->scratch2 = nullptr;
   c->scratch2_bytes = 0;
   c->ev = nullptr;
@@ -226,6 +227,7 @@ int dt_scratch_reset(dt_ctx *c, size_t total) {
   }
   c->scratch_used = 0;
   c->scratch_owner = 0;  // whatever two-phase state was here is about to be overwritten
+  c->owner_ptr = c->owner_ptr2 = nullptr;
   return DT_OK;
 }
 void *dt_scratch_take(dt_ctx *c, size_t bytes) {
@@ -703,15 +705,20 @@ extern "C" int dt_dev_flowacc_local_w(dt_ctx *c, const dt_window *win, const uin
   DtWin w;
   DT_TRY(dt_convert_window(win, &w));
   DT_REQUIRE(fdr && A_perim && xr_perim && code_perim, "NULL pointer");  // acc32 is not touched by phase 1
-  size_t need = dt_flowacc_tiled_scratch(w.H, w.W);
-  DT_TRY(dt_scratch_reset(c, need));
-  void *scr = dt_scratch_take(c, need);
+  // HAND's workspace is reserved beside flow accumulation's, so that phase 2 can run fused with HAND's phase 1
+  // (dt_dev_flowacc_finish_flowhand_local_w) without disturbing the state this call leaves
+  size_t need = dt_flowacc_tiled_scratch(w.H, w.W), need2 = dt_flowhand_tiled_scratch(w.H, w.W);
+  DT_TRY(dt_scratch_reset(c, need + need2 + 512));
+  void *scr = dt_scratch_take(c, need), *scr2 = dt_scratch_take(c, need2);
+  DT_REQUIRE(scr && scr2, "scratch reservation failed");
   DT_TRY(dt_launch_fa_local(c->stream, w, fdr, scr, need, acc32, 1));
   DT_TRY(dt_launch_fa_summary(c->stream, w, scr, A_perim, xr_perim, code_perim));
   DT_HIP(hipGetLastError());
   c->scratch_owner = 1;
   c->owner_h = w.H;
   c->owner_w = w.W;
+  c->owner_ptr = (char *)scr;
+  c->owner_ptr2 = (char *)scr2;
   return DT_OK;
 }
 
@@ -725,9 +732,71 @@ static int dev_flowacc_finish_w(dt_ctx *c, const dt_window *win, const uint8_t *
   DT_REQUIRE(c->scratch && c->scratch_owner == 1 && c->owner_h == w.H && c->owner_w == w.W,
              "dt_dev_flowacc_finish_w without a matching dt_dev_flowacc_local_w on this context (another call has "
              "used the context's scratch in between)");
-  DT_TRY(dt_launch_fa_finish(c->stream, w, fdr, dem, c->scratch, (const unsigned long long *)ext_perim, threshold,
+  DT_TRY(dt_launch_fa_finish(c->stream, w, fdr, dem, c->owner_ptr, (const unsigned long long *)ext_perim, threshold,
                              acc, acc64, river, c->status));
   DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+
+// phase 2 of flow accumulation and phase 1 of HAND in one call (the last accumulation tile pass and HAND's first
+// share the tile's codes and the river mask: one kernel in the common form, dt_launch_fa_finish_fh_local); leaves the
+// context in the state dt_dev_flowhand_local_w leaves it in
+static int dev_flowacc_finish_fh_local_w(dt_ctx *c, const dt_window *win, const uint8_t *fdr, const float *dem,
+                                         const uint64_t *ext_perim, int64_t threshold, void *acc, int acc64,
+                                         int8_t *river, uint8_t *kind, int32_t *ref, int32_t *nc, int32_t *nd,
+                                         float *zr, int64_t *ar) {
+  DT_CTX(c);
+  DtWin w;
+  DT_TRY(dt_convert_window(win, &w));
+  DT_REQUIRE(fdr && acc && river && kind && ref && nc && nd && zr && ar, "NULL pointer");
+  DT_REQUIRE(c->scratch && c->scratch_owner == 1 && c->owner_h == w.H && c->owner_w == w.W && c->owner_ptr2,
+             "dt_dev_flowacc_finish_flowhand_local_w without a matching dt_dev_flowacc_local_w on this context (another "
+             "call has used the context's scratch in between)");
+  DT_TRY(dt_launch_fa_finish_fh_local(c->stream, w, fdr, dem, c->owner_ptr, c->owner_ptr2,
+                                      dt_flowhand_tiled_scratch(w.H, w.W), (const unsigned long long *)ext_perim, threshold,
+                                      acc, acc64, river, c->status));
+  DT_TRY(dt_launch_fh_summary(c->stream, w, c->owner_ptr2, dem, acc, acc64, kind, ref, nc, nd, zr, (long long *)ar));
+  DT_HIP(hipGetLastError());
+  c->scratch_owner = 2;
+  c->owner_ptr = c->owner_ptr2;
+  c->owner_ptr2 = nullptr;
+  return DT_OK;
+}
+extern "C" int dt_dev_flowacc_finish_flowhand_local_w(dt_ctx *c, const dt_window *win, const uint8_t *fdr,
+                                                      const float *dem, const uint64_t *ext_perim, int64_t threshold,
+                                                      int32_t *acc32, int8_t *river, uint8_t *kind, int32_t *ref,
+                                                      int32_t *nc, int32_t *nd, float *zr, int64_t *ar) {
+  return dev_flowacc_finish_fh_local_w(c, win, fdr, dem, ext_perim, threshold, acc32, 0, river, kind, ref, nc, nd, zr, ar);
+}
+extern "C" int dt_dev_flowacc_finish_flowhand_local_w_a64(dt_ctx *c, const dt_window *win, const uint8_t *fdr,
+                                                          const float *dem, const uint64_t *ext_perim,
+                                                          int64_t threshold, int64_t *acc64, int8_t *river,
+                                                          uint8_t *kind, int32_t *ref, int32_t *nc, int32_t *nd,
+                                                          float *zr, int64_t *ar) {
+  return dev_flowacc_finish_fh_local_w(c, win, fdr, dem, ext_perim, threshold, acc64, 1, river, kind, ref, nc, nd, zr, ar);
+}
+
+// single raster: flow accumulation (all phases), river mask and HAND's phase 1; dt_dev_flowhand_finish_w /
+// dt_dev_flowhand_gfi_finish_w with the whole raster as the window follow
+extern "C" int dt_dev_flowacc_river_flowhand_local(dt_ctx *c, const uint8_t *fdr, const float *dem, int64_t H, int64_t W,
+                                                   int64_t threshold, int32_t *acc32, int8_t *river) {
+  DT_CTX(c);
+  DT_TRY(dt_check_hw(H, W));
+  DT_REQUIRE((fdr && acc32 && river) || H * W == 0, "NULL raster");
+  size_t need = dt_flowacc_tiled_scratch(H, W), need2 = dt_flowhand_tiled_scratch(H, W);
+  DT_TRY(dt_scratch_reset(c, need + need2 + 512));
+  void *scr = dt_scratch_take(c, need), *scr2 = dt_scratch_take(c, need2);
+  DT_REQUIRE(scr && scr2, "scratch reservation failed");
+  DtWin w = dt_full_window(H, W);
+  DT_TRY(dt_launch_fa_local(c->stream, w, fdr, scr, need, acc32, 0));
+  DT_TRY(dt_launch_fa_finish_fh_local(c->stream, w, fdr, dem, scr, scr2, need2, nullptr, threshold, acc32, 0, river,
+                                      c->status));
+  DT_HIP(hipGetLastError());
+  c->scratch_owner = 2;
+  c->owner_h = H;
+  c->owner_w = W;
+  c->owner_ptr = (char *)scr2;
+  c->owner_ptr2 = nullptr;
   return DT_OK;
 }
 extern "C" int dt_dev_flowacc_finish_w(dt_ctx *c, const dt_window *win, const uint8_t *fdr, const float *dem,
@@ -757,6 +826,8 @@ static int dev_flowhand_local_w(dt_ctx *c, const dt_window *win, const float *de
   c->scratch_owner = 2;
   c->owner_h = w.H;
   c->owner_w = w.W;
+  c->owner_ptr = (char *)scr;
+  c->owner_ptr2 = nullptr;
   return DT_OK;
 }
 extern "C" int dt_dev_flowhand_local_w(dt_ctx *c, const dt_window *win, const float *dem, const uint8_t *fdr,
@@ -789,7 +860,7 @@ static int dev_flowhand_finish_w(dt_ctx *c, const dt_window *win, const float *d
   DT_REQUIRE(c->scratch && c->scratch_owner == 2 && c->owner_h == w.H && c->owner_w == w.W,
              "flowhand finish without a matching dt_dev_flowhand_local_w on this context (another call has used the "
              "context's scratch in between)");
-  DT_TRY(dt_launch_fh_finish(c->stream, w, dem, fdr, river, acc, acc64, px, c->scratch, res_ok, res_nc, res_nd,
+  DT_TRY(dt_launch_fh_finish(c->stream, w, dem, fdr, river, acc, acc64, px, c->owner_ptr, res_ok, res_nc, res_nd,
                              (const long long *)rem_gidx, rem_zr, (const long long *)rem_ar, fdist, idx32,
                              (long long *)idx64, hand, a_river, fused ? gfi : nullptr, fused ? lnhlh : nullptr, n_gfi, b,
                              px));

@@ -37,7 +37,7 @@ void dt_set_error(const char *fmt, ...);
   } while (0)
 
 // ---- test / experiment knobs (dt_debug_set in the C ABI; all 0 by default) -------------------------
-enum { DT_DBG_TWI_FLAG_ALL = 0, DT_DBG_TWI_PLAIN = 1, DT_DBG_TWI_WX = 2, DT_DBG_TWI_MAP = 3, DT_DBG_DS_MARGIN = 4, DT_DBG_COUNT = 8 };
+enum { DT_DBG_TWI_FLAG_ALL = 0, DT_DBG_TWI_PLAIN = 1, DT_DBG_TWI_WX = 2, DT_DBG_TWI_MAP = 3, DT_DBG_DS_MARGIN = 4, DT_DBG_NO_FUSED_FA_FH = 5, DT_DBG_COUNT = 8 };
 #define DT_TWI_WX_DEFAULT 1 /* tile geometry of the fused slope + TI + MTI stencil: see k_slope_twi */
 int dt_debug_get(int key);
 
@@ -51,6 +51,8 @@ struct dt_ctx {
   size_t scratch_used;  // bump pointer, reset at the start of every entry point
   int scratch_owner;    // which two-phase op's state lives in `scratch` (0 none, 1 flow accumulation, 2 HAND):
   int64_t owner_h, owner_w;  // set by *_local_w, cleared by every dt_scratch_reset, required by *_finish_w
+  char *owner_ptr;      // where in `scratch` that state starts (HAND's follows flow accumulation's when phase 2 of the
+  char *owner_ptr2;     // one and phase 1 of the other are fused: owner_ptr2 = HAND's region reserved beside it)
   char *scratch2;       // rank-level solves (must not disturb the two-phase tile scratch)
   size_t scratch2_bytes;
   hipEvent_t ev;        // fork / join with another context's stream (created on first use)

@@ -47,6 +47,9 @@ int dt_launch_fa_finish(hipStream_t s, const DtWin &w, const uint8_t *fdr, const
                         const unsigned long long *ext_perim, int64_t river_thr, void *acc, int acc64,
                         int8_t *river, int *status = nullptr);
 size_t dt_flowhand_tiled_scratch(int64_t H, int64_t W);
+int dt_launch_fa_finish_fh_local(hipStream_t s, const DtWin &w, const uint8_t *fdr, const float *dem, void *fa_scratch,
+                                 void *fh_scratch, size_t fh_bytes, const unsigned long long *ext_perim,
+                                 int64_t river_thr, void *acc, int acc64, int8_t *river, int *status);
 int dt_launch_fh_local(hipStream_t s, const DtWin &w, const uint8_t *fdr, const int8_t *river, void *scratch,
                        size_t scratch_bytes);
 int dt_launch_fh_summary(hipStream_t s, const DtWin &w, void *scratch, const float *dem, const void *acc, int acc64,

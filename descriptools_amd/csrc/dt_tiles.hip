@@ -1052,28 +1052,18 @@ __global__ __launch_bounds__(256) void k_fh_tile1(const uint8_t *__restrict__ fd
 #define FN_LOW 0x7FFFFu  /* counts + done: what ONE addition propagates */
 #define FN_OVF 0x20100u  /* a count above 255 */
 #define FN_PTR_SH 19
-__global__ __launch_bounds__(256, 6) void k_fh_tile1n(const uint8_t *__restrict__ fdr,
-                                                     const int8_t *__restrict__ river, DtWin w, int tiles_x,
-                                                     uint32_t nnodes, unsigned long long *__restrict__ nodes,
-                                                     unsigned long long *__restrict__ cache,
-                                                     uint8_t *__restrict__ cache_wide) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_fdr[NT];
-  __shared__ __attribute__((aligned(16))) uint32_t s_w[NT];
-  __shared__ __attribute__((aligned(16))) uint8_t s_kind[NT];  // first the river mask, then the end kinds
-  __shared__ int s_ovf;
-  const int tile = dt_tile_of_block((int)blockIdx.x, (int)gridDim.x);
-  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-  const int y0 = ty * TH, x0 = tx * TW;
-  // the tile's codes and its river mask: both loads issued before the first is waited for.  (No halo ring of
-  // codes: "the successor's code is 0" need not be tested at the predecessor -- a cell whose code is 0 is a dead
-  // end in its own right (flowhand.py:601, :826), inside the tile through s_kind of the path's end, across a
-  // tile or rank border through that cell's perimeter node / ring summary.)
-  const uint4 v_fdr = dt_tile_fetch16(fdr, w, y0, x0);
-  const uint4 v_riv = dt_tile_fetch16(reinterpret_cast<const uint8_t *>(river), w, y0, x0);
-  dt_tile_put16(s_fdr, v_fdr);
-  dt_tile_put16(s_kind, v_riv);
-  if (threadIdx.x == 0) s_ovf = 0;
-  __syncthreads();
+// The narrow pass 1 from the point where the tile's codes (s_fdr) and its river mask (s_kind, one byte per cell) are
+// in LDS, *s_ovf is 0 and a barrier has been passed: shared by k_fh_tile1n (which stages both from HBM) and by
+// k_fa3fh1 (flow accumulation's last pass, which has the codes in registers and has just computed the mask).
+// (No halo ring of codes: "the successor's code is 0" need not be tested at the predecessor -- a cell whose code is 0
+// is a dead end in its own right (flowhand.py:601, :826), inside the tile through s_kind of the path's end, across a
+// tile or rank border through that cell's perimeter node / ring summary.)
+__device__ __forceinline__ void fh_tile1n_body(uint8_t *s_fdr, uint32_t *s_w, uint8_t *s_kind, int *s_ovf_p,
+                                               const DtWin &w, int tile, int tiles_x, int y0, int x0, uint32_t nnodes,
+                                               unsigned long long *__restrict__ nodes,
+                                               unsigned long long *__restrict__ cache,
+                                               uint8_t *__restrict__ cache_wide) {
+#define s_ovf (*s_ovf_p)
   uint32_t riv = 0;
 #pragma unroll
   for (int j = 0; j < CPT; j++)
@@ -1198,6 +1188,154 @@ __global__ __launch_bounds__(256, 6) void k_fh_tile1n(const uint8_t *__restrict_
     }
     nodes[(size_t)tile * PS + threadIdx.x] = o;
   }
+#undef s_ovf
+}
+
+__global__ __launch_bounds__(256, 6) void k_fh_tile1n(const uint8_t *__restrict__ fdr,
+                                                     const int8_t *__restrict__ river, DtWin w, int tiles_x,
+                                                     uint32_t nnodes, unsigned long long *__restrict__ nodes,
+                                                     unsigned long long *__restrict__ cache,
+                                                     uint8_t *__restrict__ cache_wide) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_fdr[NT];
+  __shared__ __attribute__((aligned(16))) uint32_t s_w[NT];
+  __shared__ __attribute__((aligned(16))) uint8_t s_kind[NT];  // first the river mask, then the end kinds
+  __shared__ int s_ovf;
+  const int tile = dt_tile_of_block((int)blockIdx.x, (int)gridDim.x);
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const int y0 = ty * TH, x0 = tx * TW;
+  // the tile's codes and its river mask: both loads issued before the first is waited for
+  const uint4 v_fdr = dt_tile_fetch16(fdr, w, y0, x0);
+  const uint4 v_riv = dt_tile_fetch16(reinterpret_cast<const uint8_t *>(river), w, y0, x0);
+  dt_tile_put16(s_fdr, v_fdr);
+  dt_tile_put16(s_kind, v_riv);
+  if (threadIdx.x == 0) s_ovf = 0;
+  __syncthreads();
+  fh_tile1n_body(s_fdr, s_w, s_kind, &s_ovf, w, tile, tiles_x, y0, x0, nnodes, nodes, cache, cache_wide);
+}
+
+// ---- flow accumulation's last pass and HAND's first pass in one kernel ----------------------------------------
+// Both stage the same 64 x 64 tile of direction codes, and HAND's river mask is what this pass has just computed
+// (acc > threshold): one read of the codes instead of two, no read of the mask, one launch and one tile staging less.
+// The common form only: int32 accumulation, tiles of whole 64-cell rows on 16-byte aligned rasters (the launcher
+// falls back to the two separate kernels otherwise).  The accumulation half is k_fa_tile3's vector path, the HAND
+// half fh_tile1n_body; they run one after the other in the same 25.5 KiB of LDS.
+template <bool HAS_DEM>
+__global__ __launch_bounds__(256, 6) void k_fa3fh1(const uint8_t *__restrict__ fdr, const float *__restrict__ dem,
+                                                  DtWin w, int tiles_x,
+                                                  const unsigned long long *__restrict__ ext,
+                                                  const uint16_t *__restrict__ loc16, int32_t *__restrict__ acc32,
+                                                  int32_t river_thr, int8_t *__restrict__ river,
+                                                  int *__restrict__ status, uint32_t nnodes,
+                                                  unsigned long long *__restrict__ nodes,
+                                                  unsigned long long *__restrict__ cache,
+                                                  uint8_t *__restrict__ cache_wide) {
+#define P3(c) ((uint32_t)(c) + (((uint32_t)(c) >> 6) << 2))
+#define NT3 (TH * (TW + 4))
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NT3 * 6];  // 26112 bytes
+  __shared__ unsigned long long s_in;
+  __shared__ int s_ovf;
+  // accumulation half: delta raster (also the staging area of the codes) + padded successor indices
+  uint32_t *s_delta = reinterpret_cast<uint32_t *>(smem);
+  uint16_t *s_nxt = reinterpret_cast<uint16_t *>(smem + NT3 * 4);
+  uint8_t *s_fdr0 = reinterpret_cast<uint8_t *>(s_delta);
+  const int tile = dt_tile_of_block((int)blockIdx.x, (int)gridDim.x);
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const uint4 v_fdr = dt_tile_fetch16(fdr, w, y0, x0);
+  unsigned long long e = 0ull;
+  if (threadIdx.x < PS) e = ext[(size_t)tile * PS + threadIdx.x];
+  constexpr int VPT = NT / 4 / 256;
+  uint2 l4[VPT];
+  float4 z4[VPT];
+#pragma unroll
+  for (int u = 0; u < VPT; u++) {
+    int c = 4 * (threadIdx.x + 256 * u);
+    int y = y0 + c / TW;
+    l4[u] = *reinterpret_cast<const uint2 *>(loc16 + (size_t)tile * NT + c);
+    z4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (HAS_DEM && y < w.H) z4[u] = *reinterpret_cast<const float4 *>(dem + (long long)y * w.ld + x0 + c % TW);
+  }
+  dt_tile_put16(s_fdr0, v_fdr);
+  if (threadIdx.x == 0) s_ovf = 0;
+  if (__syncthreads_or(!(e & FA_CYCLE) && FA_VALUE(e) >= (1ull << 22))) {  // see k_fa_tile3
+    if (threadIdx.x == 0) s_in = 0ull;
+    __syncthreads();
+    if (e != 0ull && !(e & FA_CYCLE)) atomicAdd(&s_in, FA_VALUE(e));
+    __syncthreads();
+    if (threadIdx.x == 0 && s_in >= (1ull << 31) - (unsigned long long)NT && status) atomicOr(status, DT_STATUS_ACC_OVERFLOW);
+  }
+  uint32_t nx[CPT];
+  if (dt_tile_interior(w, y0, x0)) {
+#pragma unroll
+    for (int j = 0; j < CPT; j++) {
+      int c = threadIdx.x + 256 * j;
+      nx[j] = dt_tile_next_interior(s_fdr0[c], c / TW, c % TW);
+    }
+  } else {
+    for (int j = 0; j < CPT; j++) {
+      int c = threadIdx.x + 256 * j;
+      nx[j] = dt_tile_next(s_fdr0[c], c / TW, c % TW, y0, x0, w);
+    }
+  }
+  __syncthreads();
+  for (int j = 0; j < CPT; j++) {
+    int c = threadIdx.x + 256 * j;
+    s_nxt[P3(c)] = (uint16_t)(nx[j] < NT ? P3(nx[j]) : nx[j]);
+    s_delta[P3(c)] = 0u;
+  }
+  __syncthreads();
+  if (e != 0ull) {
+    int ly, lx;
+    dt_cell_of_slot(threadIdx.x, ly, lx);
+    uint32_t c = P3(ly * TW + lx);
+    if (e & FA_CYCLE) {
+      for (int it = 0; it < NT && c < NT3; it++) {
+        atomicOr(&s_delta[c], 0x80000000u);
+        c = s_nxt[c];
+      }
+    } else {
+      const uint32_t add = (uint32_t)e;
+      for (int it = 0; it < NT && c < NT3; it++) {
+        atomicAdd(&s_delta[c], add);
+        c = s_nxt[c];
+      }
+    }
+  }
+  __syncthreads();
+  auto finish = [&](uint32_t l16, uint32_t d, float z) -> int32_t {
+    int32_t v = l16 == 0xFFFFu ? -100 : (int32_t)l16;
+    if (v != -100) v += (int32_t)(d & 0x7FFFFFFFu);
+    if (d & 0x80000000u) v = -100;
+    if (HAS_DEM && z <= DT_NODATA) v = -100;
+    return v;
+  };
+  uint32_t riv4[VPT];  // the river mask of the lane's 4 x 4 cells, one byte per cell
+#pragma unroll
+  for (int u = 0; u < VPT; u++) {
+    int c = 4 * (threadIdx.x + 256 * u);
+    int y = y0 + c / TW;
+    riv4[u] = 0u;
+    if (y >= w.H) continue;
+    long long o = (long long)y * w.ld + x0 + c % TW;
+    uint4 d = *reinterpret_cast<const uint4 *>(&s_delta[P3(c)]);
+    int4 v = make_int4(finish(l4[u].x & 0xFFFFu, d.x, z4[u].x), finish(l4[u].x >> 16, d.y, z4[u].y),
+                       finish(l4[u].y & 0xFFFFu, d.z, z4[u].z), finish(l4[u].y >> 16, d.w, z4[u].w));
+    *reinterpret_cast<int4 *>(acc32 + o) = v;
+    riv4[u] = (v.x > river_thr ? 1u : 0u) | (v.y > river_thr ? 0x100u : 0u) | (v.z > river_thr ? 0x10000u : 0u) |
+              (v.w > river_thr ? 0x1000000u : 0u);
+    *reinterpret_cast<uint32_t *>(river + o) = riv4[u];
+  }
+  __syncthreads();  // everybody is done with the delta raster: the same LDS now holds HAND's arrays
+#undef P3
+#undef NT3
+  uint32_t *s_w = reinterpret_cast<uint32_t *>(smem);             // 16 KiB
+  uint8_t *s_fdr = smem + NT * 4;                                  // 4 KiB
+  uint8_t *s_kind = smem + NT * 5;                                 // 4 KiB: first the river mask, then the end kinds
+  dt_tile_put16(s_fdr, v_fdr);
+#pragma unroll
+  for (int u = 0; u < VPT; u++) *reinterpret_cast<uint32_t *>(&s_kind[4 * (threadIdx.x + 256 * u)]) = riv4[u];
+  __syncthreads();
+  fh_tile1n_body(s_fdr, s_w, s_kind, &s_ovf, w, tile, tiles_x, y0, x0, nnodes, nodes, cache, cache_wide);
 }
 
 // ghost g of ring cell i: a fixed point (ptr = itself, no moves, not done) until resolved
@@ -1622,18 +1760,10 @@ size_t dt_flowhand_tiled_scratch(int64_t H, int64_t W) {
          dt_align256((size_t)ntiles * NT * 8) + 256 + dt_align256((size_t)ntiles);
 }
 
-// phase 1: tile pass + perimeter node doubling (rank exits park on their ghosts)
-int dt_launch_fh_local(hipStream_t s, const DtWin &w, const uint8_t *fdr, const int8_t *river, void *scratch,
-                       size_t scratch_bytes) {
-  if (w.H == 0 || w.W == 0) return DT_OK;
-  DT_REQUIRE(scratch_bytes >= dt_flowhand_tiled_scratch(w.H, w.W), "scratch too small");
-  FhScratch f = fh_layout(w, scratch);
-  DT_REQUIRE(f.nnodes + f.P < 0x7FFFFFF0ll, "raster too large for one device tile");
+// what follows the narrow tile pass in phase 1: the 64-bit solve for the tiles it had to give up (usually none: the
+// launch is 2048 workgroups that look at 32 flags each and leave), the ghosts, the perimeter node doubling
+static int fh_local_tail(hipStream_t s, const DtWin &w, const uint8_t *fdr, const int8_t *river, const FhScratch &f) {
   dim3 gt((unsigned)f.ntiles), b(256), gn((unsigned)((f.nnodes + f.P + 255) / 256));
-  // narrow solve everywhere, then the 64-bit solve for the tiles it had to give up (usually none: the
-  // second launch is 65536 workgroups that read one byte and leave)
-  hipLaunchKernelGGL(k_fh_tile1n, gt, b, 0, s, fdr, river, w, f.tiles_x, (uint32_t)f.nnodes, f.nodes, f.cache,
-                     f.cache_wide);
   hipLaunchKernelGGL(k_fh_tile1, dim3(gt.x < 2048u ? gt.x : 2048u), b, 0, s, fdr, river, w, f.tiles_x,
                      (uint32_t)f.nnodes, f.nodes, f.cache, f.cache_wide, 1, (int)f.ntiles);
   hipLaunchKernelGGL(k_fh_ghost_init, dim3((unsigned)((f.P + 255) / 256)), b, 0, s, f.nodes, (uint32_t)f.nnodes, f.P);
@@ -1646,6 +1776,61 @@ int dt_launch_fh_local(hipStream_t s, const DtWin &w, const uint8_t *fdr, const 
   for (int r = 0; r < 8; r++)
     hipLaunchKernelGGL(k_fh_node_jump, gj, b, 0, s, f.nodes, f.nnodes + f.P, flags, r, 3);
   return DT_OK;
+}
+
+// phase 1: tile pass + perimeter node doubling (rank exits park on their ghosts)
+int dt_launch_fh_local(hipStream_t s, const DtWin &w, const uint8_t *fdr, const int8_t *river, void *scratch,
+                       size_t scratch_bytes) {
+  if (w.H == 0 || w.W == 0) return DT_OK;
+  DT_REQUIRE(scratch_bytes >= dt_flowhand_tiled_scratch(w.H, w.W), "scratch too small");
+  FhScratch f = fh_layout(w, scratch);
+  DT_REQUIRE(f.nnodes + f.P < 0x7FFFFFF0ll, "raster too large for one device tile");
+  hipLaunchKernelGGL(k_fh_tile1n, dim3((unsigned)f.ntiles), dim3(256), 0, s, fdr, river, w, f.tiles_x,
+                     (uint32_t)f.nnodes, f.nodes, f.cache, f.cache_wide);
+  return fh_local_tail(s, w, fdr, river, f);
+}
+
+// Flow accumulation's phase 2 (inflow from other ranks, poison, last tile pass with the river mask) and HAND's phase 1
+// in one go.  `fa_scratch` holds the state dt_launch_fa_local left, `fh_scratch` receives HAND's.  In the common form
+// (int32 accumulation, rows of whole 64-cell tiles, 16-byte aligned rasters) the two tile passes are ONE kernel
+// (k_fa3fh1); otherwise they run one after the other.  Same results either way.
+int dt_launch_fa_finish_fh_local(hipStream_t s, const DtWin &w, const uint8_t *fdr, const float *dem, void *fa_scratch,
+                                 void *fh_scratch, size_t fh_bytes, const unsigned long long *ext_perim,
+                                 int64_t river_thr, void *acc, int acc64, int8_t *river, int *status) {
+  if (w.H == 0 || w.W == 0) return DT_OK;
+  DT_REQUIRE(fh_bytes >= dt_flowhand_tiled_scratch(w.H, w.W), "scratch too small");
+  DT_REQUIRE(river != nullptr, "HAND needs the river mask");
+  FaScratch f = fa_layout(w, fa_scratch);
+  FhScratch h = fh_layout(w, fh_scratch);
+  DT_REQUIRE(h.nnodes + h.P < 0x7FFFFFF0ll, "raster too large for one device tile");
+  dim3 gt((unsigned)f.ntiles), b(256), gn((unsigned)((f.nnodes + 255) / 256));
+  if (ext_perim) {
+    int64_t P = dt_perim_count(w.H, w.W);
+    hipLaunchKernelGGL(k_fa_propagate, dim3((unsigned)((P + 255) / 256)), b, 0, s, w, f.tiles_x, f.nnodes, f.nxt,
+                       ext_perim, P, f.ext);
+  }
+  hipLaunchKernelGGL(k_fa_poison, gn, b, 0, s, f.rec, f.nnodes, f.entry_of, f.state, f.ext);
+  const bool fused = !acc64 && dt_debug_get(DT_DBG_NO_FUSED_FA_FH) == 0 && w.W % TW == 0 && (w.ld & 3) == 0 &&
+                     (((uintptr_t)acc | (uintptr_t)dem) & 15) == 0 && ((uintptr_t)river & 3) == 0;
+  if (fused) {
+    int32_t thr = river_thr > 2147483647ll ? 2147483647 : (river_thr < -2147483647ll ? -2147483647 : (int32_t)river_thr);
+    if (dem)
+      hipLaunchKernelGGL(k_fa3fh1<true>, gt, b, 0, s, fdr, dem, w, f.tiles_x, f.ext, f.loc16, (int32_t *)acc, thr, river,
+                         status, (uint32_t)h.nnodes, h.nodes, h.cache, h.cache_wide);
+    else
+      hipLaunchKernelGGL(k_fa3fh1<false>, gt, b, 0, s, fdr, dem, w, f.tiles_x, f.ext, f.loc16, (int32_t *)acc, thr, river,
+                         status, (uint32_t)h.nnodes, h.nodes, h.cache, h.cache_wide);
+  } else {
+    if (acc64) {
+      fa_launch_tile3<long long>(s, gt, w, fdr, dem, f, (long long *)acc, (long long)river_thr, river, status);
+    } else {
+      int32_t thr = river_thr > 2147483647ll ? 2147483647 : (river_thr < -2147483647ll ? -2147483647 : (int32_t)river_thr);
+      fa_launch_tile3<int32_t>(s, gt, w, fdr, dem, f, (int32_t *)acc, thr, river, status);
+    }
+    hipLaunchKernelGGL(k_fh_tile1n, gt, b, 0, s, fdr, river, w, h.tiles_x, (uint32_t)h.nnodes, h.nodes, h.cache,
+                       h.cache_wide);
+  }
+  return fh_local_tail(s, w, fdr, river, h);
 }
 
 int dt_launch_fh_summary(hipStream_t s, const DtWin &w, void *scratch, const float *dem, const void *acc, int acc64,

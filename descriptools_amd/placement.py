@@ -1,0 +1,129 @@
+"""Placement-aware assignment of output rasters (net-new; no reference counterpart -- the reference round-trips every
+raster through the host).
+
+Measured on MI355X (tools/placement_probe.py, profiles/r3/placement_*): large device allocations fall
+into three CONFLICT CLASSES.  Two rasters of one class, written concurrently at equal offsets -- what every kernel
+with several output rasters does -- get ~6.1 TB/s of write bandwidth; rasters of different classes ~7 TB/s (pairs:
+0.345 vs 0.30 ms per 2 x 1 GiB; the L2 -> DRAM write-credit stalls of the busiest L2 channels are 5-10 x higher in
+the first case, request counts are identical, sub-page shifts of the bases change nothing).  The class is a property
+of where the driver put the allocation in physical memory: consecutive allocations share a class for many GiB (the
+first one or two of a process are usually of another class than the dozen that follow), so a chain that simply
+allocates its rasters one after the other gets slope, TI and MTI -- the three outputs of the fused stencil -- in ONE
+class, and the stencil runs at 66-68 % of the 8 TB/s figure instead of 75-80 %.
+
+This module labels raster-sized blocks by class with a few timed launches of the library's write-only kernel
+(dt_dev_membench_mix, ~1 ms per pair at 1 GiB) and hands the blocks to the roles that are written together so that
+no such group sits in a single class; when the blocks at hand are all of one class it allocates a bounded number of
+further candidates and keeps the ones that add a class.  Everything is measured at set-up time, nothing is assumed
+about the address map."""
+from . import _lib
+from ._lib import check
+
+MIN_BYTES = 64 << 20          # smaller rasters live in the caches' shadow: not worth a measurement
+PAIR_CONFLICT = 1.94          # a pair slower than this many single-stream times conflicts (1.8 x when it does not,
+                              # 2.08 x when it does)
+
+
+class WriteClassifier:
+    """conflict classes of device blocks of `nbytes` bytes on a context"""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.L = ctx, _lib.lib()
+        n = min(int(nbytes), 1 << 30) // 4
+        self.n = n // 65536 * 65536          # the write kernel walks rows of 16384 floats in groups of 4
+        self.reps = []                        # one representative pointer per class found so far
+        self.single_ms = None
+
+    def usable(self):
+        return self.n * 4 >= MIN_BYTES
+
+    def _time(self, ptrs, reps=3):
+        L, c = self.L, self.ctx
+        w = list(ptrs) + [ptrs[0]] * (3 - len(ptrs))
+
+        def launch():
+            check(L.dt_dev_membench_mix(c.h, None, None, w[0], w[1], w[2], self.n, 0, len(ptrs), 1))
+        launch()
+        c.sync()
+        import time
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            launch()
+        c.sync()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    def label(self, ptr):
+        """class id of the block at device pointer `ptr` (its contents are overwritten)"""
+        ptr = int(ptr)
+        if self.single_ms is None:
+            self.single_ms = min(self._time([ptr]), self._time([ptr]))
+        for k, r in enumerate(self.reps):
+            if self._time([r, ptr]) > PAIR_CONFLICT * self.single_ms:
+                return k
+        self.reps.append(ptr)
+        return len(self.reps) - 1
+
+
+def spread(labels, groups):
+    """labels: {block: class}; groups: lists of role names written together, most important first.  Returns
+    {role: block} using every block at most once, each group drawing from as many classes as possible (round robin
+    over the classes, the rarest class first), and the list of blocks left over."""
+    by_class = {}
+    for b, k in labels.items():
+        by_class.setdefault(k, []).append(b)
+    out = {}
+    for g in groups:
+        # rare classes are spent on the groups that come first; a role written alone takes from the commonest class
+        order = sorted(by_class, key=lambda k: len(by_class[k]), reverse=len(g) == 1)
+        i = 0
+        for role in g:
+            for _ in range(len(order)):
+                k = order[i % len(order)]
+                i += 1
+                if by_class[k]:
+                    out[role] = by_class[k].pop()
+                    break
+            else:
+                raise ValueError("fewer blocks than roles")
+    return out, [b for lst in by_class.values() for b in lst]
+
+
+def assign(ctx, nbytes, blocks, groups, extra_alloc=None, extra_release=None, budget=24):
+    """blocks: device pointers of equally sized blocks (>= one per role); groups: role names written together.
+    Returns ({role: pointer}, info) -- or (None, info) when the rasters are too small to bother.  When the blocks
+    span fewer classes than the largest group could use and `extra_alloc()` -> pointer is given, up to `budget`
+    further blocks are allocated and labelled; those that add diversity replace blocks of the majority class
+    (`extra_release(pointer)` gets every block that ends up unused, original or extra)."""
+    blocks = [b.value if hasattr(b, "value") else int(b) for b in blocks]
+    cl = WriteClassifier(ctx, nbytes)
+    if not cl.usable():
+        return None, {"tuned": False, "why": "rasters below %d MiB" % (MIN_BYTES >> 20)}
+    labels = {int(b): cl.label(b) for b in blocks}
+    want = min(3, max(len(g) for g in groups))   # three classes exist on MI355X; a group of 3 can use them all
+    need = sum(len(g) * 2 // 3 for g in groups if len(g) > 1)  # blocks outside the commonest class: 2/3 of each group
+    extras = []
+
+    def minority_blocks():
+        counts = {}
+        for k in labels.values():
+            counts[k] = counts.get(k, 0) + 1
+        major = max(counts, key=counts.get)
+        return sum(v for k, v in counts.items() if k != major), len(counts)
+    tried = 0
+    while extra_alloc is not None and tried < budget:
+        minority, nclasses = minority_blocks()
+        # enough when every group can avoid a single class: two blocks outside the majority class per group and
+        # (if reachable) three classes for the first group
+        if nclasses >= want and minority >= need:
+            break
+        p = int(extra_alloc())
+        tried += 1
+        extras.append(p)
+        labels[p] = cl.label(p)
+    roles, left = spread(labels, groups)
+    if extra_release is not None:
+        for b in left:
+            extra_release(b)
+    classes = {r: labels[b] for r, b in roles.items()}
+    return roles, {"tuned": True, "classes": classes, "candidates_tried": tried, "blocks": len(labels),
+                   "single_stream_ms": round(cl.single_ms, 4), "n_classes": len(cl.reps)}

@@ -261,10 +261,12 @@ class RankTile:
     """Extended rasters ((H + 2*HALO) x (W + 2*HALO)) of one rank and the windowed library calls."""
 
     def __init__(self, layout, rank, device=0, stream=None, px=10.0, n_top=0.1, n_gfi=0.4, b=0.1, dz=5.0,
-                 river_threshold=None, halo=HALO, idx64=None, acc64=None, rasters=None):
+                 river_threshold=None, halo=HALO, idx64=None, acc64=None, rasters=None, tune_placement=True):
         """acc64: flow accumulation (and the river accumulation payload) as int64 rasters, the reference's dtype --
         the default for a global raster of >= 2^31 cells, where a basin can exceed 32 bits; int32 rasters otherwise
-        (exact below 2^31 cells, half the bytes).  rasters: names of the rasters to allocate (default: all)."""
+        (exact below 2^31 cells, half the bytes).  rasters: names of the rasters to allocate (default: all).
+        tune_placement: hand the 4-byte rasters to their roles by measured write-conflict class (placement.py; only
+        rasters of >= 64 MiB are measured)."""
         import torch
         from . import _lib
         from .device import Context
@@ -296,6 +298,7 @@ class RankTile:
         sfx = "_a64" if self.acc64 else ""
         L = self.L
         self._f_fa_finish = getattr(L, "dt_dev_flowacc_finish_w" + sfx)
+        self._f_fa_finish_fh_local = getattr(L, "dt_dev_flowacc_finish_flowhand_local_w" + sfx)
         self._f_slope_twi = getattr(L, "dt_dev_slope_twi_w" + sfx)
         self._f_fh_local = getattr(L, "dt_dev_flowhand_local_w" + sfx)
         self._f_fh_finish = getattr(L, "dt_dev_flowhand_finish_w" + sfx)
@@ -312,6 +315,9 @@ class RankTile:
             if rasters is None or name in rasters:
                 t[name] = torch.zeros((self.He, self.We), dtype=dt, device=self.dev)
         self.t = t
+        self.placement = {"tuned": False, "why": "tune_placement=False"}
+        if tune_placement:
+            self._tune_placement()
         self.n_unres = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self.win = _lib.Window(self.H, self.W, self.We, self.gy0, self.gx0, layout.Hg, layout.Wg, halo)
         ys, xs = ring_coords(self.H, self.W)
@@ -337,6 +343,39 @@ class RankTile:
                      torch.zeros(max(self.P, 1), dtype=torch.int64, device=self.dev))
         self._on_ts.__exit__(None, None, None)
         self.ctx.sync()  # the buffers exist and are zero before anybody (any stream) touches them
+
+    def _tune_placement(self):
+        """placement.assign over this tile's 4-byte rasters (chain.Chain._tune_placement's counterpart): the rasters
+        one kernel writes together -- slope / TI / MTI; fdist / idx / hand / GFI / ln(hl/H) -- must not all lie in
+        one conflict class of the device's memory; further candidate blocks are tried when the first ones are alike"""
+        from . import placement
+        tc = self.torch
+        four = [n for n, x in self.t.items() if x.element_size() == 4]
+        if not four:
+            return
+        dts = {n: self.t[n].dtype for n in four}
+        objs = {self.t[n].data_ptr(): self.t[n] for n in four}
+        together = [[n for n in g if n in four] for g in (("slope", "ti", "mti"), ("fdist", "idx", "hand", "gfi", "lnhlh"))]
+        groups = [g for g in together if g] + [[n] for n in four if not any(n in g for g in together)]
+
+        def extra_alloc():
+            x = tc.zeros((self.He, self.We), dtype=tc.float32, device=self.dev)
+            objs[x.data_ptr()] = x
+            return x.data_ptr()
+
+        def extra_release(q):
+            objs.pop(q)
+        self.ctx.sync()
+        roles, info = placement.assign(self.ctx, self.He * self.We * 4, list(objs), groups, extra_alloc, extra_release)
+        self.placement = info
+        if roles is None:
+            return
+        for n, q in roles.items():
+            self.t[n] = objs[q].view(dts[n])
+            self.t[n].zero_()  # the measurement wrote into the blocks; the halos must read as zeros
+        objs.clear()
+        self.ctx.sync()
+        tc.cuda.empty_cache()
 
     def on_stream(self):
         """context manager: torch ops inside run on this tile's context stream"""
@@ -444,6 +483,21 @@ class RankTile:
                                                    self._ext.data_ptr()))
         self._chk(self._f_fa_finish(self.ctx.h, C.byref(self.win), self.p("fdr"), self.p("dem"),
                                     self._ext.data_ptr(), self.river_threshold, self.p("fac"), self.p("river")))
+
+    def fa_solve_finish_fh_local(self, rows):
+        """fa_solve_finish + fh_local in one call: the last accumulation tile pass and HAND's first share the tile's
+        direction codes and the river mask (one kernel in the common form, dt_dev_flowacc_finish_flowhand_local_w)"""
+        self._keep_rows = rows
+        self._chk(self.L.dt_dev_rank_solve_flowacc(self.ctx.h, self.layout.ty, self.layout.tx, self._heights,
+                                                   self._widths, self.pmax, rows.data_ptr(),
+                                                   FA_ROW_BYTES * self.pmax, self._fa_offs, self.rank, self.P,
+                                                   self._ext.data_ptr()))
+        v = self._fh_v
+        self._chk(self._f_fa_finish_fh_local(self.ctx.h, C.byref(self.win), self.p("fdr"), self.p("dem"),
+                                             self._ext.data_ptr(), self.river_threshold, self.p("fac"),
+                                             self.p("river"), v["kind"].data_ptr(), v["ref"].data_ptr(),
+                                             v["nc"].data_ptr(), v["nd"].data_ptr(), v["zr"].data_ptr(),
+                                             v["ar"].data_ptr()))
 
     def _idx_args(self):
         """(idx32, idx64) of the windowed HAND calls: the one of the two that matches the idx raster's dtype"""
@@ -716,8 +770,8 @@ class Exchange:
 # one rank's step as named stages in launch order: (name, algorithmic bytes per cell -- chain.OPS' definitions; 0 for
 # the exchanges --, what it covers)
 RANK_OPS = (
-    ("d8", 5), ("flowacc_local", 0), ("flowacc_gather", 0), ("downslope", 9), ("flowacc_solve_finish", 6),
-    ("flowhand_local", 2), ("flowhand_gather", 0), ("slope_twi", 20), ("flowhand_gfi_solve_finish", 28),
+    ("d8", 5), ("flowacc_local", 0), ("flowacc_gather", 0), ("downslope", 9), ("flowacc_finish_flowhand_local", 8),
+    ("flowhand_gather", 0), ("slope_twi", 20), ("flowhand_gfi_solve_finish", 28),
 )
 
 
@@ -735,9 +789,9 @@ def rank_ops(tile, layout, exchange):
     def fa_gather():
         st["fa"] = exchange.gather(tile.fa_row, exchange.fa_all)
 
-    def fa_finish():
+    def fa_finish_fh_local():
         exchange.wait()
-        tile.fa_solve_finish(st["fa"])
+        tile.fa_solve_finish_fh_local(st["fa"])
 
     def fh_gather():
         st["fh"] = exchange.gather(tile.fh_row, exchange.fh_all)
@@ -746,8 +800,7 @@ def rank_ops(tile, layout, exchange):
         exchange.wait()
         tile.fh_solve_finish(st["fh"], fuse_gfi=True, want_a_river=False)
 
-    calls = (tile.d8, fa_local, fa_gather, tile.downslope, fa_finish, lambda: tile.fh_local(sync=False), fh_gather,
-             tile.slope_twi, fh_finish)
+    calls = (tile.d8, fa_local, fa_gather, tile.downslope, fa_finish_fh_local, fh_gather, tile.slope_twi, fh_finish)
     return [(name, fn) for (name, _), fn in zip(RANK_OPS, calls)]
 
 
@@ -765,8 +818,7 @@ def run_rank(tile, layout, exchange, overlap=True):
     tile.fill_ring_codes()
     rows = exchange.gather(tile.fa_row, exchange.fa_all)
     exchange.wait()
-    tile.fa_solve_finish(rows)
-    tile.fh_local(sync=False)
+    tile.fa_solve_finish_fh_local(rows)
     rows = exchange.gather(tile.fh_row, exchange.fh_all)
     tile.slope_twi()
     exchange.wait()
@@ -809,9 +861,7 @@ def simulate_dev(tiles, layout):
         t.fill_ring_codes()
     rows = gather([t.fa_row for t in tiles])
     for t in tiles:
-        t.fa_solve_finish(rows)
-    for t in tiles:
-        t.fh_local(sync=False)
+        t.fa_solve_finish_fh_local(rows)
     rows = gather([t.fh_row for t in tiles])
     for t in tiles:
         t.fh_solve_finish(rows, fuse_gfi=True)

@@ -55,7 +55,9 @@ int dt_set_flow_impl(int impl);
 /* Test knobs, all 0 by default.  key 0 (DT_DBG_TWI_FLAG_ALL): the fused slope + TI + MTI stencil sends every
  * cell through its exact (cold) path as well as the fast one; key 1 (DT_DBG_TWI_PLAIN): default cache policy
  * instead of non-temporal loads / stores in that stencil (A/B timing); key 2 (DT_DBG_TWI_WX): tile geometry of that
- * stencil, 1 / 2 / 4 = tiles of 256 x 16 / 512 x 8 / 1024 x 4 cells (0 = the default). */
+ * stencil, 1 / 2 / 4 = tiles of 256 x 16 / 512 x 8 / 1024 x 4 cells (0 = the default); key 3 (DT_DBG_TWI_MAP): experimental
+ * workgroup -> tile maps of that stencil; key 4 (DT_DBG_DS_MARGIN): margin of the downslope kernel's LDS window (16 / 20;
+ * default 24); key 5 (DT_DBG_NO_FUSED_FA_FH): the last accumulation pass and HAND's first as two kernels (A/B timing). */
 int dt_debug_set(int key, int value);
 
 /* Context = one device + one stream + grow-only scratch.  `stream` may be NULL (the context
@@ -215,6 +217,11 @@ int dt_dev_flowacc(dt_ctx *ctx, const uint8_t *fdr, const float *dem, int64_t H,
  * same final pass */
 int dt_dev_flowacc_river(dt_ctx *ctx, const uint8_t *fdr, const float *dem, int64_t H, int64_t W,
                          int64_t threshold, int32_t *acc32, int8_t *river);
+/* the same and the first phase of HAND (tile solve, perimeter node doubling) in one call: the single-raster form
+ * of dt_dev_flowacc_finish_flowhand_local_w.  dt_dev_flowhand_finish_w / dt_dev_flowhand_gfi_finish_w with the whole
+ * raster as the window (ld = W, halo 0) follow on the same context. */
+int dt_dev_flowacc_river_flowhand_local(dt_ctx *ctx, const uint8_t *fdr, const float *dem, int64_t H, int64_t W,
+                                        int64_t threshold, int32_t *acc32, int8_t *river);
 int dt_dev_river_mask(dt_ctx *ctx, const int32_t *acc32, int64_t N, int64_t threshold,
                       int8_t *river);
 /* idx32: local flat index of the drained-to river cell (int32), -100 = none; a_river (may be
@@ -267,6 +274,15 @@ int dt_dev_flowacc_local_w(dt_ctx *ctx, const dt_window *win, const uint8_t *fdr
  * spanning ranks); NULL = none.  Must directly follow phase 1 on the same context. */
 int dt_dev_flowacc_finish_w(dt_ctx *ctx, const dt_window *win, const uint8_t *fdr, const float *dem,
                             const uint64_t *ext_perim, int64_t threshold, int32_t *acc32, int8_t *river);
+/* phase 2 of flow accumulation and phase 1 of HAND in one call: the last accumulation tile pass and HAND's first
+ * stage the same 64 x 64 tiles of direction codes, and HAND's river mask is what the accumulation pass has just
+ * computed, so in the common form (int32 accumulation, core width a multiple of 64, 16-byte aligned rasters) they are
+ * ONE kernel; otherwise the separate kernels run back to back.  Results and the state left in the context are those
+ * of dt_dev_flowacc_finish_w followed by dt_dev_flowhand_local_w (whose summary outputs kind ... ar these are). */
+int dt_dev_flowacc_finish_flowhand_local_w(dt_ctx *ctx, const dt_window *win, const uint8_t *fdr, const float *dem,
+                                           const uint64_t *ext_perim, int64_t threshold, int32_t *acc32, int8_t *river,
+                                           uint8_t *kind, int32_t *ref, int32_t *nc, int32_t *nd, float *zr,
+                                           int64_t *ar);
 /* phase 1: per ring cell, the path ENTERING the rank there: kind 1 = ends on river cell `ref` (core-local
  * flat index; zr / ar = its height / accumulation), 2 = dead, 4 = leaves the rank again through ring
  * cell `ref`; nc / nd = cardinal / diagonal moves (kind 4: including the step out of the rank).  Everything that
@@ -300,6 +316,10 @@ int dt_dev_flowhand_gfi_finish_w(dt_ctx *ctx, const dt_window *win, const float 
  * dt_dev_downslope_w do not touch the accumulation raster and are shared. */
 int dt_dev_flowacc_finish_w_a64(dt_ctx *ctx, const dt_window *win, const uint8_t *fdr, const float *dem,
                                 const uint64_t *ext_perim, int64_t threshold, int64_t *acc64, int8_t *river);
+int dt_dev_flowacc_finish_flowhand_local_w_a64(dt_ctx *ctx, const dt_window *win, const uint8_t *fdr, const float *dem,
+                                               const uint64_t *ext_perim, int64_t threshold, int64_t *acc64,
+                                               int8_t *river, uint8_t *kind, int32_t *ref, int32_t *nc, int32_t *nd,
+                                               float *zr, int64_t *ar);
 int dt_dev_slope_twi_w_a64(dt_ctx *ctx, const dt_window *win, const float *dem, const int64_t *acc64, double px,
                            double n_top, float *slope, float *slope_rad, float *ti, float *mti);
 int dt_dev_flowhand_local_w_a64(dt_ctx *ctx, const dt_window *win, const float *dem, const uint8_t *fdr,

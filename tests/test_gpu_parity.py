@@ -317,7 +317,10 @@ def test_full_size_16384_properties(dt):
     ch = chain.Chain(n, n, ctx=ctx, px=px, river_threshold=thr, alloc=alloc)
     ch.run(dem.data_ptr())
     ctx.sync()
-    t = {name: keep[i] for i, (name, _) in enumerate(chain.OUTPUTS)}
+    # the chain hands its blocks to the rasters by measured write-conflict class (placement.py): look them up by pointer
+    by_ptr = {x.data_ptr(): x for x in keep}
+    tdt = {np.float32: torch.float32, np.uint8: torch.uint8, np.int8: torch.int8, np.int32: torch.int32}
+    t = {name: by_ptr[ch.p(name)].view(tdt[dt]) for name, dt in chain.OUTPUTS}
     fdr, fac, river, idx, hand, fdist = t["fdr"], t["fac"], t["river"], t["idx"], t["hand"], t["fdist"]
     # (1) every cell drains to exactly one outlet: sum over outlets of (acc + 1) == number of cells
     #     (synthetic DEM: no nodata, no cycles); outlets = cells whose D8 step leaves the raster
