@@ -92,12 +92,12 @@ def main():
     ap.add_argument("--size", type=int, default=16384, help="tile edge per GPU")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-n", type=int, default=3072, help="edge of the CPU baseline's DEM (a bounded sample: ~20 s "
+    ap.add_argument("--cpu-n", type=int, default=3584, help="edge of the CPU baseline's DEM (a bounded sample: ~20 s "
                     "on one thread)")
     ap.add_argument("--no-verify", action="store_true", help="skip the cross-check of the timed step's rasters")
     ap.add_argument("--no-placement", action="store_true", help="rasters in allocation order (no placement tuning)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end_to_end block (host-tier API, PCIe included)")
-    ap.add_argument("--e2e-size", type=int, default=8192, help="edge of the host DEM of the end_to_end block")
+    ap.add_argument("--e2e-size", type=int, default=16384, help="edge of the host DEM of the end_to_end block")
     ap.add_argument("--graph", action="store_true", help="N = 1: the headline loop replays the step as one HIP graph "
                     "launch (chain.Chain.capture) instead of ~45 kernel launches")
     ap.add_argument("--no-overlap", action="store_true", help="headline loop on ONE stream, kernels back to back "
@@ -616,7 +616,7 @@ def end_to_end(n, seed):
     }
 
 
-def cpu_baseline(n=3072, seeds=(1,)):
+def cpu_baseline(n=3584, seeds=(1,)):
     """the reference's CPU path is its single-threaded `*_sequential_jit` family (Numba is not in
     this image), so the baseline is the oracle -- the same per-cell algorithms restated in C -- built with
     gcc -O3 -march=native, timed on the whole chain over an n x n DEM of the same generator: ONE thread (`value`),

@@ -415,6 +415,16 @@ extern "C" int dt_dev_condition_d8_async(dt_ctx *c, const float *dem, int64_t H,
   return DT_OK;
 }
 
+extern "C" int dt_dev_condition_stage_w(dt_ctx *c, const dt_window *win, int stage, int rounds, const float *dem,
+                                        float *filled, uint8_t *fdr, uint32_t *dist, int32_t *flag_dev) {
+  DT_CTX(c);
+  DtWin w;
+  DT_TRY(dt_convert_window(win, &w));
+  DT_TRY(dt_launch_condition_stage(c->stream, w, stage, rounds, dem, filled, fdr, dist, (int *)flag_dev));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+
 extern "C" int dt_dev_flowacc(dt_ctx *c, const uint8_t *fdr, const float *dem, int64_t H, int64_t W,
                               int32_t *acc32) {
   DT_CTX(c);

@@ -29,50 +29,56 @@
 
 __device__ __forceinline__ bool hy_nodata(float z) { return z == DT_NODATA; }
 
-// W = z on outlets (raster edge / next to nodata), +inf on the other valid cells, nodata stays nodata
-__global__ __launch_bounds__(256) void k_fill_init(const float *__restrict__ dem, int H, int W, float *__restrict__ wout) {
+// W = z on outlets (edge of the GLOBAL raster / next to nodata), +inf on the other valid cells, nodata stays nodata.
+// Windowed like every tile kernel: the core of `w`, neighbours read from the halo where the core ends inside the raster.
+__global__ __launch_bounds__(256) void k_fill_init(const float *__restrict__ dem, DtWin w, float *__restrict__ wout) {
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (int64_t)H * W) return;
-  int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
-  float z = dem[i];
+  if (i >= (int64_t)w.H * w.W) return;
+  int y = (int)(i / w.W), x = (int)(i - (int64_t)y * w.W);
+  const long long o = (long long)y * w.ld + x;
+  float z = dem[o];
   if (hy_nodata(z)) {
-    wout[i] = DT_NODATA;
+    wout[o] = DT_NODATA;
     return;
   }
-  bool outlet = y == 0 || x == 0 || y == H - 1 || x == W - 1;
+  const int gy = w.gy0 + y, gx = w.gx0 + x;
+  bool outlet = gy == 0 || gx == 0 || gy == w.Hg - 1 || gx == w.Wg - 1;
   if (!outlet) {
 #pragma unroll
     for (int dy = -1; dy <= 1; dy++)
 #pragma unroll
       for (int dx = -1; dx <= 1; dx++)
-        if ((dy || dx) && hy_nodata(dem[(int64_t)(y + dy) * W + x + dx])) outlet = true;
+        if ((dy || dx) && hy_nodata(dem[(long long)(y + dy) * w.ld + x + dx])) outlet = true;
   }
-  wout[i] = outlet ? z : __builtin_inff();
+  wout[o] = outlet ? z : __builtin_inff();
 }
 
 // stage the tile's 66 x 66 window of `src` into LDS; cells outside the raster read as `outside`
 template <typename T>
-__device__ __forceinline__ void hy_stage(T *s, const T *__restrict__ src, int H, int W, int y0, int x0, T outside) {
+__device__ __forceinline__ void hy_stage(T *s, const T *__restrict__ src, const DtWin &w, int y0, int x0, T outside) {
   for (int i = threadIdx.x; i < HLD * HLD; i += 256) {
     int r = i / HLD, c = i - r * HLD;
     int y = y0 - 1 + r, x = x0 - 1 + c;
-    s[i] = (y >= 0 && y < H && x >= 0 && x < W) ? src[(int64_t)y * W + x] : outside;
+    // inside the global raster and in this rank's memory (its core or its halo); a tile of a ragged last row / column
+    // reaches beyond the core into the halo, which is fine: those cells are read, never written
+    s[i] = dt_readable(w, y, x) ? src[(long long)y * w.ld + x] : outside;
   }
 }
 
 // one round of the fill: every tile to its local fixed point
 // `prev` (may be NULL): the previous round's flag -- a round that follows a quiet one has nothing to do and
 // returns at once (the asynchronous form enqueues a fixed budget of rounds and never asks the host)
-__global__ __launch_bounds__(256) void k_fill_relax(const float *__restrict__ dem, float *__restrict__ wsurf, int H,
-                                                   int W, int tiles_x, int *__restrict__ changed,
+__global__ __launch_bounds__(256) void k_fill_relax(const float *__restrict__ dem, float *__restrict__ wsurf, DtWin w,
+                                                   int tiles_x, int *__restrict__ changed,
                                                    const int *__restrict__ prev) {
+  const int H = w.H, W = w.W;
   __shared__ float s_w[HLD * HLD];
   if (prev && __hip_atomic_load(prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
   const int y0 = ty * HT, x0 = tx * HT;
   // outside the raster and nodata both read as +inf: they never lower a minimum (cells next to them are outlets
   // and already hold their final value)
-  hy_stage<float>(s_w, wsurf, H, W, y0, x0, __builtin_inff());
+  hy_stage<float>(s_w, wsurf, w, y0, x0, __builtin_inff());
   __syncthreads();
   for (int i = threadIdx.x; i < HLD * HLD; i += 256)
     if (hy_nodata(s_w[i])) s_w[i] = __builtin_inff();
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(256) void k_fill_relax(const float *__restrict__ de
     int c = threadIdx.x + 256 * j;
     int ly = c / HT, lx = c % HT;
     int y = y0 + ly, x = x0 + lx;
-    z[j] = (y < H && x < W) ? dem[(int64_t)y * W + x] : DT_NODATA;
+    z[j] = (y < H && x < W) ? dem[(long long)y * w.ld + x] : DT_NODATA;
   }
   __syncthreads();
   int any = 0;
@@ -112,7 +118,7 @@ __global__ __launch_bounds__(256) void k_fill_relax(const float *__restrict__ de
   for (int j = 0; j < H_CPT; j++) {
     int c = threadIdx.x + 256 * j;
     int y = y0 + c / HT, x = x0 + c % HT;
-    if (y < H && x < W && !hy_nodata(z[j])) wsurf[(int64_t)y * W + x] = s_w[(c / HT + 1) * HLD + (c % HT) + 1];
+    if (y < H && x < W && !hy_nodata(z[j])) wsurf[(long long)y * w.ld + x] = s_w[(c / HT + 1) * HLD + (c % HT) + 1];
   }
   if (threadIdx.x == 0) atomicOr(changed, 1);
 }
@@ -130,40 +136,41 @@ __device__ __forceinline__ void hy_scan_delta(int k, int &dy, int &dx) {
 
 // flats: dist = 0 for cells that have a code (and for nodata, which nobody asks), "infinite" for valid cells
 // without one; a code-less cell next to nodata drains into its first nodata neighbour right away
-__global__ __launch_bounds__(256) void k_flat_init(const float *__restrict__ wsurf, uint8_t *__restrict__ fdr, int H,
-                                                  int W, uint32_t *__restrict__ dist) {
+__global__ __launch_bounds__(256) void k_flat_init(const float *__restrict__ wsurf, uint8_t *__restrict__ fdr, DtWin w,
+                                                  uint32_t *__restrict__ dist) {
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (int64_t)H * W) return;
-  int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
+  if (i >= (int64_t)w.H * w.W) return;
+  int y = (int)(i / w.W), x = (int)(i - (int64_t)y * w.W);
+  const long long o = (long long)y * w.ld + x;
   uint32_t d = 0u;
-  if (!hy_nodata(wsurf[i]) && fdr[i] == 0) {
+  if (!hy_nodata(wsurf[o]) && fdr[o] == 0) {
     d = H_INF_DIST;
     for (int k = 0; k < 8; k++) {
       int dy, dx;
       hy_scan_delta(k, dy, dx);
-      int yy = y + dy, xx = x + dx;
-      if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;  // raster-edge cells got their outward code from the stencil
-      if (hy_nodata(wsurf[(int64_t)yy * W + xx])) {
-        fdr[i] = hy_code_of_scan(k);
+      if (!dt_in_global(w, y + dy, x + dx)) continue;  // raster-edge cells got their outward code from the stencil
+      if (hy_nodata(wsurf[(long long)(y + dy) * w.ld + x + dx])) {
+        fdr[o] = hy_code_of_scan(k);
         d = 0u;
         break;
       }
     }
   }
-  dist[i] = d;
+  dist[o] = d;
 }
 
 // one round of the flat distances: d(c) = 1 + min d(n) over neighbours of the same filled height
-__global__ __launch_bounds__(256) void k_flat_relax(const float *__restrict__ wsurf, uint32_t *__restrict__ dist, int H,
-                                                   int W, int tiles_x, int *__restrict__ changed,
+__global__ __launch_bounds__(256) void k_flat_relax(const float *__restrict__ wsurf, uint32_t *__restrict__ dist, DtWin w,
+                                                   int tiles_x, int *__restrict__ changed,
                                                    const int *__restrict__ prev) {
+  const int H = w.H, W = w.W;
   __shared__ float s_w[HLD * HLD];
   __shared__ uint32_t s_d[HLD * HLD];
   if (prev && __hip_atomic_load(prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
   const int y0 = ty * HT, x0 = tx * HT;
-  hy_stage<float>(s_w, wsurf, H, W, y0, x0, DT_NODATA);
-  hy_stage<uint32_t>(s_d, dist, H, W, y0, x0, H_INF_DIST);
+  hy_stage<float>(s_w, wsurf, w, y0, x0, DT_NODATA);
+  hy_stage<uint32_t>(s_d, dist, w, y0, x0, H_INF_DIST);
   __syncthreads();
   int any = 0;
   for (int it = 0; it < 4 * HT; it++) {
@@ -195,21 +202,22 @@ __global__ __launch_bounds__(256) void k_flat_relax(const float *__restrict__ ws
   for (int j = 0; j < H_CPT; j++) {
     int c = threadIdx.x + 256 * j;
     int y = y0 + c / HT, x = x0 + c % HT;
-    if (y < H && x < W) dist[(int64_t)y * W + x] = s_d[(c / HT + 1) * HLD + (c % HT) + 1];
+    if (y < H && x < W) dist[(long long)y * w.ld + x] = s_d[(c / HT + 1) * HLD + (c % HT) + 1];
   }
   if (threadIdx.x == 0) atomicOr(changed, 1);
 }
 
 // flat cells point at the first neighbour (scan order) of the same filled height that is one hop closer
 __global__ __launch_bounds__(256) void k_flat_assign(const float *__restrict__ wsurf, const uint32_t *__restrict__ dist,
-                                                    int H, int W, uint8_t *__restrict__ fdr,
+                                                    DtWin w, uint8_t *__restrict__ fdr,
                                                     int *__restrict__ unresolved) {
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (int64_t)H * W) return;
-  uint32_t d = dist[i];
+  if (i >= (int64_t)w.H * w.W) return;
+  int y = (int)(i / w.W), x = (int)(i - (int64_t)y * w.W);
+  const long long o = (long long)y * w.ld + x;
+  uint32_t d = dist[o];
   if (d == 0u) return;
-  int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
-  float wc = wsurf[i];
+  float wc = wsurf[o];
   uint8_t code = 0;
   if (d != H_INF_DIST) {
     // cardinal neighbours first (N, W, E, S), then the diagonals (NW, NE, SW, SE)
@@ -218,17 +226,16 @@ __global__ __launch_bounds__(256) void k_flat_assign(const float *__restrict__ w
       const int k = pref[q];
       int dy, dx;
       hy_scan_delta(k, dy, dx);
-      int yy = y + dy, xx = x + dx;
-      if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
-      int64_t n = (int64_t)yy * W + xx;
+      if (!dt_in_global(w, y + dy, x + dx)) continue;
+      long long n = (long long)(y + dy) * w.ld + x + dx;
       if (wsurf[n] == wc && dist[n] == d - 1u) code = hy_code_of_scan(k);
     }
   }
   if (!code) atomicAdd(unresolved, 1);
-  fdr[i] = code;
+  fdr[o] = code;
 }
 
-// scratch: flag words (256 B) + the distance raster
+// scratch: flag words + the distance raster
 // asynchronous form: the round flags (2 x up to DT_HYDRO_MAX_ASYNC_ROUNDS + the unresolved count) live in the
 // first 4 KiB
 #define DT_HYDRO_FLAG_BYTES 4096
@@ -250,22 +257,33 @@ __global__ void k_hydro_verdict(const int *__restrict__ last_fill, const int *__
 // far more often than there are tiles -- a serpentine channel with 1-cell walls crosses a 64-cell border 32 times --
 // so the number of tiles bounds nothing.)
 template <typename F>
-static int hy_iterate(hipStream_t s, int *flag, int64_t max_rounds, F round, int *rounds_out) {
+static int hy_iterate(hipStream_t s, int *flags, int64_t max_rounds, F round, int *rounds_out) {
+  // `round(flag, prev)` launches one relaxation round that raises *flag when it changed something and returns at
+  // once when *prev (the round before it, NULL for the first of a batch) was quiet.  Batches of 4, 8, ... 64 rounds
+  // with one flag read per batch; the rounds of a batch after its first quiet one cost a few microseconds each.
   int64_t rounds = 0;
   int batch = 4;
   for (;;) {
-    DT_HIP(hipMemsetAsync(flag, 0, sizeof(int), s));
-    for (int b = 0; b < batch; b++) round();
-    rounds += batch;
-    int h = 0;
-    DT_HIP(hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    DT_HIP(hipMemsetAsync(flags, 0, sizeof(int) * 64, s));
+    for (int b = 0; b < batch; b++) round(flags + b, b ? (const int *)(flags + b - 1) : (const int *)nullptr);
+    int h[64];
+    DT_HIP(hipMemcpyAsync(h, flags, sizeof(int) * (size_t)batch, hipMemcpyDeviceToHost, s));
     DT_HIP(hipStreamSynchronize(s));
-    if (!h) break;
+    int used = 0;
+    while (used < batch && h[used]) used++;
+    rounds += used < batch ? used + 1 : batch;  // the rounds that did something, and the quiet one that proved it
+    if (used < batch) break;
     DT_REQUIRE(rounds < max_rounds, "conditioning exceeded its proven bound of H * W rounds (a defect, not a property of the DEM)");
     if (batch < 64) batch *= 2;  // long-winded rasters: fewer host round trips per round
   }
   if (rounds_out) *rounds_out = (int)(rounds > 0x7FFFFFFF ? 0x7FFFFFFF : rounds);
   return DT_OK;
+}
+
+static DtWin hy_full_window(int64_t H, int64_t W) {
+  DtWin w;
+  w.H = (int)H; w.W = (int)W; w.ld = W; w.gy0 = 0; w.gx0 = 0; w.Hg = (int)H; w.Wg = (int)W; w.halo = 0;
+  return w;
 }
 
 // dem -> filled surface (may alias nothing), D8 codes with flats resolved.  *unresolved_host = flat cells left
@@ -276,24 +294,25 @@ int dt_launch_condition(hipStream_t s, const float *dem, int64_t H, int64_t W, d
   if (n == 0) return DT_OK;
   int *flag = (int *)scratch;
   uint32_t *dist = (uint32_t *)((char *)scratch + DT_HYDRO_FLAG_BYTES);
+  const DtWin w = hy_full_window(H, W);
   const int tiles_x = (int)((W + HT - 1) / HT), tiles_y = (int)((H + HT - 1) / HT);
   dim3 gc((unsigned)((n + 255) / 256)), gt((unsigned)(tiles_x * tiles_y)), b(256);
-  hipLaunchKernelGGL(k_fill_init, gc, b, 0, s, dem, (int)H, (int)W, filled);
+  hipLaunchKernelGGL(k_fill_init, gc, b, 0, s, dem, w, filled);
   int r1 = 0, r2 = 0;
   const int64_t max_rounds = n + 8;
-  DT_TRY(hy_iterate(s, flag, max_rounds, [&] { hipLaunchKernelGGL(k_fill_relax, gt, b, 0, s, dem, filled, (int)H, (int)W, tiles_x, flag, (const int *)nullptr); },
-                    &r1));
+  DT_TRY(hy_iterate(s, flag, max_rounds, [&](int *f, const int *prev) {
+    hipLaunchKernelGGL(k_fill_relax, gt, b, 0, s, dem, filled, w, tiles_x, f, prev);
+  }, &r1));
   if (fdr) {
-    DtWin w;
-    w.H = (int)H; w.W = (int)W; w.ld = W; w.gy0 = 0; w.gx0 = 0; w.Hg = (int)H; w.Wg = (int)W; w.halo = 0;
     DT_TRY(dt_launch_stencil(s, w, filled, px, nullptr, fdr, nullptr, nullptr, 0, 0.0, nullptr, nullptr));
-    hipLaunchKernelGGL(k_flat_init, gc, b, 0, s, filled, fdr, (int)H, (int)W, dist);
-    DT_TRY(hy_iterate(s, flag, max_rounds, [&] { hipLaunchKernelGGL(k_flat_relax, gt, b, 0, s, filled, dist, (int)H, (int)W, tiles_x, flag, (const int *)nullptr); },
-                      &r2));
-    DT_HIP(hipMemsetAsync(flag + 1, 0, sizeof(int), s));
-    hipLaunchKernelGGL(k_flat_assign, gc, b, 0, s, filled, dist, (int)H, (int)W, fdr, flag + 1);
+    hipLaunchKernelGGL(k_flat_init, gc, b, 0, s, filled, fdr, w, dist);
+    DT_TRY(hy_iterate(s, flag, max_rounds, [&](int *f, const int *prev) {
+      hipLaunchKernelGGL(k_flat_relax, gt, b, 0, s, filled, dist, w, tiles_x, f, prev);
+    }, &r2));
+    DT_HIP(hipMemsetAsync(flag + 64, 0, sizeof(int), s));
+    hipLaunchKernelGGL(k_flat_assign, gc, b, 0, s, filled, dist, w, fdr, flag + 64);
     int u = 0;
-    DT_HIP(hipMemcpyAsync(&u, flag + 1, sizeof(int), hipMemcpyDeviceToHost, s));
+    DT_HIP(hipMemcpyAsync(&u, flag + 64, sizeof(int), hipMemcpyDeviceToHost, s));
     DT_HIP(hipStreamSynchronize(s));
     if (unresolved_host) *unresolved_host = u;
   }
@@ -318,23 +337,63 @@ int dt_launch_condition_async(hipStream_t s, const float *dem, int64_t H, int64_
   DT_REQUIRE(rounds >= 1 && rounds <= DT_HYDRO_MAX_ASYNC_ROUNDS, "1..500 rounds");
   int *flags = (int *)scratch;  // [0, rounds): fill rounds; [rounds, 2 rounds): flat rounds; [2 rounds]: unresolved
   uint32_t *dist = (uint32_t *)((char *)scratch + DT_HYDRO_FLAG_BYTES);
+  const DtWin w = hy_full_window(H, W);
   const int tiles_x = (int)((W + HT - 1) / HT), tiles_y = (int)((H + HT - 1) / HT);
   dim3 gc((unsigned)((n + 255) / 256)), gt((unsigned)(tiles_x * tiles_y)), b(256);
   DT_HIP(hipMemsetAsync(flags, 0, DT_HYDRO_FLAG_BYTES, s));
-  hipLaunchKernelGGL(k_fill_init, gc, b, 0, s, dem, (int)H, (int)W, filled);
+  hipLaunchKernelGGL(k_fill_init, gc, b, 0, s, dem, w, filled);
   for (int r = 0; r < rounds; r++)
-    hipLaunchKernelGGL(k_fill_relax, gt, b, 0, s, dem, filled, (int)H, (int)W, tiles_x, flags + r,
+    hipLaunchKernelGGL(k_fill_relax, gt, b, 0, s, dem, filled, w, tiles_x, flags + r,
                        r ? (const int *)(flags + r - 1) : (const int *)nullptr);
-  DtWin w;
-  w.H = (int)H; w.W = (int)W; w.ld = W; w.gy0 = 0; w.gx0 = 0; w.Hg = (int)H; w.Wg = (int)W; w.halo = 0;
   DT_TRY(dt_launch_stencil(s, w, filled, px, nullptr, fdr, nullptr, nullptr, 0, 0.0, nullptr, nullptr));
-  hipLaunchKernelGGL(k_flat_init, gc, b, 0, s, filled, fdr, (int)H, (int)W, dist);
+  hipLaunchKernelGGL(k_flat_init, gc, b, 0, s, filled, fdr, w, dist);
   int *fl2 = flags + rounds;
   for (int r = 0; r < rounds; r++)
-    hipLaunchKernelGGL(k_flat_relax, gt, b, 0, s, filled, dist, (int)H, (int)W, tiles_x, fl2 + r,
+    hipLaunchKernelGGL(k_flat_relax, gt, b, 0, s, filled, dist, w, tiles_x, fl2 + r,
                        r ? (const int *)(fl2 + r - 1) : (const int *)nullptr);
-  hipLaunchKernelGGL(k_flat_assign, gc, b, 0, s, filled, dist, (int)H, (int)W, fdr, flags + 2 * rounds);
+  hipLaunchKernelGGL(k_flat_assign, gc, b, 0, s, filled, dist, w, fdr, flags + 2 * rounds);
   hipLaunchKernelGGL(k_hydro_verdict, dim3(1), dim3(1), 0, s, (const int *)(flags + rounds - 1),
                      (const int *)(fl2 + rounds - 1), (const int *)(flags + 2 * rounds), status);
+  return DT_OK;
+}
+
+// ---- the steps on one rank's window of a larger raster (multi-GPU: descriptools_amd/tiling.py iterates them with a
+// halo exchange of the surface / the distances in between until no rank changes anything) ---------------------
+// stage 0 init of the surface, 1 `rounds` fill rounds, 2 init of the flat distances (after D8 on the surface),
+// 3 `rounds` flat rounds, 4 assignment of the flat cells' codes.  *flag_dev (device int, zeroed by the caller per
+// iteration) is raised by stages 1 / 3 when something changed, and counts the unresolved cells in stage 4.
+int dt_launch_condition_stage(hipStream_t s, const DtWin &w, int stage, int rounds, const float *dem, float *filled,
+                              uint8_t *fdr, uint32_t *dist, int *flag_dev) {
+  const int64_t n = (int64_t)w.H * w.W;
+  if (n == 0) return DT_OK;
+  const int tiles_x = (w.W + HT - 1) / HT, tiles_y = (w.H + HT - 1) / HT;
+  dim3 gc((unsigned)((n + 255) / 256)), gt((unsigned)(tiles_x * tiles_y)), b(256);
+  DT_REQUIRE(rounds >= 1 || (stage != 1 && stage != 3), "rounds < 1");
+  switch (stage) {
+    case 0:
+      DT_REQUIRE(dem && filled, "NULL raster");
+      hipLaunchKernelGGL(k_fill_init, gc, b, 0, s, dem, w, filled);
+      break;
+    case 1:
+      DT_REQUIRE(dem && filled && flag_dev, "NULL pointer");
+      for (int r = 0; r < rounds; r++)
+        hipLaunchKernelGGL(k_fill_relax, gt, b, 0, s, dem, filled, w, tiles_x, flag_dev, (const int *)nullptr);
+      break;
+    case 2:
+      DT_REQUIRE(filled && fdr && dist, "NULL pointer");
+      hipLaunchKernelGGL(k_flat_init, gc, b, 0, s, filled, fdr, w, dist);
+      break;
+    case 3:
+      DT_REQUIRE(filled && dist && flag_dev, "NULL pointer");
+      for (int r = 0; r < rounds; r++)
+        hipLaunchKernelGGL(k_flat_relax, gt, b, 0, s, filled, dist, w, tiles_x, flag_dev, (const int *)nullptr);
+      break;
+    case 4:
+      DT_REQUIRE(filled && dist && fdr && flag_dev, "NULL pointer");
+      hipLaunchKernelGGL(k_flat_assign, gc, b, 0, s, filled, dist, w, fdr, flag_dev);
+      break;
+    default:
+      DT_REQUIRE(false, "stage must be 0..4");
+  }
   return DT_OK;
 }

@@ -55,7 +55,7 @@ class Layout:
         # at the core origin); only the last row / column of ranks may be ragged
         assert all(h % 64 == 0 for h in self.heights[:-1]) and all(w % 64 == 0 for w in self.widths[:-1]), \
             "rank tile heights / widths must be multiples of 64 (except the last row / column)"
-        # a rank tile must stay below 2^31 cells (32-bit in-rank indices).  A GLOBAL raster of >= 2^31 cells is
+        # a rank tile must stay below 2^31 cells (32-bit in-rank indices).  A GLOBAL raster beyond 2^31 cells is
         # allowed: its ranks keep the flow accumulation as int64 rasters (RankTile(acc64=...), the reference's own
         # dtype) -- with int32 rasters a basin that reaches 2^31 cells is detected at run time
         # (DT_STATUS_ACC_OVERFLOW, RankTile.check_status)
@@ -263,8 +263,8 @@ class RankTile:
     def __init__(self, layout, rank, device=0, stream=None, px=10.0, n_top=0.1, n_gfi=0.4, b=0.1, dz=5.0,
                  river_threshold=None, halo=HALO, idx64=None, acc64=None, rasters=None, tune_placement=True):
         """acc64: flow accumulation (and the river accumulation payload) as int64 rasters, the reference's dtype --
-        the default for a global raster of >= 2^31 cells, where a basin can exceed 32 bits; int32 rasters otherwise
-        (exact below 2^31 cells, half the bytes).  rasters: names of the rasters to allocate (default: all).
+        the default for a global raster of more than 2^31 cells, where a basin can exceed 32 bits; int32 rasters
+        otherwise (exact: an accumulation is at most cells - 1; half the bytes).  rasters: names of the rasters to allocate (default: all).
         tune_placement: hand the 4-byte rasters to their roles by measured write-conflict class (placement.py; only
         rasters of >= 64 MiB are measured)."""
         import torch
@@ -292,7 +292,9 @@ class RankTile:
         assert idx64 or layout.Hg * layout.Wg <= 2 ** 31
         self.idx_dtype = torch.int64 if idx64 else torch.int32
         if acc64 is None:
-            acc64 = layout.Hg * layout.Wg >= 2 ** 31
+            # an accumulation counts the upstream cells without the cell itself: <= cells - 1, which fits int32 up to
+            # and including a raster of exactly 2^31 cells (eight ranks of 16384^2)
+            acc64 = layout.Hg * layout.Wg > 2 ** 31
         self.acc64 = bool(acc64)
         self.acc_dtype = torch.int64 if self.acc64 else torch.int32
         sfx = "_a64" if self.acc64 else ""
@@ -437,6 +439,36 @@ class RankTile:
         dem = self.t["dem"].data_ptr() + off * 4
         fdr = self.t["fdr"].data_ptr() + off
         self._chk(self.L.dt_dev_slope_d8_w(self.ctx.h, C.byref(win), dem, self.px, None, fdr, None))
+
+    # ---- hydrological conditioning over ranks: see condition_ranks ------------------------------
+    def cond_alloc(self):
+        """the filled surface, the flat distances (extended rasters like the others) and the iteration flag"""
+        tc = self.torch
+        if "filled" not in self.t:
+            with self.on_stream():
+                self.t["filled"] = tc.zeros((self.He, self.We), dtype=tc.float32, device=self.dev)
+                self.t["dist"] = tc.zeros((self.He, self.We), dtype=tc.int32, device=self.dev)
+                self._cflag = tc.zeros(1, dtype=tc.int32, device=self.dev)
+            self.ctx.sync()
+
+    def cond_stage(self, stage, rounds=1):
+        """dt_dev_condition_stage_w on the core window; stages 1 / 3 / 4 start from a zeroed flag"""
+        if stage in (1, 3, 4):
+            with self.on_stream():
+                self._cflag.zero_()
+        self._chk(self.L.dt_dev_condition_stage_w(self.ctx.h, C.byref(self.win), stage, rounds, self.p("dem"),
+                                                  self.p("filled"), self.p("fdr"), self.p("dist"),
+                                                  self._cflag.data_ptr()))
+
+    def cond_flag(self):
+        self.ctx.sync()
+        return int(self._cflag.item())
+
+    def cond_d8(self):
+        """D8 codes of the CORE from the filled surface (its halo comes from the neighbours' exchange); the codes of
+        the halo are exchanged afterwards, not recomputed: they are the neighbours' conditioned codes"""
+        self._chk(self.L.dt_dev_slope_d8_w(self.ctx.h, C.byref(self.win), self.p("filled"), self.px, None,
+                                           self.p("fdr"), None))
 
     def ring_codes_dev(self):
         """D8 codes of the ring cells (device tensor, no synchronisation)."""
@@ -949,3 +981,85 @@ def evaluate_rank(tile, flood_core, comm, name="hand", under="under", class_map=
     if class_map:
         res["class_map"] = klass
     return res
+
+
+# ---------------------------------------------------------------------------------------------------
+# hydrological conditioning over ranks (single raster: dt_dev_condition_d8)
+# ---------------------------------------------------------------------------------------------------
+def condition_ranks(tiles, exchange, any_flag, rounds=4, max_iter=1 << 30):
+    """Depression filling + flat routing of a tiled DEM: the D8 codes every rank's step then starts from (instead of
+    RankTile.d8()).  Both fixed points are monotone relaxations, so each rank relaxes its own core against the halo it
+    has, the halos are exchanged, and the loop ends with the first iteration in which no rank changed anything -- the
+    result is the single raster's (tests/test_gpu_hydro.py: bit-identical).  One host synchronisation per iteration
+    (the flag), as in the single raster's synchronous form.
+
+    tiles: the RankTiles of THIS process with their DEM halos in place (one for a real rank, all of them for logical
+    ranks on one device); exchange(name): brings the halo of raster `name` up to date on every tile (exchange_halo
+    over torch.distributed, or exchange_halo_local); any_flag(values) -> bool: OR over ALL ranks of the per-tile
+    flags (an all-reduce for real ranks).  Returns (cells left without a code -- 0 --, fill iterations, flat
+    iterations)."""
+    for t in tiles:
+        t.cond_alloc()
+        t.cond_stage(0)
+    exchange("filled")
+    it_fill = it_flat = 0
+    for it_fill in range(1, max_iter + 1):
+        for t in tiles:
+            t.cond_stage(1, rounds)
+        changed = [t.cond_flag() for t in tiles]
+        exchange("filled")
+        if not any_flag(changed):
+            break
+    for t in tiles:
+        t.cond_d8()
+        t.cond_stage(2)
+    exchange("dist")
+    for it_flat in range(1, max_iter + 1):
+        for t in tiles:
+            t.cond_stage(3, rounds)
+        changed = [t.cond_flag() for t in tiles]
+        exchange("dist")
+        if not any_flag(changed):
+            break
+    for t in tiles:
+        t.cond_stage(4)
+    left = [t.cond_flag() for t in tiles]
+    exchange("fdr")
+    return sum(left), it_fill, it_flat
+
+
+def condition_local(tiles, layout, rounds=4):
+    """condition_ranks for N logical ranks living in one process (one device)"""
+    def exchange(name):
+        for t in tiles:
+            t.ctx.sync()
+        exchange_halo_local([t.t[name] for t in tiles], layout, tiles[0].halo)
+        tiles[0].torch.cuda.synchronize()
+    return condition_ranks(tiles, exchange, any, rounds)
+
+
+def condition_rank(tile, layout, group=None, rounds=4):
+    """condition_ranks for one real rank: point-to-point halo exchanges with the <= 8 neighbours, an all-reduce (MAX) of
+    the flag per iteration"""
+    import torch
+    import torch.distributed as dist
+    cpu = dist.get_backend(group) == "gloo"
+
+    def exchange(name):
+        tile.ctx.sync()
+        x = tile.t[name]
+        if cpu:
+            h = exchange_halo(x.cpu(), layout, tile.rank, tile.halo, group)
+            with tile.on_stream():
+                x.copy_(h)
+            tile.ctx.sync()
+        else:
+            with tile.on_stream():
+                exchange_halo(x, layout, tile.rank, tile.halo, group)
+            tile.ctx.sync()
+
+    def any_flag(vals):
+        f = torch.tensor([1 if any(vals) else 0], dtype=torch.int32, device="cpu" if cpu else tile.dev)
+        dist.all_reduce(f, op=dist.ReduceOp.MAX, group=group)
+        return bool(f.item())
+    return condition_ranks([tile], exchange, any_flag, rounds)

@@ -88,7 +88,7 @@ int dt_graph_destroy(dt_graph *graph);
 /* Sticky status bits raised by kernels since the last call (synchronises the context's stream, clears them).
  * DT_STATUS_ACC_OVERFLOW: a flow accumulation value of a multi-rank raster may have reached 2^31 cells while the step
  * ran with int32 accumulation rasters (the `_w` entry points; a device tile is < 2^31 cells), so its results are
- * not valid: rasters of >= 2^31 cells go through the `_w_a64` entry points (int64 rasters), which never raise it. */
+ * not valid: rasters of more than 2^31 cells go through the `_w_a64` entry points (int64 rasters), which never raise it. */
 #define DT_STATUS_ACC_OVERFLOW 1
 /* DT_STATUS_NOT_CONVERGED: dt_dev_condition_d8_async's budget of rounds ran out before the fixed point (or a flat
  * cell was left without a code): the conditioned rasters of that step are not valid. */
@@ -257,6 +257,15 @@ int dt_dev_confusion_multi(dt_ctx *ctx, const double *desc, const int8_t *flood,
  * cell of their core ring in between (descriptools_amd/tiling.py).  Ring order: top row, bottom row,
  * left column, right column (dt_perim_cells(H, W) rows). ------------------------------------------ */
 int64_t dt_perim_cells(int64_t H, int64_t W);
+/* hydrological conditioning on one rank's window (SURVEY.md 8f-4 tiled over ranks): the fixed points of
+ * dt_dev_condition_d8 are iterated per rank, with a halo exchange of the filled surface / the flat distances and an
+ * all-reduce of the "changed" flag in between (descriptools_amd/tiling.py: condition_ranks).  stage 0: init of the
+ * surface (outlets: edge of the GLOBAL raster, cells next to nodata); 1: `rounds` fill rounds over the core, reading
+ * the halo; 2: init of the flat distances (after D8 on the surface, dt_dev_slope_d8_w); 3: `rounds` flat rounds;
+ * 4: the flat cells' codes.  *flag_dev (device int32, zeroed by the caller): raised by stages 1 / 3 when a cell changed,
+ * number of cells left without a code after stage 4.  dist: uint32 raster laid out like the others. */
+int dt_dev_condition_stage_w(dt_ctx *ctx, const dt_window *win, int stage, int rounds, const float *dem, float *filled,
+                             uint8_t *fdr, uint32_t *dist, int32_t *flag_dev);
 int dt_dev_slope_d8_w(dt_ctx *ctx, const dt_window *win, const float *dem, double px, float *slope,
                       uint8_t *fdr, float *slope_rad);
 int dt_dev_slope_twi_w(dt_ctx *ctx, const dt_window *win, const float *dem, const int32_t *acc32, double px,
@@ -309,7 +318,8 @@ int dt_dev_flowhand_gfi_finish_w(dt_ctx *ctx, const dt_window *win, const float 
 
 /* ---- the same steps on int64 accumulation rasters (`_a64`).  The reference's flow accumulation is int64 end to
  * end (Example/example.py:39 reads it as int64; topoindexes.py:252-261, gfi.py:141-143 and :432-440 consume it).  On
- * the device a raster below 2^31 cells keeps it as int32 (half the bytes, exact); a raster of >= 2^31 cells split
+ * the device a raster of up to 2^31 cells keeps it as int32 (half the bytes; exact, an accumulation being at most
+ * cells - 1); a larger raster split
  * over ranks -- BASELINE.json configs[4], 65536^2 -- can hold basins beyond 32 bits, and its ranks run these entry
  * points instead: accumulation, river accumulation payload and every consumer (TI / MTI, HAND's river payload, GFI,
  * ln(hl/H)) in 64 bits; DT_STATUS_ACC_OVERFLOW is never raised.  dt_dev_flowacc_local_w, the rank-level solves and

@@ -1,6 +1,7 @@
 """GPU (-m gpu): BASELINE.json configs[4] -- the raster of >= 2^31 cells tiled over 8 ranks, "full chain +
 evaluation.py flood-map classifier" -- exercised on ONE MI355X as 2 x 4 logical ranks of 16384^2 (32768 x 65536 = 2^31
-cells, ~155 GB of the 288 GB): int64 flow accumulation (the default at this size), the rank-level solves on the GPU,
+cells, ~155 GB of the 288 GB): int64 flow accumulation (what a raster beyond 2^31 cells gets by default; at exactly 2^31
+cells int32 would still hold every value, so it is requested here), the rank-level solves on the GPU,
 the global river index in both widths, and the classifier's rank reductions.  No computation of the whole raster
 exists to compare with at this size (the global kernels index in 32 bits), so the checks are size-independent:
 
@@ -53,7 +54,7 @@ def _run_layout(layout, seed, thr, idx64, sample):
     Hg, Wg = layout.Hg, layout.Wg
     tiles = []
     for r in range(layout.size):
-        t = tiling.RankTile(layout, r, device=0, px=10.0, river_threshold=thr, idx64=idx64)
+        t = tiling.RankTile(layout, r, device=0, px=10.0, river_threshold=thr, idx64=idx64, acc64=True)
         assert t.acc64 and t.t["fac"].dtype == torch.int64 and t.t["a_river"].dtype == torch.int64
         t.synth_dem(seed)
         tiles.append(t)

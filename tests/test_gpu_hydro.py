@@ -198,3 +198,43 @@ def test_chain_with_conditioning():
     ch2.free()
     d_dem.free()
     ctx.close()
+
+
+@pytest.mark.parametrize("heights,widths", [([192, 130], [256, 200]), ([128, 128, 64], [192, 192])])
+def test_conditioning_tiled_over_ranks_equals_untiled(heights, widths):
+    """SURVEY.md 8f-4 tiled: N logical ranks iterate the two fixed points on their own windows with halo exchanges in
+    between (tiling.condition_ranks); filled surface and conditioned D8 codes must be the single raster's, bit for bit
+    -- including depressions and flats that span rank borders (the lake plateau and the pits straddle them)"""
+    import torch
+    from descriptools_amd import flowdir, tiling
+    layout = tiling.Layout(heights, widths)
+    Hg, Wg = layout.Hg, layout.Wg
+    px = 10.0
+    dem = _rough(Hg, Wg, 11)
+    dem[heights[0] - 12:heights[0] + 12, widths[0] - 20:widths[0] + 20] = dem[heights[0] - 12:heights[0] + 12,
+                                                                               widths[0] - 20:widths[0] + 20].min()
+    dem[dem == -100] = -100
+    fdr_u, filled_u = flowdir.d8_conditioned(dem, px, return_filled=True)
+    h = tiling.HALO
+    pad = np.zeros((Hg + 2 * h, Wg + 2 * h), np.float32)
+    pad[h:h + Hg, h:h + Wg] = dem
+    tiles = []
+    for r in range(layout.size):
+        t = tiling.RankTile(layout, r, device=0, px=px, river_threshold=10)
+        y0, x0 = layout.origin(r)
+        t.set_dem_ext(pad[y0:y0 + t.He, x0:x0 + t.We])
+        tiles.append(t)
+    left, it_fill, it_flat = tiling.condition_local(tiles, layout)
+    assert left == 0 and it_fill >= 2 and it_flat >= 1
+    for t in tiles:
+        y0, x0 = layout.origin(t.rank)
+        sl = (slice(y0, y0 + t.H), slice(x0, x0 + t.W))
+        assert np.array_equal(t.host("filled"), filled_u[sl]), "rank %d filled surface" % t.rank
+        assert np.array_equal(t.host("fdr"), fdr_u[sl]), "rank %d conditioned D8" % t.rank
+    # the halos hold the neighbours' conditioned codes: the step that follows needs them (downslope's margin)
+    t0 = tiles[0]
+    ext = t0.t["fdr"].cpu().numpy()
+    assert np.array_equal(ext[h:h + t0.H, h + t0.W:h + t0.W + 8], fdr_u[0:t0.H, t0.W:t0.W + 8])
+    for t in tiles:
+        t.free()
+    torch.cuda.empty_cache()

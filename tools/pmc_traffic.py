@@ -1,5 +1,6 @@
 """Build profiles/<round>/<tag>_pmc_traffic.json from two rocprofv3 counter runs
-(`--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, each of `python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline`).
+(`--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, each of `python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-verify
+--no-e2e --no-overlap --no-placement`: the serial schedule).
 
     python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [size]
 
@@ -31,14 +32,14 @@ def read(path, counter, steps):
 
 
 def main():
-    steps = 2  # warm-up + 1 timed step
+    steps = 4  # --no-overlap --steps 1 --warmup 1: (warm-up + timed step) of the headline loop and of the per-op loop
     fetch, calls = read(sys.argv[1], "FETCH_SIZE", steps)
     write, _ = read(sys.argv[2], "WRITE_SIZE", steps)
     size = int(sys.argv[4]) if len(sys.argv) > 4 else 16384
     out = {"size": size,
            "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate runs of `python3 bench.py "
-                   "--steps 1 --warmup 1 --no-cpu-baseline`; values are KB summed over a kernel's launches in the timed "
-                   "step; hbm_bytes = "
+                   "--steps 1 --warmup 1 --no-cpu-baseline --no-verify --no-e2e --no-overlap --no-placement`; values are KB "
+                   "summed over a kernel's launches in the last step; hbm_bytes = "
                    "(2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts 64 B per 128-B request on wide "
                    "coalesced reads, MI355X_MICROARCH.md HBM section; for the 64-B-row tile loads the factor 2 is "
                    "an upper bound)",
