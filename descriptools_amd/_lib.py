@@ -97,6 +97,7 @@ _SIGS = {
     "dt_dev_flowhand_gfi": (ci, [vp, vp, vp, vp, vp, i64, i64, f64, f64, f64, vp, vp, vp, vp, vp, vp]),
     "dt_dev_flowhand_gfi_finish_w": (ci, [vp, vp, vp, vp, vp, vp, f64, f64, f64, vp, vp, vp, vp, vp,
                                           vp, vp, vp, vp, vp, vp, vp, vp]),
+    "dt_ctx_set_priority": (ci, [vp, ci]),
     "dt_ctx_fork": (ci, [vp, vp]),
     "dt_ctx_join": (ci, [vp, vp]),
     "dt_dev_rank_solve_flowacc": (ci, [vp, ci, ci, c_i64p, c_i64p, i64, vp, i64, c_i64p, ci, i64, vp]),

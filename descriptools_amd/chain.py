@@ -34,10 +34,10 @@ WRITE_GROUPS = (("slope", "ti", "mti"), ("fdist", "idx", "hand", "gfi", "lnhlh")
 OPS = (
     ("d8", 5, ["k_d8<false>", "k_d8_fix"]),
     ("downslope", 9, ["k_downslope_win<24>"]),
-    ("flowacc_flowhand_local", 5 + 1 + 2, ["k_fa_tile1", "k_fa_reduce", "k_fa_poison", "k_fa3fh1<true>", "k_fh_tile1",
+    ("flowacc_flowhand_local", 5 + 1 + 2, ["k_fa_tile1<true>", "k_fa_reduce", "k_fa_poison", "k_fa3fh1<true>", "k_fh_tile1",
                                            "k_fh_ghost_init", "k_fh_node_jump"]),
-    ("flowhand_gfi_finish", 28, ["k_fh_tile3<false, 1, 5, int>"]),
     ("slope_twi", 20, ["k_slope_twi<true, false, 1, int, 1>", "k_slope_twi_fix<int, 1>"]),
+    ("flowhand_gfi_finish", 28, ["k_fh_tile3<false, 1, 5, int>"]),
 )
 
 
@@ -47,9 +47,8 @@ class Chain:
     def __init__(self, H, W, ctx=None, px=10.0, n_top=0.1, n_gfi=0.4, b=0.1, dz=5.0,
                  river_threshold=None, alloc=None, want_slope_rad=True, side_ctx=None, overlap=True,
                  condition=False, condition_rounds=64, tune_placement=True, release=None):
-        """overlap (the default): downslope runs as a second branch on its own stream (side_ctx, created on demand)
-        beside the flow-accumulation / HAND kernels, whose latency chains leave most of the GPU idle: ~3-5 % faster
-        end to end at 16384^2.  overlap=False: one stream, kernels back to back (what per-kernel timings need:
+        """overlap (the default): downslope and the slope + TI + MTI stencil run as a second branch on their own stream
+        (side_ctx, created on demand) beside the flow-accumulation / HAND kernels: ~3 % faster end to end at 16384^2.  overlap=False: one stream, kernels back to back (what per-kernel timings need:
         ops(serial=True) gives that order on a chain built either way).
         condition: the D8 codes come from the hydrologically conditioned surface (depressions filled, flats routed:
         dt_dev_condition_d8_async) instead of the plain steepest descent, for DEMs with pits and
@@ -117,9 +116,9 @@ class Chain:
 
     def ops(self, dem_ptr, want_a_river=False, serial=False):
         """The step as a list of (name, context, call) in launch order -- THE definition of the chain: run()
-        executes it, bench.py times it op by op.  With `overlap` the downslope op belongs to the side context
-        (forked after D8, joined at the end by run()); serial=True binds every op to the main context (one
-        stream, back to back), whatever the chain was built with."""
+        executes it, bench.py times it op by op.  With `overlap` the downslope and slope_twi ops belong to the side
+        context (run() forks it before each of them and joins at the end); serial=True binds every op to the main
+        context (one stream, back to back), whatever the chain was built with."""
         L, c, H, W = _lib.lib(), self.ctx, self.H, self.W
         p = self.p
         side = self.side if (self.side is not None and not serial) else c
@@ -137,20 +136,24 @@ class Chain:
                                                            p("down"))),
             ("flowacc_flowhand_local", c, lambda: L.dt_dev_flowacc_river_flowhand_local(
                 c.h, p("fdr"), dem_ptr, H, W, self.river_threshold, p("fac"), p("river"))),
+            ("slope_twi", side, lambda: L.dt_dev_slope_twi(side.h, dem_ptr, p("fac"), H, W, self.px, self.n_top,
+                                                           p("slope"), rad, p("ti"), p("mti"))),
             ("flowhand_gfi_finish", c, lambda: L.dt_dev_flowhand_gfi_finish_w(
                 c.h, C.byref(full), dem_ptr, p("fdr"), p("river"), p("fac"), self.px, self.n_gfi, self.b, None, None,
                 None, None, None, None, p("fdist"), p("idx"), None, p("hand"),
                 p("a_river") if want_a_river else None, p("gfi"), p("lnhlh"))),
-            ("slope_twi", c, lambda: L.dt_dev_slope_twi(c.h, dem_ptr, p("fac"), H, W, self.px, self.n_top, p("slope"),
-                                                        rad, p("ti"), p("mti"))),
         ]
 
     def run(self, dem_ptr, want_a_river=True):
-        """Enqueue the whole chain (asynchronous).  Downslope needs only the DEM and the D8 codes: with `overlap` it
-        runs as a second branch on the side context's stream between the D8 kernel and the end of the chain."""
+        """Enqueue the whole chain (asynchronous).  With `overlap` the side context's stream carries a second branch:
+        downslope (needs only the DEM and the D8 codes) from the D8 kernel on, then the slope + TI + MTI stencil (needs
+        the accumulation) beside HAND's last pass; the branches join at the end.  Of the two-stream schedules tried
+        (tools/schedule_probe.py, profiles/r3/schedule_probe.txt) this is the fastest by a small margin: every
+        split of these kernels over two streams lands within 0.3 ms of the serial order, stream priorities and the
+        fork point make no difference -- concurrent kernels share LDS and bandwidth, they do not add them."""
         for name, ctx, call in self.ops(dem_ptr, want_a_river):
-            if name == "downslope" and self.side is not None:
-                self.ctx.fork(self.side)
+            if ctx is not self.ctx:
+                self.ctx.fork(ctx)  # the branch sees everything enqueued on the main stream so far
             check(call())
         if self.side is not None:
             self.ctx.join(self.side)

@@ -66,6 +66,8 @@ extern "C" int dt_ctx_create(int device, void *stream, dt_ctx **out) {
   c->ev = nullptr;
   c->aux = nullptr;
   c->aux_bytes = 0;
+  c->ds_work = nullptr;
+  c->ds_work_bytes = 0;
   c->ws_gen = 0;
   c->status = nullptr;
   if (hipMalloc((void **)&c->status, 64) != hipSuccess || hipMemset(c->status, 0, 64) != hipSuccess) {
@@ -108,6 +110,7 @@ extern "C" int dt_ctx_destroy(dt_ctx *c) {
   if (c->scratch) (void)hipFree(c->scratch);
   if (c->scratch2) (void)hipFree(c->scratch2);
   if (c->aux) (void)hipFree(c->aux);
+  if (c->ds_work) (void)hipFree(c->ds_work);
   if (c->status) (void)hipFree(c->status);
   if (c->ev) (void)hipEventDestroy(c->ev);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -129,6 +132,24 @@ extern "C" int dt_ctx_set_stream(dt_ctx *c, void *stream) {
   return DT_OK;
 }
 extern "C" void *dt_ctx_stream(dt_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+// The context's own stream re-created with a scheduling priority: -1 high, 0 normal, +1 low (clamped to what the
+// device offers).  A side branch of a pipeline on a LOW-priority stream fills the slots the main branch leaves
+// idle instead of competing with it for every freed slot.
+extern "C" int dt_ctx_set_priority(dt_ctx *c, int priority) {
+  DT_REQUIRE(c != nullptr, "ctx is NULL");
+  DT_REQUIRE(c->own_stream, "the context runs on a caller's stream: create that stream with the priority wanted");
+  DT_HIP(hipSetDevice(c->device));
+  int least = 0, greatest = 0;  // numerically: least priority = largest value
+  DT_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  int pr = priority < greatest ? greatest : (priority > least ? least : priority);
+  hipStream_t ns = nullptr;
+  DT_HIP(hipStreamCreateWithPriority(&ns, hipStreamNonBlocking, pr));
+  DT_HIP(hipStreamSynchronize(c->stream));
+  DT_HIP(hipStreamDestroy(c->stream));
+  c->stream = ns;
+  return DT_OK;
+}
 
 // `waiter`'s stream waits for everything enqueued so far on `signaller`'s stream (no host synchronisation)
 static int dt_ctx_order(dt_ctx *signaller, dt_ctx *waiter) {
@@ -571,7 +592,8 @@ extern "C" int dt_dev_downslope(dt_ctx *c, const float *dem, const uint8_t *fdr,
   if (dt_flow_impl() == 1) {  // v1: one thread per cell walking global memory (kept for A/B and verification runs)
     DT_TRY(dt_launch_downslope_v1(c->stream, dem, fdr, H, W, px, dz, raw, out));
   } else {
-    DT_TRY(dt_launch_downslope(c->stream, dt_full_window(H, W), dem, fdr, px, dz, raw, out, nullptr));
+    DT_TRY(dt_side_reserve(c, &c->ds_work, &c->ds_work_bytes, dt_downslope_work_bytes(H, W)));
+    DT_TRY(dt_launch_downslope(c->stream, dt_full_window(H, W), dem, fdr, px, dz, raw, out, nullptr, c->ds_work));
   }
   DT_HIP(hipGetLastError());
   return DT_OK;
@@ -704,7 +726,8 @@ extern "C" int dt_dev_downslope_w(dt_ctx *c, const dt_window *win, const float *
   DT_TRY(dt_convert_window(win, &w));
   DT_REQUIRE(dem && fdr && out, "NULL raster");
   if (n_unresolved_dev) DT_HIP(hipMemsetAsync(n_unresolved_dev, 0, sizeof(int32_t), c->stream));
-  DT_TRY(dt_launch_downslope(c->stream, w, dem, fdr, px, dz, raw, out, (int *)n_unresolved_dev));
+  DT_TRY(dt_side_reserve(c, &c->ds_work, &c->ds_work_bytes, dt_downslope_work_bytes(w.H, w.W)));
+  DT_TRY(dt_launch_downslope(c->stream, w, dem, fdr, px, dz, raw, out, (int *)n_unresolved_dev, c->ds_work));
   DT_HIP(hipGetLastError());
   return DT_OK;
 }

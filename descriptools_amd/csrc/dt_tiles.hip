@@ -205,6 +205,62 @@ __device__ __forceinline__ void dt_tile_sums(uint16_t *s_ptr, uint32_t *s_recv, 
   __syncthreads();
 }
 
+// The same rounds with ONE random LDS access per cell and round instead of two: pointer word and receive word share
+// a 32-bit LDS word (ptr:16 << 16 | recv:16), and the scatter is a RETURNING atomic add whose old value carries the
+// target's pointer word -- the add and the gather are one instruction.  The receive field cannot carry into the
+// pointer: off cycles a round delivers <= 4096 to a cell (the senders' subtrees are disjoint), and what a cell
+// sends is clamped to 4096 (only cells ON an in-tile cycle ever exceed it, one such sender per target and round),
+// so a round delivers <= 8192 < 2^16.  The owner reads and rewrites its pair of words (one conflict-free 64-bit
+// access each way) between the barriers.
+__device__ __forceinline__ void dt_tile_sums_packed(uint32_t *s_word, uint8_t *s_cyc, uint32_t (&va)[CPT / 2],
+                                                    uint32_t (&vb)[CPT / 2]) {
+  uint32_t P[CPT / 2];  // my two pointer words: cell a | cell b << 16
+  unsigned long long *s_word2 = reinterpret_cast<unsigned long long *>(s_word);
+#pragma unroll
+  for (int j = 0; j < CPT / 2; j++) {
+    unsigned long long r = s_word2[threadIdx.x + 256 * j];
+    P[j] = ((uint32_t)r >> 16) | ((uint32_t)(r >> 32) & 0xFFFF0000u);
+    va[j] = vb[j] = 1u;
+  }
+  for (int round = 0; round < 12; round++) {
+    int any = 0;
+#pragma unroll
+    for (int j = 0; j < CPT / 2; j++) {
+      const uint32_t p = P[j];
+      if (p & PT_ALIVE) {
+        P[j] = (P[j] & 0xFFFF0000u) | (atomicAdd(&s_word[p & PT_IDX], min(va[j], (uint32_t)NT)) >> 16);
+        any = 1;
+      }
+      if (p & (PT_ALIVE << 16)) {
+        P[j] = (P[j] & 0xFFFFu) | (atomicAdd(&s_word[(p >> 16) & PT_IDX], min(vb[j], (uint32_t)NT)) & 0xFFFF0000u);
+        any = 1;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < CPT / 2; j++) {
+      int c2 = threadIdx.x + 256 * j;
+      unsigned long long r = s_word2[c2];
+      va[j] += (uint32_t)r & 0xFFFFu;
+      vb[j] += (uint32_t)(r >> 32) & 0xFFFFu;
+      s_word2[c2] = ((unsigned long long)(P[j] & 0xFFFF0000u) << 32) | (unsigned long long)(P[j] << 16);
+    }
+    if (!__syncthreads_or(any)) break;
+  }
+  // still alive after 2^12 moves: the path never ends inside the tile -> in-tile cycle
+#pragma unroll
+  for (int j = 0; j < CPT / 2; j++) {
+    if (P[j] & PT_ALIVE) s_cyc[P[j] & PT_IDX] = 1;
+    if (P[j] & (PT_ALIVE << 16)) s_cyc[(P[j] >> 16) & PT_IDX] = 1;
+  }
+  // the final sums beside the final pointers, where the perimeter lanes read both with one load
+#pragma unroll
+  for (int j = 0; j < CPT / 2; j++)
+    s_word2[threadIdx.x + 256 * j] = ((unsigned long long)((P[j] & 0xFFFF0000u) | (vb[j] & 0xFFFFu)) << 32) |
+                                     (unsigned long long)((P[j] << 16) | (va[j] & 0xFFFFu));
+  __syncthreads();
+}
+
 // countdown word of an exit node in the perimeter graph: pending feeders << 54 | sum of what arrived so far
 #define FA_NONE 0xFFFFFFFFu
 #define FA2_SH 54 /* pending count in bits 54-63: a tile exit has at most 260 feeders (the cells around the tile) */
@@ -227,6 +283,7 @@ __device__ __forceinline__ unsigned long long fa_rec(uint32_t W_, uint32_t xslot
 #define REC_XSLOT(r) ((uint32_t)(((r) >> 16) & 0xFFFFu))
 #define REC_CODE(r) ((uint32_t)(((r) >> 8) & 0xFFu))
 
+template <bool PACKED>
 __global__ __launch_bounds__(256, 6) void k_fa_tile1(const uint8_t *__restrict__ fdr, DtWin w, int tiles_x,
                                                     unsigned long long *__restrict__ rec,
                                                     uint16_t *__restrict__ loc16,
@@ -237,9 +294,12 @@ __global__ __launch_bounds__(256, 6) void k_fa_tile1(const uint8_t *__restrict__
   // 24 KiB of LDS: six tiles per CU.  The direction codes are staged through the receive array (free until
   // the rounds start), which is all zero again when the rounds end and then serves as the cycle mask (bytes
   // [0, 4 KiB)), the pending counts (252 words from 4 KiB) and the final sums (16 bits per cell from 8 KiB).
-  __shared__ __attribute__((aligned(16))) uint16_t s_ptr[NT];   // idx:12 | PT_EXIT | PT_ALIVE
+  // PACKED (the default): 21 KiB -- one 32-bit word per cell (pointer word << 16 | receive field, dt_tile_sums_packed)
+  // and 5 KiB that stage the codes, then hold the cycle mask and the pending counts.
+  __shared__ __attribute__((aligned(16))) uint16_t s_ptr[PACKED ? 8 : NT];   // idx:12 | PT_EXIT | PT_ALIVE
   __shared__ __attribute__((aligned(16))) uint32_t s_recv[NT];  // what a cell receives in a round
-  uint8_t *s_fdr = reinterpret_cast<uint8_t *>(s_recv);
+  __shared__ __attribute__((aligned(16))) uint32_t s_aux[PACKED ? NT / 4 + 256 : 4];
+  uint8_t *s_fdr = reinterpret_cast<uint8_t *>(PACKED ? s_aux : s_recv);
   const int tile = dt_tile_of_block((int)blockIdx.x, (int)gridDim.x);
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int y0 = ty * TH, x0 = tx * TW;
@@ -306,37 +366,52 @@ __global__ __launch_bounds__(256, 6) void k_fa_tile1(const uint8_t *__restrict__
     }
   }
   __syncthreads();
-  uint8_t *s_cyc = reinterpret_cast<uint8_t *>(s_recv);
-  uint32_t *s_pend = s_recv + NT / 4;  // 252 words above the cycle mask (the array is all zero after the rounds)
+  uint8_t *s_cyc = reinterpret_cast<uint8_t *>(PACKED ? s_aux : s_recv);
+  uint32_t *s_pend = PACKED ? s_aux + NT / 4 : s_recv + NT / 4;  // 252 words above the cycle mask (all zero after the rounds)
   for (int j = 0; j < CPT; j++) {
     int c = threadIdx.x + 256 * j;
     uint32_t n = nx[j];
     // terminals point at themselves; an exit terminal carries PT_EXIT, which every cell whose
     // in-tile path ends there inherits through the jumps
     bool ex = (n == NX_EXIT || n == NX_REXIT);
-    s_ptr[c] = (uint16_t)(n < NT ? (n | PT_ALIVE) : ((uint32_t)c | (ex ? PT_EXIT : 0u)));
-    s_recv[c] = 0u;
+    const uint32_t pw = n < NT ? (n | PT_ALIVE) : ((uint32_t)c | (ex ? PT_EXIT : 0u));
+    if (PACKED) {
+      s_recv[c] = pw << 16;
+    } else {
+      s_ptr[c] = (uint16_t)pw;
+      s_recv[c] = 0u;
+    }
+  }
+  if (PACKED) {  // the staged codes have been consumed (barrier above): cycle mask and pending counts start at zero
+    reinterpret_cast<uint4 *>(s_aux)[threadIdx.x] = make_uint4(0, 0, 0, 0);
+    s_aux[NT / 4 + threadIdx.x] = 0u;
   }
   __syncthreads();
   uint32_t va[CPT / 2], vb[CPT / 2];  // running sums of my cells 2 (t + 256 j) and + 1
-  dt_tile_sums(s_ptr, s_recv, s_cyc, va, vb);
-  // the final sums where the perimeter lanes can read them (<= 4096 off cycles: 16 bits)
-  uint32_t *s_val2 = s_recv + NT / 2;
-  const uint16_t *s_val = reinterpret_cast<const uint16_t *>(s_val2);
+  const uint16_t *s_val = nullptr;
+  if (PACKED) {
+    dt_tile_sums_packed(s_recv, s_cyc, va, vb);
+  } else {
+    dt_tile_sums(s_ptr, s_recv, s_cyc, va, vb);
+    // the final sums where the perimeter lanes can read them (<= 4096 off cycles: 16 bits)
+    uint32_t *s_val2 = s_recv + NT / 2;
+    s_val = reinterpret_cast<const uint16_t *>(s_val2);
 #pragma unroll
-  for (int j = 0; j < CPT / 2; j++) s_val2[threadIdx.x + 256 * j] = (va[j] & 0xFFFFu) | (vb[j] << 16);
-  __syncthreads();
+    for (int j = 0; j < CPT / 2; j++) s_val2[threadIdx.x + 256 * j] = (va[j] & 0xFFFFu) | (vb[j] << 16);
+    __syncthreads();
+  }
   if (threadIdx.x < PS) {
     int ly, lx;
     dt_cell_of_slot(threadIdx.x, ly, lx);
     int c = ly * TW + lx;
-    uint32_t p = s_ptr[c];
+    const uint32_t pv = PACKED ? s_recv[c] : ((uint32_t)s_ptr[c] << 16) | (uint32_t)s_val[c];
+    uint32_t p = pv >> 16;
     uint32_t xs = X_NONE;
     if (!(p & PT_ALIVE) && (p & PT_EXIT)) {
       uint32_t f = p & PT_IDX;
       xs = (uint32_t)dt_slot_of((int)f / TW, (int)f % TW);
     }
-    rec[(size_t)tile * PS + threadIdx.x] = fa_rec(my_code ? (uint32_t)s_val[c] : 0u, xs, my_code, my_flags);
+    rec[(size_t)tile * PS + threadIdx.x] = fa_rec(my_code ? (pv & 0xFFFFu) : 0u, xs, my_code, my_flags);
     // what enters at my cell waits at the exit its in-tile path leads to
     if (xs != X_NONE && feeders) atomicAdd(&s_pend[xs], feeders);
     const uint32_t me = (uint32_t)tile * PS + threadIdx.x, par = xs != X_NONE ? (uint32_t)tile * PS + xs : FA_NONE;
@@ -746,8 +821,12 @@ int dt_launch_fa_local(hipStream_t s, const DtWin &w, const uint8_t *fdr, void *
   DT_REQUIRE(f.nnodes < 0x7FFFFFF0ll, "raster too large for one device tile");
   dim3 gt((unsigned)f.ntiles), b(256), gn((unsigned)((f.nnodes + 255) / 256));
   (void)acc32;  // written by pass 3 only
-  hipLaunchKernelGGL(k_fa_tile1, gt, b, 0, s, fdr, w, f.tiles_x, f.rec, f.loc16, f.state, f.ext, f.entry_of,
-                     f.parent);
+  if (dt_debug_get(DT_DBG_FA_TILE1_OLD))
+    hipLaunchKernelGGL(k_fa_tile1<false>, gt, b, 0, s, fdr, w, f.tiles_x, f.rec, f.loc16, f.state, f.ext, f.entry_of,
+                       f.parent);
+  else
+    hipLaunchKernelGGL(k_fa_tile1<true>, gt, b, 0, s, fdr, w, f.tiles_x, f.rec, f.loc16, f.state, f.ext, f.entry_of,
+                       f.parent);
   hipLaunchKernelGGL(k_fa_reduce, gn, b, 0, s, f.rec, f.nnodes, f.entry_of, f.parent, f.state, f.ext);
   if (rank_level) {
     hipLaunchKernelGGL(k_fa_nxt_init, gn, b, 0, s, f.rec, f.nnodes, f.entry_of, f.state, f.nxt);

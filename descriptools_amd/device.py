@@ -95,11 +95,14 @@ class Context:
     """dt_ctx wrapper: one device, one stream (own, or an external hipStream_t such as
     torch.cuda.current_stream().cuda_stream)."""
 
-    def __init__(self, device=0, stream=None):
+    def __init__(self, device=0, stream=None, priority=None):
+        """priority (own stream only): -1 high, 0 normal, +1 low -- see dt_ctx_set_priority"""
         h = C.c_void_p()
         check(_lib.lib().dt_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h)))
         self.h = h
         self.device = device
+        if priority is not None:
+            check(_lib.lib().dt_ctx_set_priority(self.h, int(priority)))
 
     def empty(self, shape, dtype):
         return DeviceArray(self, shape, dtype)

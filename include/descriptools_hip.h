@@ -57,7 +57,9 @@ int dt_set_flow_impl(int impl);
  * instead of non-temporal loads / stores in that stencil (A/B timing); key 2 (DT_DBG_TWI_WX): tile geometry of that
  * stencil, 1 / 2 / 4 = tiles of 256 x 16 / 512 x 8 / 1024 x 4 cells (0 = the default); key 3 (DT_DBG_TWI_MAP): experimental
  * workgroup -> tile maps of that stencil; key 4 (DT_DBG_DS_MARGIN): margin of the downslope kernel's LDS window (16 / 20;
- * default 24); key 5 (DT_DBG_NO_FUSED_FA_FH): the last accumulation pass and HAND's first as two kernels (A/B timing). */
+ * default 24); key 5 (DT_DBG_NO_FUSED_FA_FH): the last accumulation pass and HAND's first as two kernels (A/B timing); key 6
+ * (DT_DBG_FA_TILE1_OLD): the first accumulation pass with separate pointer / receive words in LDS (A/B timing); key 7
+ * (DT_DBG_DS_NO_QUANT): downslope without the integer walk for DEMs on a binary quantum (A/B timing; same results). */
 int dt_debug_set(int key, int value);
 
 /* Context = one device + one stream + grow-only scratch.  `stream` may be NULL (the context
@@ -70,6 +72,9 @@ void *dt_ctx_stream(dt_ctx *ctx);
  * for everything enqueued so far on the parent's; after dt_ctx_join the parent's waits for the child's.
  * Device-side ordering only (events), the host never blocks.  The chain uses it to run downslope beside the
  * flow-accumulation / HAND kernels, whose latency chains leave most of the GPU idle. */
+/* Re-create the context's own stream with a scheduling priority: -1 high, 0 normal, +1 low (clamped to the device's
+ * range).  DT_EINVAL for a context that runs on a caller's stream. */
+int dt_ctx_set_priority(dt_ctx *ctx, int priority);
 int dt_ctx_fork(dt_ctx *parent, dt_ctx *child);
 int dt_ctx_join(dt_ctx *parent, dt_ctx *child);
 int dt_ctx_sync(dt_ctx *ctx);
