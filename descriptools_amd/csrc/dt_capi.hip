@@ -66,8 +66,6 @@ extern "C" int dt_ctx_create(int device, void *stream, dt_ctx **out) {
   c->ev = nullptr;
   c->aux = nullptr;
   c->aux_bytes = 0;
-  c->ds_work = nullptr;
-  c->ds_work_bytes = 0;
   c->ws_gen = 0;
   c->status = nullptr;
   if (hipMalloc((void **)&c->status, 64) != hipSuccess || hipMemset(c->status, 0, 64) != hipSuccess) {
@@ -110,7 +108,6 @@ extern "C" int dt_ctx_destroy(dt_ctx *c) {
   if (c->scratch) (void)hipFree(c->scratch);
   if (c->scratch2) (void)hipFree(c->scratch2);
   if (c->aux) (void)hipFree(c->aux);
-  if (c->ds_work) (void)hipFree(c->ds_work);
   if (c->status) (void)hipFree(c->status);
   if (c->ev) (void)hipEventDestroy(c->ev);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -592,8 +589,7 @@ extern "C" int dt_dev_downslope(dt_ctx *c, const float *dem, const uint8_t *fdr,
   if (dt_flow_impl() == 1) {  // v1: one thread per cell walking global memory (kept for A/B and verification runs)
     DT_TRY(dt_launch_downslope_v1(c->stream, dem, fdr, H, W, px, dz, raw, out));
   } else {
-    DT_TRY(dt_side_reserve(c, &c->ds_work, &c->ds_work_bytes, dt_downslope_work_bytes(H, W)));
-    DT_TRY(dt_launch_downslope(c->stream, dt_full_window(H, W), dem, fdr, px, dz, raw, out, nullptr, c->ds_work));
+    DT_TRY(dt_launch_downslope(c->stream, dt_full_window(H, W), dem, fdr, px, dz, raw, out, nullptr));
   }
   DT_HIP(hipGetLastError());
   return DT_OK;
@@ -726,8 +722,7 @@ extern "C" int dt_dev_downslope_w(dt_ctx *c, const dt_window *win, const float *
   DT_TRY(dt_convert_window(win, &w));
   DT_REQUIRE(dem && fdr && out, "NULL raster");
   if (n_unresolved_dev) DT_HIP(hipMemsetAsync(n_unresolved_dev, 0, sizeof(int32_t), c->stream));
-  DT_TRY(dt_side_reserve(c, &c->ds_work, &c->ds_work_bytes, dt_downslope_work_bytes(w.H, w.W)));
-  DT_TRY(dt_launch_downslope(c->stream, w, dem, fdr, px, dz, raw, out, (int *)n_unresolved_dev, c->ds_work));
+  DT_TRY(dt_launch_downslope(c->stream, w, dem, fdr, px, dz, raw, out, (int *)n_unresolved_dev));
   DT_HIP(hipGetLastError());
   return DT_OK;
 }

@@ -37,7 +37,7 @@ void dt_set_error(const char *fmt, ...);
   } while (0)
 
 // ---- test / experiment knobs (dt_debug_set in the C ABI; all 0 by default) -------------------------
-enum { DT_DBG_TWI_FLAG_ALL = 0, DT_DBG_TWI_PLAIN = 1, DT_DBG_TWI_WX = 2, DT_DBG_TWI_MAP = 3, DT_DBG_DS_MARGIN = 4, DT_DBG_NO_FUSED_FA_FH = 5, DT_DBG_FA_TILE1_OLD = 6, DT_DBG_DS_NO_QUANT = 7, DT_DBG_COUNT = 8 };
+enum { DT_DBG_TWI_FLAG_ALL = 0, DT_DBG_TWI_PLAIN = 1, DT_DBG_TWI_WX = 2, DT_DBG_TWI_MAP = 3, DT_DBG_DS_MARGIN = 4, DT_DBG_NO_FUSED_FA_FH = 5, DT_DBG_FA_TILE1_OLD = 6, DT_DBG_COUNT = 8 };
 #define DT_TWI_WX_DEFAULT 1 /* tile geometry of the fused slope + TI + MTI stencil: see k_slope_twi */
 int dt_debug_get(int key);
 
@@ -59,8 +59,6 @@ struct dt_ctx {
   int *status;          // device word of sticky DT_STATUS_* bits raised by kernels (dt_ctx_status reads and clears)
   char *aux;            // workspace of the fused slope + TI + MTI stencil (it runs between the two phases of
   size_t aux_bytes;     // the tile kernels in a multi-GPU step, so it must not touch `scratch`)
-  char *ds_work;        // downslope: quantum word + per-core marks (its own block: downslope runs between the two
-  size_t ds_work_bytes; // phases of the tile kernels in a multi-GPU step and on side branches)
   uint64_t ws_gen;      // bumped whenever scratch / scratch2 / aux is reallocated or freed: a captured graph holds
                         // their raw addresses and must not be replayed across such a change (dt_graph_launch checks)
 };

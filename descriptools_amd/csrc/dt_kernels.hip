@@ -498,8 +498,7 @@ __global__ __launch_bounds__(256) void k_downslope(const float *__restrict__ dem
   if (raw && failed) out[i] = -50.0f;
   else out[i] = dist == 0.0 ? 0.0f : (float)((double)drop / dist);
 }
-// What one cell's fast walk in the LDS window hands over, turned into the stored value (shared by the float and the
-// quantised window kernels).  drop: z0 - z(cell the walk stands on) (+inf: it stepped onto nodata); loop / nd: moves
+// What one cell's fast walk in the LDS window hands over, turned into the stored value.  drop: z0 - z(cell the walk stands on) (+inf: it stepped onto nodata); loop / nd: moves
 // made / diagonal ones; stop_fail: the walk stopped on a cell that cannot be left (non-D8 code, move off the raster);
 // (y, x): rank coordinates of the cell it stands on.
 __device__ __forceinline__ void ds_finish_cell(const DtWin &w, const float *__restrict__ dem,
@@ -627,19 +626,12 @@ __device__ __forceinline__ void ds_finish_cell(const DtWin &w, const float *__re
 #define MW_RING 0x2000u
 #define MW_STOP 0x8000u
 
-// binary quantum exponents k_downslope_q accepts (k_ds_probe's word; anything else = "not quantised")
-#define DQ_QE_MIN (-24)
-#define DQ_QE_MAX 24
-__device__ __forceinline__ bool dq_quantised(int qe) { return qe >= DQ_QE_MIN && qe <= DQ_QE_MAX; }
-
 template <int DW_M>
 __global__ __launch_bounds__(1024, 8) void k_downslope_win(const float *__restrict__ dem,
                                                        const uint8_t *__restrict__ fdr, DtWin w,
                                                        double px, double dz, float dzf, int raw,
                                                        float *__restrict__ out, int tiles_x, int ntiles,
-                                                       int *__restrict__ n_unresolved,
-                                                       const int *__restrict__ qwork,
-                                                       const uint8_t *__restrict__ qmarks) {
+                                                       int *__restrict__ n_unresolved) {
   constexpr int DW_WIN = DW_CORE + 2 * DW_M, DW_LD = DW_WIN + 4;
   // one LDS block: heights at byte 0, move words at byte DW_LD*DW_WIN*4 (the walk reads both from one
   // address register)
@@ -665,9 +657,6 @@ __global__ __launch_bounds__(1024, 8) void k_downslope_win(const float *__restri
       tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + j;
     }
   }
-  // after k_downslope_q on a quantised DEM: only the cores that kernel handed back (window not interior, heights
-  // off the quantum or out of the 16-bit range)
-  if (qwork != nullptr && dq_quantised(qwork[0]) && qmarks[tile] == 0) return;
   const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
   const int wy0 = tyi * DW_CORE - DW_M, wx0 = txi * DW_CORE - DW_M;
   const bool vec = (w.ld % 4 == 0) && (((uintptr_t)dem & 15) == 0) && (((uintptr_t)fdr & 3) == 0);
@@ -849,261 +838,8 @@ __global__ __launch_bounds__(1024, 8) void k_downslope_win(const float *__restri
   }
 }
 
-// ===========================================================================================
-// Downslope on DEMs whose heights lie on a binary quantum (integer DEMs such as the Example's int16 raster, fixed-
-// point products, the synthetic benchmark DEM: 2^-8 m): every height is s * 2^qe with an integer s, so inside a
-// window a height is the 16-bit integer u = s - s_min and the reference's float32 drop z0 - zt = (u0 - ut) * 2^qe is
-// EXACT (an integer below 2^24 times a power of two) -- the walk can compare integers:
-//     (double)drop < dz   <=>   u0 - ut < D,  D = ceil(dzf * 2^-qe)   <=>   ut >= u0 - D + 1.
-// A cell is then ONE 32-bit LDS word, move word << 16 | u: 4 bytes instead of 6, one LDS read per move instead of
-// two, 6 VALU instructions instead of 7, and a 128 x 64 core fits two workgroups per CU (176 x 112 window:
-// window / core 2.41 instead of 3.06).  Nothing is assumed: k_ds_probe proposes qe from a million samples, every
-// window verifies ALL its heights against it (multiple of 2^qe, |s| < 2^24, range <= 65534) and hands its two
-// 64 x 64 cores back to k_downslope_win (the float kernel, launched behind this one) when the check fails or the
-// window is not interior; a DEM off any quantum makes this kernel return at once.  Results are bit-identical to
-// k_downslope_win's (same tail, ds_finish_cell).
-// ===========================================================================================
-#define DQ_CW 128
-#define DQ_CH 64
-#define DQ_M 24
-#define DQ_WW (DQ_CW + 2 * DQ_M) /* 176 */
-#define DQ_WH (DQ_CH + 2 * DQ_M) /* 112 */
-#define DQ_LD (DQ_WW + 4)        /* 180 = 20 mod 32 banks, rows 16-byte aligned (see DW_LD) */
-// move word (high half of a cell's LDS word): bits 0-10 BYTE offset of the successor's word, biased by 1024; bit 11
-// diagonal move; bits 12-14 why the walk must stop here; bit 15 any of those (the sign bit of the LDS word)
-#define QW_OFF 0x7FFu
-#define QW_BIAS 1024
-#define QW_DIAG 0x800u
-#define QW_FAIL 0x1000u
-#define QW_RING 0x2000u
-#define QW_NODATA 0x4000u
-#define QW_STOP 0x8000u
-
-// exponent of the lowest set bit of v's binary expansion (v = m * 2^e, m odd): the quantum v sits on
-__global__ __launch_bounds__(256) void k_ds_probe(const float *__restrict__ dem, DtWin w, int *__restrict__ qwork) {
-  const long long n = (long long)w.H * w.W;
-  const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
-  const long long total = (long long)gridDim.x * 1024;
-  int le = 0x7F7F7F7F;
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    // samples spread evenly over the core, successive ones ~n / total cells apart
-    const long long idx = (long long)((double)(i0 + k) * ((double)n / (double)total));
-    if (idx >= n) continue;
-    const long long y = idx / w.W, x = idx - y * w.W;
-    const float v = dem[y * w.ld + x];
-    const uint32_t b = __float_as_uint(v);
-    if (v == DT_NODATA || (b & 0x7FFFFFFFu) == 0u) continue;
-    const int e = (int)((b >> 23) & 0xFFu);
-    if (e == 0 || e == 255) {
-      le = -1000;  // denormal, inf, NaN: not for the integer walk
-      continue;
-    }
-    const uint32_t mant = (b & 0x7FFFFFu) | 0x800000u;
-    le = min(le, e - 150 + (int)__builtin_ctz(mant));
-  }
-  for (int o = 32; o > 0; o >>= 1) le = min(le, __shfl_xor(le, o));
-  if ((threadIdx.x & 63) == 0 && le != 0x7F7F7F7F) atomicMin(qwork, le);
-}
-
-__global__ __launch_bounds__(1024, 8) void k_downslope_q(const float *__restrict__ dem,
-                                                         const uint8_t *__restrict__ fdr, DtWin w, double px,
-                                                         double dz, float dzf, int raw, float *__restrict__ out,
-                                                         int tiles_x, int ntiles, const int *__restrict__ qwork,
-                                                         uint8_t *__restrict__ qmarks, int mtiles_x,
-                                                         int *__restrict__ n_unresolved) {
-  __shared__ __attribute__((aligned(16))) uint32_t s_c[DQ_LD * DQ_WH];
-  __shared__ uint16_t s_lut[256];
-  __shared__ int s_red[32];
-  const int qe = qwork[0];
-  if (!dq_quantised(qe)) return;  // k_downslope_win does the whole raster
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)s_c;
-  int b = blockIdx.x, tile;
-  {  // XCD bands walked in strips of 8 tile columns, as k_downslope_win
-    int xcd = b & 7, j = b >> 3;
-    int q = ntiles >> 3, rem = ntiles & 7;
-    if (rem == 0 && q % tiles_x == 0 && (tiles_x & 7) == 0) {
-      const int rows = q / tiles_x, per_strip = rows * 8;
-      const int strip = j / per_strip, r = (j - strip * per_strip) >> 3, c = (j & 7) + strip * 8;
-      tile = xcd * q + r * tiles_x + c;
-    } else {
-      tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + j;
-    }
-  }
-  const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
-  const int wy0 = tyi * DQ_CH - DQ_M, wx0 = txi * DQ_CW - DQ_M;
-  const bool vec = (w.ld % 4 == 0) && (((uintptr_t)dem & 15) == 0) && (((uintptr_t)fdr & 3) == 0);
-  const int ya = max(-w.halo, -w.gy0), yb = min(w.H + w.halo, w.Hg - w.gy0);
-  const int xa = max(-w.halo, -w.gx0), xb = min(w.W + w.halo, w.Wg - w.gx0);
-  // block-uniform: every window cell is in memory and no move from it can leave the global raster
-  const bool interior = vec && wy0 >= ya && wy0 + DQ_WH <= yb && wx0 >= xa && wx0 + DQ_WW <= xb &&
-                        w.gy0 + wy0 >= 1 && w.gy0 + wy0 + DQ_WH <= w.Hg - 1 && w.gx0 + wx0 >= 1 &&
-                        w.gx0 + wx0 + DQ_WW <= w.Wg - 1;
-  // the (up to) two 64 x 64 cores of k_downslope_win this workgroup covers
-  auto hand_back = [&](int v) {
-    if (threadIdx.x < 2 && 2 * txi + (int)threadIdx.x < mtiles_x)
-      qmarks[(size_t)tyi * mtiles_x + 2 * txi + threadIdx.x] = (uint8_t)v;
-  };
-  if (!interior) {
-    hand_back(1);
-    return;
-  }
-  constexpr int NG = DQ_WH * (DQ_WW / 4);  // 4928 groups of 4 cells: up to 5 per thread
-  float4 vv[5];
-  uint32_t cc[5];
-#pragma unroll
-  for (int u = 0; u < 5; u++) {
-    int i = threadIdx.x + 1024 * u;
-    if (i < NG) {
-      int r = i / (DQ_WW / 4), c4 = (i - r * (DQ_WW / 4)) * 4;
-      long long g = (long long)(wy0 + r) * w.ld + wx0 + c4;
-      vv[u] = *reinterpret_cast<const float4 *>(dem + g);
-      cc[u] = *reinterpret_cast<const uint32_t *>(fdr + g);
-    }
-  }
-  if (threadIdx.x < 256) {
-    uint32_t code = threadIdx.x, mw = QW_FAIL | QW_STOP | QW_BIAS;
-    if (dt_d8_valid(code)) {
-      int dy, dx;
-      dt_d8_delta(code, dy, dx);
-      mw = (uint32_t)(4 * (dy * DQ_LD + dx) + QW_BIAS);
-      if (dy != 0 && dx != 0) mw |= QW_DIAG;
-    }
-    s_lut[code] = (uint16_t)mw;
-  }
-  // heights -> integers s = v * 2^-qe (exact scaling), verified: integer-valued, below 2^24
-  const float sc = __builtin_ldexpf(1.0f, -qe);
-  int si[5][4];
-  uint32_t nod = 0;
-  int ok = 1, mn = 0x7FFFFFFF, mx = (int)0x80000000;
-#pragma unroll
-  for (int u = 0; u < 5; u++) {
-    if ((int)threadIdx.x + 1024 * u < NG) {
-      const float v4[4] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const float t = v4[k] * sc;
-        const int sv = (int)t;
-        if (v4[k] == DT_NODATA) {
-          nod |= 1u << (4 * u + k);
-          si[u][k] = 0;
-        } else {
-          ok &= (int)((float)sv == t && fabsf(t) < 16777216.0f);  // false for NaN / inf as well
-          mn = min(mn, sv);
-          mx = max(mx, sv);
-          si[u][k] = sv;
-        }
-      }
-    }
-  }
-  for (int o = 32; o > 0; o >>= 1) {
-    mn = min(mn, __shfl_xor(mn, o));
-    mx = max(mx, __shfl_xor(mx, o));
-  }
-  if ((threadIdx.x & 63) == 0) {
-    s_red[threadIdx.x >> 6] = mn;
-    s_red[16 + (threadIdx.x >> 6)] = mx;
-  }
-  ok = __syncthreads_and(ok);  // also publishes s_lut and s_red
-  int smin = s_red[0], smax = s_red[16];
-#pragma unroll
-  for (int k = 1; k < 16; k++) {
-    smin = min(smin, s_red[k]);
-    smax = max(smax, s_red[16 + k]);
-  }
-  if (!ok || (smax >= smin && (long long)smax - (long long)smin > 65534ll)) {
-    hand_back(1);
-    return;
-  }
-  hand_back(0);
-#pragma unroll
-  for (int u = 0; u < 5; u++) {
-    int i = threadIdx.x + 1024 * u;
-    if (i < NG) {
-      int r = i / (DQ_WW / 4), c4 = (i - r * (DQ_WW / 4)) * 4;
-      const uint32_t rowring = (r == 0 || r == DQ_WH - 1) ? (QW_RING | QW_STOP) : 0u;
-      uint32_t wd[4];
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        uint32_t m = (uint32_t)s_lut[(cc[u] >> (8 * k)) & 0xFFu] | rowring;
-        if ((k == 0 && c4 == 0) || (k == 3 && c4 == DQ_WW - 4)) m |= QW_RING | QW_STOP;
-        const bool nd_ = (nod >> (4 * u + k)) & 1u;
-        if (nd_) m |= QW_NODATA | QW_STOP;
-        wd[k] = (m << 16) | (nd_ ? 0xFFFFu : (uint32_t)(si[u][k] - smin));
-      }
-      *reinterpret_cast<uint4 *>(&s_c[r * DQ_LD + c4]) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
-    }
-  }
-  __syncthreads();
-  const double dcard = px, ddiag = px * sqrt(2.0);
-  const float qs = __builtin_ldexpf(1.0f, qe);
-  // D = ceil(dzf * 2^-qe), clamped (beyond 2^20 no 16-bit difference reaches it); z0 <= -100  <=>  s0 <= floor(-100 * 2^-qe)
-  const double dq = ceil((double)dzf * __builtin_ldexp(1.0, -qe));
-  const int D = dq > 1048576.0 ? 1048576 : (dq < -1048576.0 ? -1048576 : (int)dq);
-  const int s_nodata = (int)floor(-100.0 * __builtin_ldexp(1.0, -qe));
-  for (int j = 0; j < (DQ_CW * DQ_CH) / 1024; j++) {
-    int c = threadIdx.x + 1024 * j;
-    int cy = c / DQ_CW, cx = c - cy * DQ_CW;
-    int y0 = tyi * DQ_CH + cy, x0 = txi * DQ_CW + cx;
-    if (y0 >= w.H || x0 >= w.W) continue;
-    const int pos0 = (cy + DQ_M) * DQ_LD + cx + DQ_M;
-    uint32_t wv = s_c[pos0];
-    const int u0 = (int)(wv & 0xFFFFu);
-    long long o = (long long)y0 * w.ld + x0;
-    if ((wv & (QW_NODATA << 16)) || u0 + smin <= s_nodata) {
-      out[o] = DT_NODATA;
-      continue;
-    }
-    // continue while ut >= T (drop below dz) and the cell's stop bit -- the word's sign -- is clear; acc += move
-    // word + 2^20: moves in bits 20.., below them the sum of the biased offsets and of 2048 per diagonal move
-    const uint32_t T = (uint32_t)max(u0 - D + 1, 0);
-    const uint32_t q_0 = lds0 + 4u * (uint32_t)pos0;
-    uint32_t q = q_0, acc = 0;
-    {
-      uint32_t t, m, cnt;
-      uint64_t sv;
-      asm volatile(
-          "s_mov_b64 %[sv], exec\n\t"
-          "s_movk_i32 %[cnt], 255\n\t"
-          "v_cmpx_ge_u32_sdwa vcc, %[wv], %[T] src0_sel:WORD_0 src1_sel:DWORD\n\t"
-          "v_cmpx_le_i32 vcc, 0, %[wv]\n\t"
-          "s_cbranch_execz 2f\n"
-          "1:\n\t"
-          "v_lshrrev_b32 %[m], 16, %[wv]\n\t"
-          "v_and_b32 %[t], 0x7ff, %[m]\n\t"
-          "v_add3_u32 %[acc], %[acc], %[m], %[k20]\n\t"
-          "v_add3_u32 %[q], %[q], %[t], %[nbias]\n\t"
-          "ds_read_b32 %[wv], %[q]\n\t"
-          "s_sub_u32 %[cnt], %[cnt], 1\n\t"
-          "s_waitcnt lgkmcnt(0)\n\t"
-          "s_cbranch_scc1 2f\n\t"  // borrow: that was the 256th move, hand over
-          "v_cmpx_ge_u32_sdwa vcc, %[wv], %[T] src0_sel:WORD_0 src1_sel:DWORD\n\t"
-          "v_cmpx_le_i32 vcc, 0, %[wv]\n\t"
-          "s_cbranch_execnz 1b\n"
-          "2:\n\t"
-          "s_mov_b64 exec, %[sv]"
-          : [q] "+v"(q), [wv] "+v"(wv), [acc] "+v"(acc), [t] "=&v"(t), [m] "=&v"(m), [sv] "=&s"(sv), [cnt] "=&s"(cnt)
-          : [T] "v"(T), [nbias] "s"(0u - (uint32_t)QW_BIAS), [k20] "s"(1u << 20)
-          : "vcc", "scc", "memory");
-    }
-    const uint32_t loop = acc >> 20;
-    const uint32_t nd = ((acc & 0xFFFFFu) - (q - q_0) - (uint32_t)QW_BIAS * loop) / QW_DIAG;
-    const uint32_t mwf = wv >> 16;
-    const float z0 = (float)(u0 + smin) * qs;  // exact: |s| < 2^24
-    const float drop = (mwf & QW_NODATA) ? __builtin_inff() : (float)(u0 - (int)(wv & 0xFFFFu)) * qs;
-    const uint32_t pos = (q - lds0) >> 2;
-    ds_finish_cell(w, dem, fdr, y0, x0, z0, drop, loop, nd, (mwf & QW_FAIL) != 0u, wy0 + (int)(pos / DQ_LD),
-                   wx0 + (int)(pos % DQ_LD), dcard, ddiag, dz, dzf, raw, out + o, n_unresolved);
-  }
-}
-
-
-size_t dt_downslope_work_bytes(int64_t H, int64_t W) {
-  return 256 + (size_t)((W + DW_CORE - 1) / DW_CORE) * (size_t)((H + DW_CORE - 1) / DW_CORE);
-}
-// qwork (optional, dt_downslope_work_bytes): enables the quantised kernel in front of the float one
 int dt_launch_downslope(hipStream_t s, const DtWin &w, const float *dem, const uint8_t *fdr, double px,
-                        double dz, int raw, float *out, int *n_unresolved, void *qwork) {
+                        double dz, int raw, float *out, int *n_unresolved) {
   const int64_t H = w.H, W = w.W;
   int64_t n = H * W;
   if (n == 0) return DT_OK;
@@ -1114,27 +850,15 @@ int dt_launch_downslope(hipStream_t s, const DtWin &w, const float *dem, const u
   if ((double)dzf < dz) dzf = nextafterf(dzf, INFINITY);
   // margin of the LDS window around the 64 x 64 core: walks that reach the window's ring carry on in global memory
   const int m = dt_debug_get(DT_DBG_DS_MARGIN);
-  int *qw = nullptr;
-  uint8_t *qm = nullptr;
-  // rasters with no interior 176 x 112 window gain nothing from the quantised kernel
-  if (qwork && !dt_debug_get(DT_DBG_DS_NO_QUANT) && m != 16 && m != 20 && H >= 256 && W >= 512) {
-    qw = (int *)qwork;
-    qm = (uint8_t *)qwork + 256;
-    DT_HIP(hipMemsetAsync(qw, 0x7F, sizeof(int), s));
-    hipLaunchKernelGGL(k_ds_probe, dim3(1024), dim3(256), 0, s, dem, w, qw);
-    const int qtx = (int)((W + DQ_CW - 1) / DQ_CW), qty = (int)((H + DQ_CH - 1) / DQ_CH);
-    hipLaunchKernelGGL(k_downslope_q, dim3((unsigned)(qtx * qty)), dim3(1024), 0, s, dem, fdr, w, px, dz, dzf, raw, out,
-                       qtx, qtx * qty, qw, qm, tiles_x, n_unresolved);
-  }
   if (m == 16)
     hipLaunchKernelGGL(k_downslope_win<16>, dim3((unsigned)ntiles), dim3(1024), 0, s, dem, fdr, w, px, dz, dzf, raw,
-                       out, tiles_x, (int)ntiles, n_unresolved, qw, qm);
+                       out, tiles_x, (int)ntiles, n_unresolved);
   else if (m == 20)
     hipLaunchKernelGGL(k_downslope_win<20>, dim3((unsigned)ntiles), dim3(1024), 0, s, dem, fdr, w, px, dz, dzf, raw,
-                       out, tiles_x, (int)ntiles, n_unresolved, qw, qm);
+                       out, tiles_x, (int)ntiles, n_unresolved);
   else
     hipLaunchKernelGGL(k_downslope_win<24>, dim3((unsigned)ntiles), dim3(1024), 0, s, dem, fdr, w, px, dz, dzf, raw,
-                       out, tiles_x, (int)ntiles, n_unresolved, qw, qm);
+                       out, tiles_x, (int)ntiles, n_unresolved);
   return DT_OK;
 }
 int dt_launch_downslope_v1(hipStream_t s, const float *dem, const uint8_t *fdr, int64_t H, int64_t W,
