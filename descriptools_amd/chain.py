@@ -34,7 +34,7 @@ WRITE_GROUPS = (("slope", "ti", "mti"), ("fdist", "idx", "hand", "gfi", "lnhlh")
 OPS = (
     ("d8", 5, ["k_d8<false>", "k_d8_fix"]),
     ("downslope", 9, ["k_downslope_win<24>"]),
-    ("flowacc_flowhand_local", 5 + 1 + 2, ["k_fa_tile1<true>", "k_fa_reduce", "k_fa_poison", "k_fa3fh1<true>", "k_fh_tile1",
+    ("flowacc_flowhand_local", 5 + 1 + 2, ["k_fa_tile1", "k_fa_reduce", "k_fa_poison", "k_fa3fh1<true>", "k_fh_tile1",
                                            "k_fh_ghost_init", "k_fh_node_jump"]),
     ("slope_twi", 20, ["k_slope_twi<true, false, 1, int, 1>", "k_slope_twi_fix<int, 1>"]),
     ("flowhand_gfi_finish", 28, ["k_fh_tile3<false, 1, 5, int>"]),

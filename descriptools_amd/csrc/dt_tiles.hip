@@ -144,70 +144,13 @@ __device__ __forceinline__ uint32_t dt_tile_next_interior(uint32_t code, int ly,
 #define PT_EXIT 0x4000u
 #define PT_IDX 0x0FFFu
 
-// LDS holds what OTHER lanes need: a cell's pointer word (16 bits: idx:12 | PT_EXIT | PT_ALIVE; gathered by the
-// cells that jump over it) and a 32-bit receive word (scatter target).  A cell's running sum is read and written
-// by its owner only and lives in a register.  Each lane owns PAIRS of adjacent cells (2 * (t + 256 j), +1): its
-// two pointer words move as one 32-bit LDS word, its two receive words as one 64-bit exchange.  Per cell and
-// round: one LDS atomic add, one 16-bit gather and ~5 VALU instructions (the previous form, val:16 | ptr:16 in
-// one word with two 16-bit receive sums per word, spent 18 for the same time: the rounds are bound by the LDS
-// atomics and their bank conflicts, not by instruction issue).
-// On an in-tile D8 cycle the sums are garbage and double every round: they wrap in 32 bits, harmlessly (such
-// cells end up in s_cyc).
-__device__ __forceinline__ void dt_tile_sums(uint16_t *s_ptr, uint32_t *s_recv, uint8_t *s_cyc,
-                                             uint32_t (&va)[CPT / 2], uint32_t (&vb)[CPT / 2]) {
-  uint32_t P[CPT / 2], NP[CPT / 2];
-  uint32_t *s_ptr2 = reinterpret_cast<uint32_t *>(s_ptr);
-  unsigned long long *s_recv2 = reinterpret_cast<unsigned long long *>(s_recv);
-#pragma unroll
-  for (int j = 0; j < CPT / 2; j++) {
-    P[j] = s_ptr2[threadIdx.x + 256 * j];
-    va[j] = vb[j] = 1u;
-  }
-  for (int round = 0; round < 12; round++) {
-    int any = 0;
-#pragma unroll
-    for (int j = 0; j < CPT / 2; j++) {
-      uint32_t npa = P[j] & 0xFFFFu, npb = P[j] >> 16;
-      if (P[j] & PT_ALIVE) {
-        uint32_t t = P[j] & PT_IDX;
-        atomicAdd(&s_recv[t], va[j]);
-        npa = s_ptr[t];
-        any = 1;
-      }
-      if (P[j] & (PT_ALIVE << 16)) {
-        uint32_t t = (P[j] >> 16) & PT_IDX;
-        atomicAdd(&s_recv[t], vb[j]);
-        npb = s_ptr[t];
-        any = 1;
-      }
-      NP[j] = npa | (npb << 16);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < CPT / 2; j++) {
-      int c2 = threadIdx.x + 256 * j;
-      unsigned long long r = atomicExch(&s_recv2[c2], 0ull);  // read and clear in one LDS instruction
-      va[j] += (uint32_t)r;
-      vb[j] += (uint32_t)(r >> 32);
-      if (P[j] != NP[j]) {
-        P[j] = NP[j];
-        s_ptr2[c2] = NP[j];
-      }
-    }
-    if (!__syncthreads_or(any)) return;
-  }
-  // still alive after 2^12 moves: the path never ends inside the tile -> in-tile cycle
-#pragma unroll
-  for (int j = 0; j < CPT / 2; j++) {
-    if (P[j] & PT_ALIVE) s_cyc[P[j] & PT_IDX] = 1;
-    if (P[j] & (PT_ALIVE << 16)) s_cyc[(P[j] >> 16) & PT_IDX] = 1;
-  }
-  __syncthreads();
-}
-
-// The same rounds with ONE random LDS access per cell and round instead of two: pointer word and receive word share
-// a 32-bit LDS word (ptr:16 << 16 | recv:16), and the scatter is a RETURNING atomic add whose old value carries the
-// target's pointer word -- the add and the gather are one instruction.  The receive field cannot carry into the
+// LDS holds what OTHER lanes need, one 32-bit word per cell: the cell's pointer word (idx:12 | PT_EXIT | PT_ALIVE) in
+// the high half, what it receives in a round in the low half.  The scatter is a RETURNING atomic add whose old value
+// carries the target's pointer word -- the add and the gather of the jump are one LDS instruction (round 3; with
+// separate pointer / receive arrays and two random accesses per cell and round the pass took 3-5 % longer).  A cell's
+// running sum is read and written by its owner only and lives in a register; each lane owns PAIRS of adjacent cells
+// (2 (t + 256 j), + 1): its two words move as one 64-bit access.  On an in-tile D8 cycle the sums are garbage (such
+// cells end up in s_cyc).  The receive field cannot carry into the
 // pointer: off cycles a round delivers <= 4096 to a cell (the senders' subtrees are disjoint), and what a cell
 // sends is clamped to 4096 (only cells ON an in-tile cycle ever exceed it, one such sender per target and round),
 // so a round delivers <= 8192 < 2^16.  The owner reads and rewrites its pair of words (one conflict-free 64-bit
@@ -283,7 +226,6 @@ __device__ __forceinline__ unsigned long long fa_rec(uint32_t W_, uint32_t xslot
 #define REC_XSLOT(r) ((uint32_t)(((r) >> 16) & 0xFFFFu))
 #define REC_CODE(r) ((uint32_t)(((r) >> 8) & 0xFFu))
 
-template <bool PACKED>
 __global__ __launch_bounds__(256, 6) void k_fa_tile1(const uint8_t *__restrict__ fdr, DtWin w, int tiles_x,
                                                     unsigned long long *__restrict__ rec,
                                                     uint16_t *__restrict__ loc16,
@@ -291,15 +233,12 @@ __global__ __launch_bounds__(256, 6) void k_fa_tile1(const uint8_t *__restrict__
                                                     unsigned long long *__restrict__ ext,
                                                     uint32_t *__restrict__ entry_of,
                                                     uint32_t *__restrict__ parent) {
-  // 24 KiB of LDS: six tiles per CU.  The direction codes are staged through the receive array (free until
-  // the rounds start), which is all zero again when the rounds end and then serves as the cycle mask (bytes
-  // [0, 4 KiB)), the pending counts (252 words from 4 KiB) and the final sums (16 bits per cell from 8 KiB).
-  // PACKED (the default): 21 KiB -- one 32-bit word per cell (pointer word << 16 | receive field, dt_tile_sums_packed)
-  // and 5 KiB that stage the codes, then hold the cycle mask and the pending counts.
-  __shared__ __attribute__((aligned(16))) uint16_t s_ptr[PACKED ? 8 : NT];   // idx:12 | PT_EXIT | PT_ALIVE
-  __shared__ __attribute__((aligned(16))) uint32_t s_recv[NT];  // what a cell receives in a round
-  __shared__ __attribute__((aligned(16))) uint32_t s_aux[PACKED ? NT / 4 + 256 : 4];
-  uint8_t *s_fdr = reinterpret_cast<uint8_t *>(PACKED ? s_aux : s_recv);
+  // 21.5 KiB of LDS: six tiles per CU.  s_word: one 32-bit word per cell (dt_tile_sums_packed); s_aux stages the
+  // direction codes, then holds the cycle mask (4 KiB) and the pending counts (252 words); s_lut: code -> successor.
+  __shared__ __attribute__((aligned(16))) uint32_t s_word[NT];
+  __shared__ __attribute__((aligned(16))) uint32_t s_aux[NT / 4 + 256];
+  __shared__ uint16_t s_lut[256];  // D8 code -> successor's offset + 128 (0: not a D8 code)
+  uint8_t *s_fdr = reinterpret_cast<uint8_t *>(s_aux);
   const int tile = dt_tile_of_block((int)blockIdx.x, (int)gridDim.x);
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int y0 = ty * TH, x0 = tx * TW;
@@ -323,19 +262,47 @@ __global__ __launch_bounds__(256, 6) void k_fa_tile1(const uint8_t *__restrict__
       c2[q] = (live && !inside && dt_in_core(w, y + dy, x + dx)) ? (uint32_t)fdr[(long long)(y + dy) * w.ld + x + dx] : 0u;
     }
   }
+  {
+    uint32_t code = threadIdx.x, e = 0u;
+    if (dt_d8_valid(code)) {
+      int dy, dx;
+      dt_d8_delta(code, dy, dx);
+      e = (uint32_t)(dy * TW + dx + 128);
+    }
+    s_lut[code] = (uint16_t)e;
+  }
   dt_tile_put16(s_fdr, v_fdr);
   __syncthreads();
-  uint32_t nx[CPT];
+  // Every cell's pointer word: terminals point at themselves; an exit terminal carries PT_EXIT, which every cell
+  // whose in-tile path ends there inherits through the jumps.  A lane sets up the 4 x 4 cells 4 (t + 256 u) + k:
+  // codes and words move as 32 / 128-bit LDS accesses.
   if (dt_tile_interior(w, y0, x0)) {
+    // all cells and successors inside the core: the successor left the tile iff its index left [0, 4096) or its
+    // column wrapped (0 <-> 63: it differs from mine by 63 instead of <= 1)
+    const uint32_t lx0 = (4u * threadIdx.x) & 63u;
 #pragma unroll
-    for (int j = 0; j < CPT; j++) {
-      int c = threadIdx.x + 256 * j;
-      nx[j] = dt_tile_next_interior(s_fdr[c], c / TW, c % TW);
+    for (int u = 0; u < NT / 4 / 256; u++) {
+      const int c0 = 4 * (threadIdx.x + 256 * u);
+      const uint32_t codes = *reinterpret_cast<const uint32_t *>(&s_fdr[c0]);
+      uint32_t pw[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t c = (uint32_t)(c0 + k), e = s_lut[(codes >> (8 * k)) & 0xFFu];
+        const uint32_t n = c + e - 128u;
+        const bool out = n > (uint32_t)(NT - 1) || ((n & 63u) - (lx0 + (uint32_t)k - 1u)) > 2u;
+        pw[k] = (e == 0u ? c : (out ? (c | PT_EXIT) : (n | PT_ALIVE))) << 16;
+      }
+      *reinterpret_cast<uint4 *>(&s_word[c0]) = make_uint4(pw[0], pw[1], pw[2], pw[3]);
     }
   } else {
-    for (int j = 0; j < CPT; j++) {
-      int c = threadIdx.x + 256 * j;
-      nx[j] = dt_tile_next(s_fdr[c], c / TW, c % TW, y0, x0, w);
+    for (int u = 0; u < NT / 4 / 256; u++) {
+      const int c0 = 4 * (threadIdx.x + 256 * u);
+      for (int k = 0; k < 4; k++) {
+        const int c = c0 + k;
+        const uint32_t n = dt_tile_next(s_fdr[c], c / TW, c % TW, y0, x0, w);
+        const bool ex = (n == NX_EXIT || n == NX_REXIT);
+        s_word[c] = (n < NT ? (n | PT_ALIVE) : ((uint32_t)c | (ex ? PT_EXIT : 0u))) << 16;
+      }
     }
   }
   uint32_t my_code = 0, my_flags = 0;  // D8 code of my perimeter cell when it is an exit cell
@@ -366,45 +333,19 @@ __global__ __launch_bounds__(256, 6) void k_fa_tile1(const uint8_t *__restrict__
     }
   }
   __syncthreads();
-  uint8_t *s_cyc = reinterpret_cast<uint8_t *>(PACKED ? s_aux : s_recv);
-  uint32_t *s_pend = PACKED ? s_aux + NT / 4 : s_recv + NT / 4;  // 252 words above the cycle mask (all zero after the rounds)
-  for (int j = 0; j < CPT; j++) {
-    int c = threadIdx.x + 256 * j;
-    uint32_t n = nx[j];
-    // terminals point at themselves; an exit terminal carries PT_EXIT, which every cell whose
-    // in-tile path ends there inherits through the jumps
-    bool ex = (n == NX_EXIT || n == NX_REXIT);
-    const uint32_t pw = n < NT ? (n | PT_ALIVE) : ((uint32_t)c | (ex ? PT_EXIT : 0u));
-    if (PACKED) {
-      s_recv[c] = pw << 16;
-    } else {
-      s_ptr[c] = (uint16_t)pw;
-      s_recv[c] = 0u;
-    }
-  }
-  if (PACKED) {  // the staged codes have been consumed (barrier above): cycle mask and pending counts start at zero
-    reinterpret_cast<uint4 *>(s_aux)[threadIdx.x] = make_uint4(0, 0, 0, 0);
-    s_aux[NT / 4 + threadIdx.x] = 0u;
-  }
-  __syncthreads();
+  // the staged codes have been consumed: cycle mask and pending counts start at zero (the rounds' first barrier comes
+  // before anything reads them)
+  uint8_t *s_cyc = reinterpret_cast<uint8_t *>(s_aux);
+  uint32_t *s_pend = s_aux + NT / 4;  // 252 words above the cycle mask
+  reinterpret_cast<uint4 *>(s_aux)[threadIdx.x] = make_uint4(0, 0, 0, 0);
+  s_aux[NT / 4 + threadIdx.x] = 0u;
   uint32_t va[CPT / 2], vb[CPT / 2];  // running sums of my cells 2 (t + 256 j) and + 1
-  const uint16_t *s_val = nullptr;
-  if (PACKED) {
-    dt_tile_sums_packed(s_recv, s_cyc, va, vb);
-  } else {
-    dt_tile_sums(s_ptr, s_recv, s_cyc, va, vb);
-    // the final sums where the perimeter lanes can read them (<= 4096 off cycles: 16 bits)
-    uint32_t *s_val2 = s_recv + NT / 2;
-    s_val = reinterpret_cast<const uint16_t *>(s_val2);
-#pragma unroll
-    for (int j = 0; j < CPT / 2; j++) s_val2[threadIdx.x + 256 * j] = (va[j] & 0xFFFFu) | (vb[j] << 16);
-    __syncthreads();
-  }
+  dt_tile_sums_packed(s_word, s_cyc, va, vb);
   if (threadIdx.x < PS) {
     int ly, lx;
     dt_cell_of_slot(threadIdx.x, ly, lx);
     int c = ly * TW + lx;
-    const uint32_t pv = PACKED ? s_recv[c] : ((uint32_t)s_ptr[c] << 16) | (uint32_t)s_val[c];
+    const uint32_t pv = s_word[c];  // final pointer word << 16 | final sum (<= 4096 off cycles)
     uint32_t p = pv >> 16;
     uint32_t xs = X_NONE;
     if (!(p & PT_ALIVE) && (p & PT_EXIT)) {
@@ -821,12 +762,8 @@ int dt_launch_fa_local(hipStream_t s, const DtWin &w, const uint8_t *fdr, void *
   DT_REQUIRE(f.nnodes < 0x7FFFFFF0ll, "raster too large for one device tile");
   dim3 gt((unsigned)f.ntiles), b(256), gn((unsigned)((f.nnodes + 255) / 256));
   (void)acc32;  // written by pass 3 only
-  if (dt_debug_get(DT_DBG_FA_TILE1_OLD))
-    hipLaunchKernelGGL(k_fa_tile1<false>, gt, b, 0, s, fdr, w, f.tiles_x, f.rec, f.loc16, f.state, f.ext, f.entry_of,
-                       f.parent);
-  else
-    hipLaunchKernelGGL(k_fa_tile1<true>, gt, b, 0, s, fdr, w, f.tiles_x, f.rec, f.loc16, f.state, f.ext, f.entry_of,
-                       f.parent);
+  hipLaunchKernelGGL(k_fa_tile1, gt, b, 0, s, fdr, w, f.tiles_x, f.rec, f.loc16, f.state, f.ext, f.entry_of,
+                     f.parent);
   hipLaunchKernelGGL(k_fa_reduce, gn, b, 0, s, f.rec, f.nnodes, f.entry_of, f.parent, f.state, f.ext);
   if (rank_level) {
     hipLaunchKernelGGL(k_fa_nxt_init, gn, b, 0, s, f.rec, f.nnodes, f.entry_of, f.state, f.nxt);
@@ -1131,48 +1068,81 @@ __global__ __launch_bounds__(256) void k_fh_tile1(const uint8_t *__restrict__ fd
 #define FN_LOW 0x7FFFFu  /* counts + done: what ONE addition propagates */
 #define FN_OVF 0x20100u  /* a count above 255 */
 #define FN_PTR_SH 19
-// The narrow pass 1 from the point where the tile's codes (s_fdr) and its river mask (s_kind, one byte per cell) are
-// in LDS, *s_ovf is 0 and a barrier has been passed: shared by k_fh_tile1n (which stages both from HBM) and by
+// The narrow pass 1 from the point where the tile's codes (s_fdr) and the code table (s_lut) are in LDS, every lane
+// holds the river mask of its 4 x 4 cells (riv4), *s_ovf is 0 and a barrier has been passed: shared by k_fh_tile1n (which stages both from HBM) and by
 // k_fa3fh1 (flow accumulation's last pass, which has the codes in registers and has just computed the mask).
 // (No halo ring of codes: "the successor's code is 0" need not be tested at the predecessor -- a cell whose code is 0
 // is a dead end in its own right (flowhand.py:601, :826), inside the tile through s_kind of the path's end, across a
 // tile or rank border through that cell's perimeter node / ring summary.)
+// s_lut (256 words, fh_lut_entry): what a D8 code adds to a cell's word  c << FN_PTR_SH  -- the successor's offset in
+// the pointer field and the move in its count field (0 in the count field: not a D8 code).
+__device__ __forceinline__ uint32_t fh_lut_entry(uint32_t code) {
+  if (!dt_d8_valid(code)) return 0u;
+  int dy, dx;
+  dt_d8_delta(code, dy, dx);
+  return ((uint32_t)(dy * TW + dx) << FN_PTR_SH) + ((dy != 0 && dx != 0) ? (1u << 9) : 1u);
+}
 __device__ __forceinline__ void fh_tile1n_body(uint8_t *s_fdr, uint32_t *s_w, uint8_t *s_kind, int *s_ovf_p,
+                                               const uint32_t *s_lut, const uint32_t (&riv4)[NT / 4 / 256],
                                                const DtWin &w, int tile, int tiles_x, int y0, int x0, uint32_t nnodes,
                                                unsigned long long *__restrict__ nodes,
                                                unsigned long long *__restrict__ cache,
                                                uint8_t *__restrict__ cache_wide) {
 #define s_ovf (*s_ovf_p)
-  uint32_t riv = 0;
-#pragma unroll
-  for (int j = 0; j < CPT; j++)
-    if (s_kind[threadIdx.x + 256 * j] == 1) riv |= 1u << j;
-  __syncthreads();
+  // A lane sets up the 4 x 4 cells  4 (t + 256 u) + k  whose river mask it holds (riv4, one byte per cell): codes,
+  // words and kinds move as 32 / 128-bit LDS accesses, and nobody else touches these cells before the barrier.
   const bool interior = dt_tile_interior(w, y0, x0);
-  for (int j = 0; j < CPT; j++) {
-    int c = threadIdx.x + 256 * j;
-    int ly = c / TW, lx = c % TW;
-    int y = y0 + ly, x = x0 + lx;
-    uint32_t code = s_fdr[c];
-    uint32_t word = ((uint32_t)c << FN_PTR_SH) | FN_DONE, kind = K_DEAD;  // flowhand.py:601 / non-D8 code :830
-    if ((interior || (y < w.H && x < w.W)) && code != 0u) {
-      if ((riv >> j) & 1u) {
-        kind = K_RIVER;  // flowhand.py:609-612
-      } else if (dt_d8_valid(code)) {
-        int dy, dx;
-        dt_d8_delta(code, dy, dx);
-        uint32_t ny = (uint32_t)(ly + dy), nx = (uint32_t)(lx + dx);
-        bool in_tile = ny < (uint32_t)TH && nx < (uint32_t)TW;
-        // a step off the raster stays dead (flowhand.py:623-628)
-        if (interior || dt_in_global(w, y + dy, x + dx)) {
-          if (!interior && !dt_in_core(w, y + dy, x + dx)) kind = K_REXIT;
-          else if (!in_tile) kind = K_EXIT;  // the step itself is added by the user
-          else word = ((ny * TW + nx) << FN_PTR_SH) | ((dy != 0 && dx != 0) ? (1u << 9) : 1u);
+  const uint32_t lx0 = (4u * threadIdx.x) & 63u;  // column of my cells' first (1024 u keeps it)
+#pragma unroll
+  for (int u = 0; u < NT / 4 / 256; u++) {
+    const int c0 = 4 * (threadIdx.x + 256 * u);
+    const uint32_t codes = *reinterpret_cast<const uint32_t *>(&s_fdr[c0]);
+    uint32_t wd[4], kinds = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int c = c0 + k;
+      const uint32_t code = (codes >> (8 * k)) & 0xFFu, cw = (uint32_t)c << FN_PTR_SH;
+      const bool is_river = ((riv4[u] >> (8 * k)) & 0xFFu) == 1u;
+      uint32_t word = cw | FN_DONE, kind = K_DEAD;  // flowhand.py:601 / non-D8 code :830
+      if (interior) {
+        // every cell and every successor is in the core: the table gives the successor's word in one addition; it
+        // left the tile iff the 13-bit pointer field went negative / past 4095 (bit 31) or its column wrapped
+        // (0 <-> 63: the new column differs from mine by 63 instead of <= 1)
+        const uint32_t wn = cw + s_lut[code];
+        if (code != 0u) {
+          if (is_river) {
+            kind = K_RIVER;  // flowhand.py:609-612
+          } else if (wn & FN_CNT) {
+            const bool out = (int32_t)wn < 0 || (((wn >> FN_PTR_SH) & 63u) - (lx0 + (uint32_t)k - 1u)) > 2u;
+            if (out) kind = K_EXIT;  // the step itself is added by the user
+            else word = wn;
+          }
+        }
+      } else {
+        const int ly = c / TW, lx = c % TW;
+        const int y = y0 + ly, x = x0 + lx;
+        if (y < w.H && x < w.W && code != 0u) {
+          if (is_river) {
+            kind = K_RIVER;
+          } else if (dt_d8_valid(code)) {
+            int dy, dx;
+            dt_d8_delta(code, dy, dx);
+            uint32_t ny = (uint32_t)(ly + dy), nx = (uint32_t)(lx + dx);
+            bool in_tile = ny < (uint32_t)TH && nx < (uint32_t)TW;
+            // a step off the raster stays dead (flowhand.py:623-628)
+            if (dt_in_global(w, y + dy, x + dx)) {
+              if (!dt_in_core(w, y + dy, x + dx)) kind = K_REXIT;
+              else if (!in_tile) kind = K_EXIT;
+              else word = ((ny * TW + nx) << FN_PTR_SH) | ((dy != 0 && dx != 0) ? (1u << 9) : 1u);
+            }
+          }
         }
       }
+      wd[k] = word;
+      kinds |= kind << (8 * k);
     }
-    s_w[c] = word;
-    s_kind[c] = (uint8_t)kind;
+    *reinterpret_cast<uint4 *>(&s_w[c0]) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+    *reinterpret_cast<uint32_t *>(&s_kind[c0]) = kinds;
   }
   __syncthreads();
   // pointer doubling in place; ONE addition of the low 19 bits adds both counts and inherits the done bit
@@ -1192,27 +1162,17 @@ __device__ __forceinline__ void fh_tile1n_body(uint8_t *s_fdr, uint32_t *s_w, ui
       if (dx && dy) continue;
       // two jumps per round (in place: a target read here may or may not have jumped already this round; every
       // value it ever held is true): half the rounds, barriers and done-tests for the same gathers
+      // a jump: pointer and done bit of the target, counts added -- ONE addition, target word + my counts (my done
+      // bit is clear, and counts <= 255 cannot carry out of their 9-bit fields)
       if (!dx) {
-        uint32_t t = s_w[v.x >> FN_PTR_SH];
-        uint32_t sum = (v.x & FN_LOW) + (t & FN_LOW);
-        v.x = (t & ~FN_LOW) | sum;
-        if (!(sum & (FN_DONE | FN_OVF))) {
-          t = s_w[v.x >> FN_PTR_SH];
-          sum = (v.x & FN_LOW) + (t & FN_LOW);
-          v.x = (t & ~FN_LOW) | sum;
-        }
-        ovf |= sum & FN_OVF;
+        v.x = s_w[v.x >> FN_PTR_SH] + (v.x & FN_CNT);
+        if (!(v.x & (FN_DONE | FN_OVF))) v.x = s_w[v.x >> FN_PTR_SH] + (v.x & FN_CNT);
+        ovf |= v.x & FN_OVF;
       }
       if (!dy) {
-        uint32_t t = s_w[v.y >> FN_PTR_SH];
-        uint32_t sum = (v.y & FN_LOW) + (t & FN_LOW);
-        v.y = (t & ~FN_LOW) | sum;
-        if (!(sum & (FN_DONE | FN_OVF))) {
-          t = s_w[v.y >> FN_PTR_SH];
-          sum = (v.y & FN_LOW) + (t & FN_LOW);
-          v.y = (t & ~FN_LOW) | sum;
-        }
-        ovf |= sum & FN_OVF;
+        v.y = s_w[v.y >> FN_PTR_SH] + (v.y & FN_CNT);
+        if (!(v.y & (FN_DONE | FN_OVF))) v.y = s_w[v.y >> FN_PTR_SH] + (v.y & FN_CNT);
+        ovf |= v.y & FN_OVF;
       }
       own[j] = v;
       s_w2[c2] = v;
@@ -1226,20 +1186,20 @@ __device__ __forceinline__ void fh_tile1n_body(uint8_t *s_fdr, uint32_t *s_w, ui
     if (threadIdx.x == 0) cache_wide[tile] = 2;  // for k_fh_tile1
     return;
   }
-  // cells unfinished after 13 rounds run into an in-tile D8 cycle: dead (flowhand.py:830-837)
-  uint32_t wv[CPT];
-#pragma unroll
-  for (int j = 0; j < CPT; j++) {
-    int c = threadIdx.x + 256 * j;
-    uint32_t v = s_w[c];
+  // cells unfinished after 13 rounds run into an in-tile D8 cycle: dead (flowhand.py:830-837).  The final words of a
+  // lane's pairs are in its registers and the last round ended with a barrier: the cache's narrow words go straight
+  // into s_w (cache store, perimeter lanes), the kinds of the paths' ends are the only gathers left.
+  auto narrow = [&](uint32_t v, uint32_t c) -> uint32_t {
     uint32_t f = v >> FN_PTR_SH, kind = s_kind[f];
-    if (!(v & FN_DONE)) { f = (uint32_t)c; kind = K_DEAD; v = 0; }
-    wv[j] = f | (kind << 12) | (((v >> 9) & 0xFFu) << 15) | ((v & 0xFFu) << 23);  // the cache's narrow word
+    if (!(v & FN_DONE)) { f = c; kind = K_DEAD; v = 0; }
+    return f | (kind << 12) | (((v >> 9) & 0xFFu) << 15) | ((v & 0xFFu) << 23);
+  };
+#pragma unroll
+  for (int j = 0; j < CPT / 2; j++) {
+    const int c2 = threadIdx.x + 256 * j;
+    s_w2[c2] = make_uint2(narrow(own[j].x, 2u * (uint32_t)c2), narrow(own[j].y, 2u * (uint32_t)c2 + 1u));
   }
   if (threadIdx.x == 0) cache_wide[tile] = 0;
-  __syncthreads();  // everybody has read s_w: reuse it for the final words (cache store, perimeter lanes)
-#pragma unroll
-  for (int j = 0; j < CPT; j++) s_w[threadIdx.x + 256 * j] = wv[j];
   __syncthreads();
   uint32_t *c32 = reinterpret_cast<uint32_t *>(cache + (size_t)tile * NT);
 #pragma unroll
@@ -1278,6 +1238,7 @@ __global__ __launch_bounds__(256, 6) void k_fh_tile1n(const uint8_t *__restrict_
   __shared__ __attribute__((aligned(16))) uint8_t s_fdr[NT];
   __shared__ __attribute__((aligned(16))) uint32_t s_w[NT];
   __shared__ __attribute__((aligned(16))) uint8_t s_kind[NT];  // first the river mask, then the end kinds
+  __shared__ uint32_t s_lut[256];
   __shared__ int s_ovf;
   const int tile = dt_tile_of_block((int)blockIdx.x, (int)gridDim.x);
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
@@ -1287,9 +1248,13 @@ __global__ __launch_bounds__(256, 6) void k_fh_tile1n(const uint8_t *__restrict_
   const uint4 v_riv = dt_tile_fetch16(reinterpret_cast<const uint8_t *>(river), w, y0, x0);
   dt_tile_put16(s_fdr, v_fdr);
   dt_tile_put16(s_kind, v_riv);
+  s_lut[threadIdx.x] = fh_lut_entry(threadIdx.x);
   if (threadIdx.x == 0) s_ovf = 0;
   __syncthreads();
-  fh_tile1n_body(s_fdr, s_w, s_kind, &s_ovf, w, tile, tiles_x, y0, x0, nnodes, nodes, cache, cache_wide);
+  uint32_t riv4[NT / 4 / 256];
+#pragma unroll
+  for (int u = 0; u < NT / 4 / 256; u++) riv4[u] = *reinterpret_cast<const uint32_t *>(&s_kind[4 * (threadIdx.x + 256 * u)]);
+  fh_tile1n_body(s_fdr, s_w, s_kind, &s_ovf, s_lut, riv4, w, tile, tiles_x, y0, x0, nnodes, nodes, cache, cache_wide);
 }
 
 // ---- flow accumulation's last pass and HAND's first pass in one kernel ----------------------------------------
@@ -1410,11 +1375,11 @@ __global__ __launch_bounds__(256, 6) void k_fa3fh1(const uint8_t *__restrict__ f
   uint32_t *s_w = reinterpret_cast<uint32_t *>(smem);             // 16 KiB
   uint8_t *s_fdr = smem + NT * 4;                                  // 4 KiB
   uint8_t *s_kind = smem + NT * 5;                                 // 4 KiB: first the river mask, then the end kinds
+  uint32_t *s_lut = reinterpret_cast<uint32_t *>(smem + NT * 6);   // 1 KiB of the 1.5 KiB left
+  s_lut[threadIdx.x] = fh_lut_entry(threadIdx.x);
   dt_tile_put16(s_fdr, v_fdr);
-#pragma unroll
-  for (int u = 0; u < VPT; u++) *reinterpret_cast<uint32_t *>(&s_kind[4 * (threadIdx.x + 256 * u)]) = riv4[u];
   __syncthreads();
-  fh_tile1n_body(s_fdr, s_w, s_kind, &s_ovf, w, tile, tiles_x, y0, x0, nnodes, nodes, cache, cache_wide);
+  fh_tile1n_body(s_fdr, s_w, s_kind, &s_ovf, s_lut, riv4, w, tile, tiles_x, y0, x0, nnodes, nodes, cache, cache_wide);
 }
 
 // ghost g of ring cell i: a fixed point (ptr = itself, no moves, not done) until resolved

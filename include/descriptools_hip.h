@@ -57,8 +57,7 @@ int dt_set_flow_impl(int impl);
  * instead of non-temporal loads / stores in that stencil (A/B timing); key 2 (DT_DBG_TWI_WX): tile geometry of that
  * stencil, 1 / 2 / 4 = tiles of 256 x 16 / 512 x 8 / 1024 x 4 cells (0 = the default); key 3 (DT_DBG_TWI_MAP): experimental
  * workgroup -> tile maps of that stencil; key 4 (DT_DBG_DS_MARGIN): margin of the downslope kernel's LDS window (16 / 20;
- * default 24); key 5 (DT_DBG_NO_FUSED_FA_FH): the last accumulation pass and HAND's first as two kernels (A/B timing); key 6
- * (DT_DBG_FA_TILE1_OLD): the first accumulation pass with separate pointer / receive words in LDS (A/B timing). */
+ * default 24); key 5 (DT_DBG_NO_FUSED_FA_FH): the last accumulation pass and HAND's first as two kernels (A/B timing). */
 int dt_debug_set(int key, int value);
 
 /* Context = one device + one stream + grow-only scratch.  `stream` may be NULL (the context
