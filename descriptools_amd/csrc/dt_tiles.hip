@@ -1278,10 +1278,9 @@ __global__ __launch_bounds__(256, 6) void k_fa3fh1(const uint8_t *__restrict__ f
   __shared__ __attribute__((aligned(16))) unsigned char smem[NT3 * 6];  // 26112 bytes
   __shared__ unsigned long long s_in;
   __shared__ int s_ovf;
-  // accumulation half: delta raster (also the staging area of the codes) + padded successor indices
+  // accumulation half: delta raster + padded successor indices
   uint32_t *s_delta = reinterpret_cast<uint32_t *>(smem);
   uint16_t *s_nxt = reinterpret_cast<uint16_t *>(smem + NT3 * 4);
-  uint8_t *s_fdr0 = reinterpret_cast<uint8_t *>(s_delta);
   const int tile = dt_tile_of_block((int)blockIdx.x, (int)gridDim.x);
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int y0 = ty * TH, x0 = tx * TW;
@@ -1299,7 +1298,6 @@ __global__ __launch_bounds__(256, 6) void k_fa3fh1(const uint8_t *__restrict__ f
     z4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (HAS_DEM && y < w.H) z4[u] = *reinterpret_cast<const float4 *>(dem + (long long)y * w.ld + x0 + c % TW);
   }
-  dt_tile_put16(s_fdr0, v_fdr);
   if (threadIdx.x == 0) s_ovf = 0;
   if (__syncthreads_or(!(e & FA_CYCLE) && FA_VALUE(e) >= (1ull << 22))) {  // see k_fa_tile3
     if (threadIdx.x == 0) s_in = 0ull;
@@ -1308,24 +1306,26 @@ __global__ __launch_bounds__(256, 6) void k_fa3fh1(const uint8_t *__restrict__ f
     __syncthreads();
     if (threadIdx.x == 0 && s_in >= (1ull << 31) - (unsigned long long)NT && status) atomicOr(status, DT_STATUS_ACC_OVERFLOW);
   }
-  uint32_t nx[CPT];
-  if (dt_tile_interior(w, y0, x0)) {
+  // successor indices of the 16 cells whose codes this lane fetched (row t / 4, columns 16 (t % 4) ..): straight from
+  // its registers, the padded row is contiguous -- four 8-byte stores of indices, four 16-byte stores of zeros
+  {
+    const int ly = (int)threadIdx.x >> 2, lxb = ((int)threadIdx.x & 3) * 16;
+    const uint32_t cv[4] = {v_fdr.x, v_fdr.y, v_fdr.z, v_fdr.w};
+    const bool interior = dt_tile_interior(w, y0, x0);
+    const int pbase = ly * (TW + 4) + lxb;
 #pragma unroll
-    for (int j = 0; j < CPT; j++) {
-      int c = threadIdx.x + 256 * j;
-      nx[j] = dt_tile_next_interior(s_fdr0[c], c / TW, c % TW);
+    for (int q = 0; q < 4; q++) {
+      uint32_t nn[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t code = (cv[q] >> (8 * k)) & 0xFFu;
+        const int lx = lxb + 4 * q + k;
+        const uint32_t n = interior ? dt_tile_next_interior(code, ly, lx) : dt_tile_next(code, ly, lx, y0, x0, w);
+        nn[k] = n < NT ? P3(n) : n;
+      }
+      *reinterpret_cast<uint2 *>(&s_nxt[pbase + 4 * q]) = make_uint2(nn[0] | (nn[1] << 16), nn[2] | (nn[3] << 16));
+      *reinterpret_cast<uint4 *>(&s_delta[pbase + 4 * q]) = make_uint4(0, 0, 0, 0);
     }
-  } else {
-    for (int j = 0; j < CPT; j++) {
-      int c = threadIdx.x + 256 * j;
-      nx[j] = dt_tile_next(s_fdr0[c], c / TW, c % TW, y0, x0, w);
-    }
-  }
-  __syncthreads();
-  for (int j = 0; j < CPT; j++) {
-    int c = threadIdx.x + 256 * j;
-    s_nxt[P3(c)] = (uint16_t)(nx[j] < NT ? P3(nx[j]) : nx[j]);
-    s_delta[P3(c)] = 0u;
   }
   __syncthreads();
   if (e != 0ull) {
