@@ -573,15 +573,23 @@ def end_to_end(n, seed):
     del rh
     # (b) the reference's call sequence through the drop-in API
     river = (fac > thr).astype(np.int8)
+    lib_s = 0.0
+
+    def timed(fn, *a):
+        nonlocal lib_s
+        ta = time.perf_counter()
+        r = fn(*a)
+        lib_s += time.perf_counter() - ta
+        return r
     t6 = time.perf_counter()
-    sl = slope.sloper(dem, px).astype("float32")
+    sl = timed(slope.sloper, dem, px).astype("float32")
     slr = np.arctan(sl / 100).astype("float32")
     slr = np.where(dem == -100, -100, slr)
-    ti, mti = topoindexes.topographic_index(fac, slr, px, 0.1)
-    down = downslope.downsloper(dem, fdr, px, 5)
-    flow, indices, hand = flowhand.flow_hand_index(dem, fdr, river, px)
-    geofi = gfi.gfi_calculator(hand, fac, indices, 0.4, 0.1, px)
-    lnhlh = gfi.ln_hl_H_calculator(hand, fac, 0.4, 0.1, px)
+    ti, mti = timed(topoindexes.topographic_index, fac, slr, px, 0.1)
+    down = timed(downslope.downsloper, dem, fdr, px, 5)
+    flow, indices, hand = timed(flowhand.flow_hand_index, dem, fdr, river, px)
+    geofi = timed(gfi.gfi_calculator, hand, fac, indices, 0.4, 0.1, px)
+    lnhlh = timed(gfi.ln_hl_H_calculator, hand, fac, 0.4, 0.1, px)
     t7 = time.perf_counter()
     del sl, slr, ti, mti, down, flow, indices, hand, geofi, lnhlh, river, fdr, fac, dem
     from descriptools_amd import device
@@ -609,9 +617,12 @@ def end_to_end(n, seed):
                      "note": "chain.run_host, numpy DEM in, 13 numpy rasters out (fac / idx widened to int64), warm "
                              "page-locked pool"},
         "dropin_api": {"seconds": round(t7 - t6, 3), "Mcells_s": round(cells / (t7 - t6) / 1e6, 1),
+                       "library_calls_s": round(lib_s, 3), "caller_numpy_s": round(t7 - t6 - lib_s, 3),
                        "note": "sloper, arctan (host numpy, example.py:63), topographic_index, downsloper, "
                                "flow_hand_index, gfi_calculator, ln_hl_H_calculator: pageable numpy in / out in the "
-                               "reference's dtypes, one H2D / D2H round trip per call as the reference's *_cpu shims"},
+                               "reference's dtypes, one H2D / D2H round trip per call as the reference's *_cpu shims; "
+                               "library_calls_s = inside the six library functions, caller_numpy_s = the script's own "
+                               "numpy lines between them (astype / arctan / where, example.py:63)"},
         "example": ex,
     }
 

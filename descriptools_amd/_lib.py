@@ -30,6 +30,7 @@ _SIGS = {
     "dt_host_trim": (ci, []),
     "dt_host_alloc": (ci, [i64, C.POINTER(vp)]),
     "dt_host_free": (ci, [vp]),
+    "dt_host_f32_to_f64": (ci, [c_f32p, C.POINTER(C.c_double), i64]),
     "dt_ctx_create": (ci, [ci, vp, C.POINTER(vp)]),
     "dt_ctx_destroy": (ci, [vp]),
     "dt_ctx_set_stream": (ci, [vp, vp]),

@@ -98,8 +98,23 @@ class Chain:
             elif self._release is not None:
                 self._release(q)
         can_grow = self._alloc is None or self._release is not None
+
+        def spacer_alloc(nbytes):
+            rows = max(int(nbytes) // (self.W * 4), 1)
+            if self._alloc:
+                return ("user", self._alloc((rows, self.W), F32))
+            return ("own", self.ctx.empty((rows, self.W), F32))
+
+        def spacer_release(h):
+            kind, b = h
+            if kind == "own":
+                b.free()
+            else:
+                self._release(int(b.ptr.value if hasattr(b, "ptr") else b))
         roles, info = placement.assign(self.ctx, self.N * 4, list(objs), [list(g) for g in WRITE_GROUPS],
-                                       extra_alloc if can_grow else None, extra_release if can_grow else None)
+                                       extra_alloc if can_grow else None, extra_release if can_grow else None,
+                                       spacer_alloc=spacer_alloc if can_grow else None,
+                                       spacer_release=spacer_release if can_grow else None)
         self.placement = info
         if roles is None:
             return

@@ -2,7 +2,10 @@
 #include <stdarg.h>
 #include <stdlib.h>
 
+#include <sys/mman.h>
 #include <mutex>
+#include <thread>
+#include <utility>
 #include <vector>
 
 #include "dt_common.h"
@@ -1084,14 +1087,90 @@ extern "C" int dt_host_trim(void) {
 }
 // page-locked host memory for rasters that cross PCIe at full rate (the Python package keeps a pool of these
 // behind the arrays chain.run_host returns)
+// Page-locked host memory for rasters.  Large blocks are anonymous mappings on transparent huge pages, first touched
+// by a few threads, then registered with the runtime: 9-15 ms per GiB on the MI355X host against 125 ms for
+// hipHostMalloc (which faults and pins 4 KiB pages one thread at a time), the same 57 GB/s device-to-host
+// (tools/micro/host_alloc.cpp, profiles/r3/host_alloc.txt).  Falls back to hipHostMalloc when the mapping or the
+// registration is refused.
+struct HostMap {
+  void *map;
+  size_t map_bytes;
+};
+static std::mutex g_hostmap_mu;
+static std::vector<std::pair<void *, HostMap>> g_hostmaps;  // registered blocks by their aligned address
+static const size_t DT_HUGE = (size_t)2 << 20;
+
 extern "C" int dt_host_alloc(int64_t bytes, void **out) {
   DT_REQUIRE(out && bytes >= 0, "bad arguments");
   *out = nullptr;
+  if ((size_t)bytes >= 16 * DT_HUGE) {
+    const size_t n = ((size_t)bytes + DT_HUGE - 1) & ~(DT_HUGE - 1);
+    void *m = mmap(nullptr, n + DT_HUGE, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (m != MAP_FAILED) {
+      char *a = (char *)(((uintptr_t)m + DT_HUGE - 1) & ~(uintptr_t)(DT_HUGE - 1));
+      (void)madvise(a, n, MADV_HUGEPAGE);
+      unsigned hc = std::thread::hardware_concurrency();
+      const int threads = (int)(hc == 0 ? 1 : (hc > 8 ? 8 : hc));
+      const size_t per = ((n / (size_t)threads) + DT_HUGE - 1) & ~(DT_HUGE - 1);
+      std::vector<std::thread> th;
+      for (int t = 0; t < threads; t++)
+        th.emplace_back([=] {
+          for (size_t o = per * (size_t)t; o < n && o < per * (size_t)(t + 1); o += 4096) a[o] = 0;
+        });
+      for (auto &t : th) t.join();
+      if (hipHostRegister(a, n, hipHostRegisterDefault) == hipSuccess) {
+        std::lock_guard<std::mutex> lk(g_hostmap_mu);
+        g_hostmaps.push_back({(void *)a, HostMap{m, n + DT_HUGE}});
+        *out = a;
+        return DT_OK;
+      }
+      (void)hipGetLastError();
+      munmap(m, n + DT_HUGE);
+    }
+  }
   DT_HIP(hipHostMalloc(out, bytes > 0 ? (size_t)bytes : 16, hipHostMallocDefault));
   return DT_OK;
 }
 extern "C" int dt_host_free(void *p) {
-  if (p) DT_HIP(hipHostFree(p));
+  if (!p) return DT_OK;
+  HostMap hm{nullptr, 0};
+  {
+    std::lock_guard<std::mutex> lk(g_hostmap_mu);
+    for (size_t i = 0; i < g_hostmaps.size(); i++)
+      if (g_hostmaps[i].first == p) {
+        hm = g_hostmaps[i].second;
+        g_hostmaps.erase(g_hostmaps.begin() + (long)i);
+        break;
+      }
+  }
+  if (hm.map) {
+    DT_HIP(hipHostUnregister(p));
+    munmap(hm.map, hm.map_bytes);
+    return DT_OK;
+  }
+  DT_HIP(hipHostFree(p));
+  return DT_OK;
+}
+// float32 -> float64 on the host with a few threads (the reference's containers are float64 rasters holding float32
+// values: numpy's single-threaded astype over a 16384^2 raster costs more than the kernel and both copies together)
+extern "C" int dt_host_f32_to_f64(const float *src, double *dst, int64_t n) {
+  DT_REQUIRE((src && dst) || n == 0, "NULL pointer");
+  DT_REQUIRE(n >= 0, "negative size");
+  unsigned hc = std::thread::hardware_concurrency();
+  int threads = (int)(hc == 0 ? 1 : (hc > 8 ? 8 : hc));
+  if (n < (int64_t)1 << 22) threads = 1;
+  const int64_t per = (n + threads - 1) / threads;
+  auto work = [=](int t) {
+    const int64_t a = per * t, b = a + per < n ? a + per : n;
+    for (int64_t i = a; i < b; i++) dst[i] = (double)src[i];
+  };
+  if (threads == 1) {
+    work(0);
+    return DT_OK;
+  }
+  std::vector<std::thread> th;
+  for (int t = 0; t < threads; t++) th.emplace_back(work, t);
+  for (auto &t : th) t.join();
   return DT_OK;
 }
 #define H2D(dst, src, bytes, c) DT_HIP(hipMemcpyAsync((dst).p, (src), (bytes), hipMemcpyHostToDevice, (c)->stream))

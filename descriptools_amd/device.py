@@ -60,6 +60,30 @@ class PinnedPool:
 
 PINNED = PinnedPool()
 
+HOST_POOL_MIN = 32 << 20   # rasters from this size come from the page-locked pool
+
+
+def host_empty(shape, dtype):
+    """Host array for a raster the library is about to fill: page-locked pool memory from 32 MiB (a device-to-host
+    copy into fresh pageable memory runs at a third of the PCIe rate, and faulting the pages in costs as much
+    again), plain numpy below."""
+    dtype = np.dtype(dtype)
+    if int(np.prod(shape)) * dtype.itemsize >= HOST_POOL_MIN:
+        return PINNED.empty(shape, dtype)
+    return np.empty(shape, dtype)
+
+
+def widen64(a32):
+    """float32 raster -> the float64 container the reference returns (values unchanged): threaded on the host for
+    large rasters, numpy's astype below"""
+    a32 = np.ascontiguousarray(a32, np.float32)
+    if a32.nbytes < HOST_POOL_MIN:
+        return a32.astype(np.float64)
+    out = PINNED.empty(a32.shape, np.float64)
+    check(_lib.lib().dt_host_f32_to_f64(a32.ctypes.data_as(C.POINTER(C.c_float)),
+                                        out.ctypes.data_as(C.POINTER(C.c_double)), a32.size))
+    return out
+
 
 class DeviceArray:
     def __init__(self, ctx, shape, dtype):

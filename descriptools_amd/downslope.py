@@ -5,13 +5,14 @@ import numpy as np
 
 from . import _lib
 from ._lib import c_f32p, c_u8p, check, dem_f32, ptr
+from .device import host_empty, widen64
 
 
 def _run(dem, flow_direction, px, elevation_difference, raw):
     d = dem_f32(dem)
     fdr = np.ascontiguousarray(flow_direction, np.uint8)
     H, W = d.shape
-    out = np.empty((H, W), np.float32)
+    out = host_empty((H, W), np.float32)
     check(_lib.lib().dt_downslope(ptr(d, c_f32p), ptr(fdr, c_u8p), H, W, float(px),
                                   float(elevation_difference), raw, ptr(out, c_f32p)))
     return out
@@ -24,7 +25,7 @@ def downsloper(dem, flow_direction, px, elevation_difference, column_division=0,
 
 def downslope_cpu(dem, flow_direction, px, elevation_difference, blocks=0, threads=0):
     """downslope.py:379-431 alone: float64, walks the kernel cannot finish are the marker -50."""
-    return _run(dem, flow_direction, px, elevation_difference, 1).astype(np.float64)
+    return widen64(_run(dem, flow_direction, px, elevation_difference, 1))
 
 
 def downslope_sequential_jit(dem, flow_direction, px, elevation_difference, downslope=None):

@@ -4,6 +4,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import c_f32p, c_i8p, c_i64p, c_u8p, check, dem_f32, ptr
+from .device import host_empty
 
 
 def _hand_dtype(dem):
@@ -19,21 +20,23 @@ def flow_hand_index(dem_raster, flow_direction_matrix, river_matrix, px, divisio
     fdr = np.ascontiguousarray(flow_direction_matrix, np.uint8)
     river = np.ascontiguousarray(river_matrix, np.int8)
     H, W = fdr.shape
-    fd = np.empty((H, W), np.float32)
-    idx = np.empty((H, W), np.int64)
-    hand = np.empty((H, W), np.float32)
+    fd = host_empty((H, W), np.float32)
+    idx = host_empty((H, W), np.int64)
+    hand = host_empty((H, W), np.float32)
     check(_lib.lib().dt_flowhand(ptr(dem32, c_f32p), ptr(fdr, c_u8p), ptr(river, c_i8p), H, W, float(px),
                                  ptr(fd, c_f32p), ptr(idx, c_i64p), ptr(hand, c_f32p)))
-    return fd, idx, hand.astype(_hand_dtype(dem_raster))
+    ht = _hand_dtype(dem_raster)
+    return fd, idx, (hand if ht == np.float32 else hand.astype(ht))
 
 
 def hand_calculator(dem, indices):
     """flowhand.py:414-442."""
     dem32 = dem_f32(dem)
     idx = np.ascontiguousarray(indices, np.int64)
-    hand = np.empty(dem32.shape, np.float32)
+    hand = host_empty(dem32.shape, np.float32)
     check(_lib.lib().dt_hand_f32(ptr(dem32, c_f32p), ptr(idx, c_i64p), dem32.size, ptr(hand, c_f32p)))
-    return hand.astype(_hand_dtype(dem))
+    ht = _hand_dtype(dem)
+    return hand if ht == np.float32 else hand.astype(ht)
 
 
 def index_calculator(river_indices, row_start, column_start, column_size):

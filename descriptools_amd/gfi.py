@@ -3,13 +3,14 @@ import numpy as np
 
 from . import _lib
 from ._lib import c_f32p, c_i64p, check, dem_f32, ptr
+from .device import host_empty, widen64
 
 
 def river_accumulation(flow_accumulation, indices):
     """gfi.py:119-147: fac.flat[idx] where idx != -100, else fac.flat[0]."""
     fac = np.ascontiguousarray(flow_accumulation, np.int64)
     idx = np.ascontiguousarray(indices, np.int64)
-    out = np.empty(fac.shape, np.int64)
+    out = host_empty(fac.shape, np.int64)
     check(_lib.lib().dt_river_accumulation(ptr(fac, c_i64p), ptr(idx, c_i64p), fac.size, ptr(out, c_i64p)))
     return out
 
@@ -17,7 +18,7 @@ def river_accumulation(flow_accumulation, indices):
 def _area_index(hand, area, expoent, scale_factor, size, zero_guard):
     h = dem_f32(hand, "HAND")
     a = np.ascontiguousarray(area, np.int64)
-    out = np.empty(h.shape, np.float32)
+    out = host_empty(h.shape, np.float32)
     check(_lib.lib().dt_gfi_area(ptr(h, c_f32p), ptr(a, c_i64p), h.size, float(expoent), float(scale_factor),
                                  float(size), zero_guard, ptr(out, c_f32p)))
     return out
@@ -35,10 +36,10 @@ def gfi_calculator(hand, flow_accumulation, indices, n_gfi, scale_factor, size, 
     h = dem_f32(hand, "HAND")
     fac = np.ascontiguousarray(flow_accumulation, np.int64)
     idx = np.ascontiguousarray(indices, np.int64)
-    out = np.empty(h.shape, np.float32)
+    out = host_empty(h.shape, np.float32)
     check(_lib.lib().dt_gfi(ptr(h, c_f32p), ptr(fac, c_i64p), ptr(idx, c_i64p), h.size, float(n_gfi),
                             float(scale_factor), float(size), ptr(out, c_f32p)))
-    return out.astype(np.float64)
+    return widen64(out)
 
 
 def ln_hl_H_cpu(hand, flow_accumulation, expoent, scale_factor, size, blocks=0, threads=0):
@@ -49,7 +50,7 @@ def ln_hl_H_cpu(hand, flow_accumulation, expoent, scale_factor, size, blocks=0, 
 def ln_hl_H_calculator(hand, flow_accumulation, n_gfi, scale_factor, size, division_column=0,
                        division_row=0):
     """gfi.py:297-346 -> float64 raster holding float32 values."""
-    return ln_hl_H_cpu(hand, flow_accumulation, n_gfi, scale_factor, size).astype(np.float64)
+    return widen64(ln_hl_H_cpu(hand, flow_accumulation, n_gfi, scale_factor, size))
 
 
 def geomorphic_flood_index_sequential_jit(hand, river_flow_accumulation, expoent, scale_factor, size):

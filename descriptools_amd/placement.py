@@ -88,12 +88,18 @@ def spread(labels, groups):
     return out, [b for lst in by_class.values() for b in lst]
 
 
-def assign(ctx, nbytes, blocks, groups, extra_alloc=None, extra_release=None, budget=24):
+def assign(ctx, nbytes, blocks, groups, extra_alloc=None, extra_release=None, budget=24, spacer_alloc=None,
+           spacer_release=None, spacer_budget=160 << 30):
     """blocks: device pointers of equally sized blocks (>= one per role); groups: role names written together.
     Returns ({role: pointer}, info) -- or (None, info) when the rasters are too small to bother.  When the blocks
     span fewer classes than the largest group could use and `extra_alloc()` -> pointer is given, up to `budget`
     further blocks are allocated and labelled; those that add diversity replace blocks of the majority class
-    (`extra_release(pointer)` gets every block that ends up unused, original or extra)."""
+    (`extra_release(pointer)` gets every block that ends up unused, original or extra).
+    A class holds for runs of 8-32 GiB of consecutive allocations (profiles/r3/placement_classes.txt: 120 x 1 GiB on
+    one box read ABBAABBBBBBBBBBBB AAAAAAAA B x16 C x16 A x16 B x32 A x15), so candidates allocated back to back can
+    all be alike: with `spacer_alloc(nbytes)` -> handle a candidate that adds nothing is followed by a spacer
+    (4, 8, 16, 16, ... GiB, `spacer_budget` bytes in all, released at the end) that moves the next candidate on,
+    and one that does add a class is followed by its neighbours, which share its run."""
     blocks = [b.value if hasattr(b, "value") else int(b) for b in blocks]
     cl = WriteClassifier(ctx, nbytes)
     if not cl.usable():
@@ -101,29 +107,59 @@ def assign(ctx, nbytes, blocks, groups, extra_alloc=None, extra_release=None, bu
     labels = {int(b): cl.label(b) for b in blocks}
     want = min(3, max(len(g) for g in groups))   # three classes exist on MI355X; a group of 3 can use them all
     need = sum(len(g) * 2 // 3 for g in groups if len(g) > 1)  # blocks outside the commonest class: 2/3 of each group
-    extras = []
+    spacers, spaced = [], 0
 
-    def minority_blocks():
-        counts = {}
+    def counts():
+        c = {}
         for k in labels.values():
-            counts[k] = counts.get(k, 0) + 1
-        major = max(counts, key=counts.get)
-        return sum(v for k, v in counts.items() if k != major), len(counts)
-    tried = 0
-    while extra_alloc is not None and tried < budget:
-        minority, nclasses = minority_blocks()
-        # enough when every group can avoid a single class: two blocks outside the majority class per group and
-        # (if reachable) three classes for the first group
-        if nclasses >= want and minority >= need:
-            break
-        p = int(extra_alloc())
-        tried += 1
-        extras.append(p)
-        labels[p] = cl.label(p)
+            c[k] = c.get(k, 0) + 1
+        return c
+
+    def enough():
+        c = counts()
+        major = max(c, key=c.get)
+        # every group can avoid a single class: two blocks outside the majority class per group and (if reachable)
+        # three classes for the first group
+        return len(c) >= want and sum(v for k, v in c.items() if k != major) >= need
+    tried, step, full = 0, 4 << 30, False
+
+    def try_alloc(fn, *a):
+        nonlocal full
+        try:
+            return fn(*a)
+        except (MemoryError, RuntimeError):  # the device is full: work with what was found
+            full = True
+            return None
+    try:
+        while extra_alloc is not None and tried < budget and not full and not enough():
+            before = counts()
+            p = try_alloc(extra_alloc)
+            if p is None:
+                break
+            p = int(p)
+            tried += 1
+            k = labels[p] = cl.label(p)
+            major = max(before, key=before.get)
+            if k != major or spacer_alloc is None:
+                continue  # a rarer class: its neighbours in allocation order share the run -- keep allocating
+            if spaced + step > spacer_budget:
+                spacer_alloc = None  # out of spacer budget: back-to-back candidates for what is left of `budget`
+                continue
+            h = try_alloc(spacer_alloc, step)
+            if h is None:
+                full, spacer_alloc = False, None  # no room for spacers: carry on without them
+                continue
+            spacers.append(h)
+            spaced += step
+            step = min(step * 2, 16 << 30)
+    finally:
+        if spacer_release is not None:
+            for h in spacers:
+                spacer_release(h)
     roles, left = spread(labels, groups)
     if extra_release is not None:
         for b in left:
             extra_release(b)
     classes = {r: labels[b] for r, b in roles.items()}
     return roles, {"tuned": True, "classes": classes, "candidates_tried": tried, "blocks": len(labels),
-                   "single_stream_ms": round(cl.single_ms, 4), "n_classes": len(cl.reps)}
+                   "spacer_GiB": spaced >> 30, "single_stream_ms": round(cl.single_ms, 4), "n_classes": len(cl.reps)}

@@ -8,11 +8,12 @@ import numpy as np
 
 from . import _lib
 from ._lib import C, c_f32p, check, dem_f32, ptr
+from .device import host_empty, widen64
 
 
 def _slope(dem32, px):
     H, W = dem32.shape
-    out = np.empty((H, W), np.float32)
+    out = host_empty((H, W), np.float32)
     check(_lib.lib().dt_slope_f32(ptr(dem32, c_f32p), H, W, float(px), ptr(out, c_f32p)))
     return out
 
@@ -22,7 +23,7 @@ def sloper(dem, px, division_column=0, division_row=0):
     dem32 = dem_f32(dem)
     if dem32.ndim != 2:
         raise ValueError("dem must be 2-D")
-    return _slope(dem32, px).astype(np.float64)
+    return widen64(_slope(dem32, px))
 
 
 def slope_cpu(dem, px, extra, blocks=0, threads=0):

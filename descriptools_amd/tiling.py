@@ -367,8 +367,14 @@ class RankTile:
 
         def extra_release(q):
             objs.pop(q)
+        def spacer_alloc(nbytes):
+            return tc.empty(int(nbytes), dtype=tc.uint8, device=self.dev)
+
+        def spacer_release(x):
+            del x
         self.ctx.sync()
-        roles, info = placement.assign(self.ctx, self.He * self.We * 4, list(objs), groups, extra_alloc, extra_release)
+        roles, info = placement.assign(self.ctx, self.He * self.We * 4, list(objs), groups, extra_alloc, extra_release,
+                                       spacer_alloc=spacer_alloc, spacer_release=spacer_release)
         self.placement = info
         if roles is None:
             return

@@ -105,6 +105,9 @@ int64_t dt_ctx_scratch_bytes(dt_ctx *ctx);
 int dt_host_trim(void);
 int dt_host_alloc(int64_t bytes, void **out);
 int dt_host_free(void *p);
+/* dst[i] = (double)src[i] on the host with a few threads (float64 containers of float32 rasters, as the reference
+ * returns them). */
+int dt_host_f32_to_f64(const float *src, double *dst, int64_t n);
 
 
 /* slope.slope_cpu + slope_gpu (slope.py:152-259): steepest-descent slope in percent.  The

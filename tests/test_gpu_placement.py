@@ -45,3 +45,79 @@ def test_tuned_chain_gives_identical_rasters():
     dem.free()
     ctx.close()
     torch.cuda.empty_cache()
+
+
+class _RunOfOneClass:
+    """stands in for placement.WriteClassifier: the first `run` distinct blocks it sees are class 0 (a long run of one
+    class in allocation order, as on some boxes: profiles/r3/placement_classes.txt), later ones alternate 1 / 2"""
+    run = 30
+
+    def __init__(self, ctx, nbytes):
+        self.seen, self.reps, self.single_ms = {}, [], 0.1
+
+    def usable(self):
+        return True
+
+    def label(self, p):
+        p = int(p)
+        if p not in self.seen:
+            i = len(self.seen)
+            self.seen[p] = 0 if i < self.run else 1 + (i % 2)
+            if self.seen[p] not in [self.seen[q] for q in self.reps]:
+                self.reps.append(p)
+        return self.seen[p]
+
+
+def test_search_with_spacers_when_the_first_blocks_are_all_alike(monkeypatch):
+    """12 rasters + 24 back-to-back candidates of one class used to leave the chain untuned; with spacers between the
+    candidates the search moves on, finds the other classes and releases every spacer and unused candidate -- for the
+    chain's own allocator, for a caller's alloc / release pair, and for a rank tile's torch tensors"""
+    import torch
+    from descriptools_amd import _lib, chain, placement, tiling
+    from descriptools_amd.device import Context
+    monkeypatch.setattr(placement, "WriteClassifier", _RunOfOneClass)
+    n = 2048
+    ctx = Context()
+    L = _lib.lib()
+    dem = ctx.empty((n, n), np.float32)
+    _lib.check(L.dt_dev_synth_dem(ctx.h, 3, n, n, 0, 0, n, n, 1, dem.ptr))
+    ref = chain.Chain(n, n, ctx=ctx, tune_placement=False)
+    ref.run(dem.ptr)
+    ctx.sync()
+    want = {k: ref.buf[k].to_host() for k, _ in chain.OUTPUTS}
+    ref.free()
+    # (a) the chain's own allocator
+    ch = chain.Chain(n, n, ctx=ctx)
+    info = ch.placement
+    assert info["tuned"] and info["n_classes"] == 3 and info["spacer_GiB"] >= 4
+    assert len({info["classes"][r] for r in ("slope", "ti", "mti")}) >= 2
+    ch.run(dem.ptr)
+    ctx.sync()
+    for k, _ in chain.OUTPUTS:
+        assert np.array_equal(ch.buf[k].to_host(), want[k], equal_nan=True), k
+    ch.free()
+    # (b) a caller's alloc / release pair (torch): everything not kept comes back
+    held = {}
+
+    def alloc(shape, dt):
+        t = torch.empty(shape, dtype={np.float32: torch.float32, np.uint8: torch.uint8, np.int8: torch.int8,
+                                      np.int32: torch.int32}[dt], device="cuda")
+        held[t.data_ptr()] = t
+        return t.data_ptr()
+
+    def release(q):
+        del held[q]
+    ch = chain.Chain(n, n, ctx=ctx, alloc=alloc, release=release)
+    assert ch.placement["spacer_GiB"] >= 4 and len(held) == len(chain.OUTPUTS)
+    ch.run(dem.ptr)
+    ctx.sync()
+    ch.free()
+    held.clear()
+    # (c) a rank tile
+    layout = tiling.Layout([n], [n])
+    tl = tiling.RankTile(layout, 0, device=0)
+    assert tl.placement["tuned"] and tl.placement["spacer_GiB"] >= 4
+    tl.free()
+    dem.free()
+    ctx.close()
+    torch.cuda.empty_cache()

@@ -221,7 +221,8 @@ def mode_classes(K, pattern):
 def mode_shift(K):
     """do two / three write streams that CONFLICT (rasters allocated alike: mode pick) stop conflicting when their
     bases differ by less than a 4-KiB page?  Candidates are allocated with slack and used at byte offsets k * step."""
-    slack = 8192  # floats
+    big = os.environ.get("PROBE_BIGSHIFT", "0") == "1"  # shifts up to 128 MiB (bank / row bits) instead of < 16 KiB
+    slack = (160 << 20) // 4 if big else 8192  # floats
     store = [torch.empty(n + slack, dtype=torch.float32, device="cuda") for _ in range(K)]
 
     def view(i, off_bytes):
@@ -234,7 +235,16 @@ def mode_shift(K):
     print("pairs at equal offsets (ms): " + "  ".join("%d-%d %.3f" % (i, j, wr([view(i, 0), view(j, 0)]))
                                                      for i, j in itertools.combinations(range(min(K, 5)), 2)))
     a, b, c = K - 3, K - 2, K - 1  # late allocations: the class that conflicts with itself
-    for step in (0, 64, 128, 256, 512, 1024, 2048, 4096, 8192):
+    if big:  # a triple that does conflict at equal offsets, wherever it was allocated
+        slow = lambda i, j: wr([view(i, 0), view(j, 0)]) > 0.325 * (n / 2 ** 28)
+        found = [(i, j, k) for i, j, k in itertools.combinations(range(K), 3) if slow(i, j) and slow(i, k) and slow(j, k)]
+        if found:
+            a, b, c = found[0]
+        print("conflicting triple: blocks %d %d %d%s" % (a, b, c, "" if found else "  (NONE FOUND: the steps below say nothing)"))
+    steps = (0, 64, 128, 256, 512, 1024, 2048, 4096, 8192)
+    if big:
+        steps = (0,) + tuple(1 << k for k in range(14, 27)) + (3 << 18, 3 << 20, 5 << 20, 3 << 22, 5 << 22, 3 << 24)
+    for step in steps:
         p2 = wr([view(a, 0), view(b, step)])
         p3 = wr([view(a, 0), view(b, step), view(c, 2 * step)])
         print("second / third raster shifted by %5d / %5d bytes: pair %.3f ms   triple %.3f ms (%.0f GB/s)"
@@ -242,7 +252,7 @@ def mode_shift(K):
     dem, fac = raster(), raster()
     _lib.check(L.dt_dev_synth_dem(ctx.h, 1, S, S, 0, 0, S, S, 0, dem.data_ptr()))
     fac.view(torch.int32).random_(0, 5000)
-    for step in (0, 256, 512, 1024, 2048):
+    for step in ((0, 1 << 18, 1 << 20, 1 << 22, 1 << 24, 3 << 20) if big else (0, 256, 512, 1024, 2048)):
         ms = timed(fused(dem, fac, view(a, 0), view(b, step), view(c, 2 * step)))
         ms2 = timed(fused(dem, view(K - 4, step * 3)[:n] if K >= 4 else fac, view(a, 0), view(b, step), view(c, 2 * step)))
         print("fused stencil, outputs shifted by 0 / %d / %d bytes: %.3f ms = %.1f %% of 8 TB/s   (fac shifted by %d too: %.3f ms)"
