@@ -58,6 +58,7 @@ def _check(parts, Hg, Wg, seed, nodata):
     (4, 192, 256, 2, "exchange", 0),     # 2 x 2, DEM halo exchanged point-to-point, nodata blobs
     (4, 128, 128, 0, "synth", 1),        # 2 x 2, downslope as a second branch
     (3, 128, 192, 3, "exchange", 0),     # 1 x 3 (at most 4 ranks: the box admits 6 GPU processes, pytest is one)
+    (2, 2048, 1536, 1, "exchange", 1),   # 1 x 2 of 32 x 24 tiles each: rivers and HAND paths across a process border
 ])
 def test_run_rank_gloo_ranks_sharing_the_gpu(tmp_path, world, h, w, nodata, halo, overlap):
     parts = _launch(tmp_path, world, h, w, seed=5, nodata=nodata, halo=halo, overlap=overlap)
