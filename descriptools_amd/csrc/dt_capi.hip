@@ -1118,7 +1118,7 @@ extern "C" int dt_host_alloc(int64_t bytes, void **out) {
           for (size_t o = per * (size_t)t; o < n && o < per * (size_t)(t + 1); o += 4096) a[o] = 0;
         });
       for (auto &t : th) t.join();
-      if (hipHostRegister(a, n, hipHostRegisterDefault) == hipSuccess) {
+      if (hipHostRegister(a, n, hipHostRegisterPortable) == hipSuccess) {
         std::lock_guard<std::mutex> lk(g_hostmap_mu);
         g_hostmaps.push_back({(void *)a, HostMap{m, n + DT_HUGE}});
         *out = a;
