@@ -559,7 +559,8 @@ def end_to_end(n, seed):
     ch.run(d.ptr, want_a_river=False)
     ctx.sync()
     t2 = time.perf_counter()
-    outs = {k: ch.buf[k].to_host(pinned=True) for k, _ in chain.OUTPUTS if k not in ("a_river", "slope_rad")}
+    outs = {k: ch.buf[k].to_host_async() for k, _ in chain.OUTPUTS if k not in ("a_river", "slope_rad")}
+    ctx.sync()
     t3 = time.perf_counter()
     nbytes_out = sum(a.nbytes for a in outs.values())
     fdr, fac = outs["fdr"].copy(), outs["fac"].astype(np.int64)

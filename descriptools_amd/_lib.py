@@ -65,6 +65,7 @@ _SIGS = {
     "dt_dev_free": (ci, [vp, vp]),
     "dt_dev_h2d": (ci, [vp, vp, vp, i64]),
     "dt_dev_d2h": (ci, [vp, vp, vp, i64]),
+    "dt_dev_d2h_async": (ci, [vp, vp, vp, i64]),
     "dt_dev_synth_dem": (ci, [vp, u32, i64, i64, i64, i64, i64, i64, ci, vp]),
     "dt_dev_slope_d8": (ci, [vp, vp, i64, i64, f64, vp, vp, vp]),
     "dt_dev_slope_twi": (ci, [vp, vp, vp, i64, i64, f64, f64, vp, vp, vp, vp]),

@@ -354,6 +354,15 @@ extern "C" int dt_dev_d2h(dt_ctx *c, void *dst, const void *src, int64_t bytes) 
   return DT_OK;
 }
 
+// enqueue only (dt_ctx_sync before the host reads dst; dst should be page-locked: dt_host_alloc)
+extern "C" int dt_dev_d2h_async(dt_ctx *c, void *dst, const void *src, int64_t bytes) {
+  DT_CTX(c);
+  if (bytes <= 0) return DT_OK;
+  DT_REQUIRE(dst && src, "NULL pointer");
+  DT_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
+  return DT_OK;
+}
+
 extern "C" int dt_dev_slope_twi(dt_ctx *c, const float *dem, const int32_t *acc32, int64_t H, int64_t W,
                                 double px, double n_top, float *slope, float *slope_rad, float *ti,
                                 float *mti) {

@@ -197,6 +197,8 @@ int dt_dev_malloc(dt_ctx *ctx, int64_t bytes, void **out);
 int dt_dev_free(dt_ctx *ctx, void *p);
 int dt_dev_h2d(dt_ctx *ctx, void *dst_dev, const void *src_host, int64_t bytes); /* synchronous */
 int dt_dev_d2h(dt_ctx *ctx, void *dst_host, const void *src_dev, int64_t bytes); /* synchronous */
+/* enqueue only: dt_ctx_sync before the host reads dst_host (page-locked memory: dt_host_alloc) */
+int dt_dev_d2h_async(dt_ctx *ctx, void *dst_host, const void *src_dev, int64_t bytes);
 int dt_dev_synth_dem(dt_ctx *ctx, uint32_t seed, int64_t Hg, int64_t Wg, int64_t y0, int64_t x0,
                      int64_t h, int64_t w, int nodata_pct, float *out);
 /* slope (may be NULL), fdr (may be NULL), slope_rad (may be NULL): fused 3x3 stencil.
