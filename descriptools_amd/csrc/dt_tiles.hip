@@ -166,17 +166,17 @@ __device__ __forceinline__ void dt_tile_sums_packed(uint32_t *s_word, uint8_t *s
     va[j] = vb[j] = 1u;
   }
   for (int round = 0; round < 12; round++) {
-    int any = 0;
+    uint32_t jumped = 0;  // bit j: a cell of pair j jumped this round (its pointer word changed)
 #pragma unroll
     for (int j = 0; j < CPT / 2; j++) {
       const uint32_t p = P[j];
       if (p & PT_ALIVE) {
         P[j] = (P[j] & 0xFFFF0000u) | (atomicAdd(&s_word[p & PT_IDX], min(va[j], (uint32_t)NT)) >> 16);
-        any = 1;
+        jumped |= 1u << j;
       }
       if (p & (PT_ALIVE << 16)) {
         P[j] = (P[j] & 0xFFFFu) | (atomicAdd(&s_word[(p >> 16) & PT_IDX], min(vb[j], (uint32_t)NT)) & 0xFFFF0000u);
-        any = 1;
+        jumped |= 1u << j;
       }
     }
     __syncthreads();
@@ -184,11 +184,14 @@ __device__ __forceinline__ void dt_tile_sums_packed(uint32_t *s_word, uint8_t *s
     for (int j = 0; j < CPT / 2; j++) {
       int c2 = threadIdx.x + 256 * j;
       unsigned long long r = s_word2[c2];
-      va[j] += (uint32_t)r & 0xFFFFu;
-      vb[j] += (uint32_t)(r >> 32) & 0xFFFFu;
-      s_word2[c2] = ((unsigned long long)(P[j] & 0xFFFF0000u) << 32) | (unsigned long long)(P[j] << 16);
+      const uint32_t ra = (uint32_t)r & 0xFFFFu, rb = (uint32_t)(r >> 32) & 0xFFFFu;
+      va[j] += ra;
+      vb[j] += rb;
+      // a pair that neither jumped nor received keeps its words as they are (most pairs, in the late rounds)
+      if (((jumped >> j) & 1u) | ra | rb)
+        s_word2[c2] = ((unsigned long long)(P[j] & 0xFFFF0000u) << 32) | (unsigned long long)(P[j] << 16);
     }
-    if (!__syncthreads_or(any)) break;
+    if (!__syncthreads_or((int)jumped)) break;
   }
   // still alive after 2^12 moves: the path never ends inside the tile -> in-tile cycle
 #pragma unroll
