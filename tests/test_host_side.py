@@ -1,0 +1,83 @@
+"""CPU (not gpu): host-side helpers that need no device -- the threaded float32 -> float64 container fill, and the
+placement search's logic (spacers between candidates, neighbours of a block that adds a class) against the
+allocation pattern measured on an MI355X box (profiles/r3/placement_classes.txt), with a stand-in classifier."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+
+@pytest.mark.parametrize("n", [0, 1, 1000, (1 << 22) + 12345])
+def test_threaded_f32_to_f64_equals_astype(n):
+    from descriptools_amd import _lib
+    rng = np.random.default_rng(n)
+    a = (rng.standard_normal(n) * 1e3).astype(np.float32)
+    if n > 10:
+        a[:4] = [np.nan, np.inf, -np.inf, -100.0]
+    out = np.full(n, 7.0, np.float64)
+    _lib.check(_lib.lib().dt_host_f32_to_f64(a.ctypes.data_as(C.POINTER(C.c_float)),
+                                             out.ctypes.data_as(C.POINTER(C.c_double)), n))
+    assert np.array_equal(out, a.astype(np.float64), equal_nan=True)
+
+
+PATTERN = ("ABBAABBBBBBBBBBBBAAAAAAAABBBBBBBBBBBBBBBBCCCCCCCCCCCCCCCCAAAAAAAAAAAAAAAABBBBBBBBBBBBBBBBBBBBBBBBBBBBBBBBAAAAAAAAAAAAAAA"
+           * 2)  # 1-GiB allocations of one process in order, by conflict class
+
+
+class _ByPosition:
+    """the class of a block is the pattern's letter at its position in allocation order (pointer = position)"""
+
+    def __init__(self, ctx, nbytes):
+        self.reps, self.single_ms, self.names = [], 0.167, {}
+
+    def usable(self):
+        return True
+
+    def label(self, p):
+        c = PATTERN[int(p)]
+        if c not in self.names:
+            self.names[c] = len(self.names)
+            self.reps.append(int(p))
+        return self.names[c]
+
+
+@pytest.mark.parametrize("start", [0, 5, 17, 25, 41, 57, 73, 80, 100])
+def test_placement_search_finds_other_classes_behind_long_runs(monkeypatch, start):
+    from descriptools_amd import chain, placement
+    monkeypatch.setattr(placement, "WriteClassifier", _ByPosition)
+    pos = [start + 12]
+    released, spacers = [], []
+
+    def extra_alloc():
+        pos[0] += 1
+        return pos[0] - 1
+
+    def spacer_alloc(nbytes):
+        h = (pos[0], nbytes >> 30)
+        pos[0] += nbytes >> 30
+        spacers.append(h)
+        return h
+    groups = [list(g) for g in chain.WRITE_GROUPS]
+    roles, info = placement.assign(None, 1 << 30, list(range(start, start + 12)), groups, extra_alloc, released.append,
+                                   spacer_alloc=spacer_alloc, spacer_release=spacers.remove)
+    assert not spacers, "every spacer is released"
+    assert len(set(roles.values())) == sum(len(g) for g in groups)           # one block per role, no block twice
+    assert not (set(released) & set(roles.values()))                          # nothing kept is released
+    assert info["tuned"] and info["candidates_tried"] <= 24 and info["spacer_GiB"] <= 160
+    # what the search is for: no group of rasters written together sits in one class
+    for g in groups:
+        if len(g) > 1:
+            assert len({info["classes"][r] for r in g}) >= 2, (start, g, info)
+
+
+def test_placement_search_without_spacers_is_the_old_back_to_back_search(monkeypatch):
+    from descriptools_amd import chain, placement
+    monkeypatch.setattr(placement, "WriteClassifier", _ByPosition)
+    pos = [73 + 12]
+
+    def extra_alloc():
+        pos[0] += 1
+        return pos[0] - 1
+    roles, info = placement.assign(None, 1 << 30, list(range(73, 85)), [list(g) for g in chain.WRITE_GROUPS], extra_alloc,
+                                   lambda q: None, budget=16)
+    assert info["spacer_GiB"] == 0 and info["candidates_tried"] == 16 and info["n_classes"] == 1  # the run is 32 long
