@@ -77,5 +77,9 @@ def bench(name, dem, px):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:  # python tools/condition_bench.py N: the rough DEM at N x N only
+        n = int(sys.argv[1])
+        bench("rough synthetic DEM", rough(n), 10.0)
+        sys.exit(0)
     bench("Example DEM", example(), 12.5)
     bench("rough synthetic DEM", rough(4096), 10.0)
