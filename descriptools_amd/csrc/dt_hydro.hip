@@ -56,12 +56,28 @@ __global__ __launch_bounds__(256) void k_fill_init(const float *__restrict__ dem
 // stage the tile's 66 x 66 window of `src` into LDS; cells outside the raster read as `outside`
 template <typename T>
 __device__ __forceinline__ void hy_stage(T *s, const T *__restrict__ src, const DtWin &w, int y0, int x0, T outside) {
-  for (int i = threadIdx.x; i < HLD * HLD; i += 256) {
-    int r = i / HLD, c = i - r * HLD;
-    int y = y0 - 1 + r, x = x0 - 1 + c;
-    // inside the global raster and in this rank's memory (its core or its halo); a tile of a ragged last row / column
-    // reaches beyond the core into the halo, which is fine: those cells are read, never written
-    s[i] = dt_readable(w, y, x) ? src[(long long)y * w.ld + x] : outside;
+  // all of a thread's (up to 18) loads are issued before the first is used: one memory round trip per staging, not
+  // eighteen (the loop form waited for each load before it computed the next address)
+  constexpr int N = (HLD * HLD + 255) / 256;
+  T v[N];
+  // block-uniform: the whole 66 x 66 window is readable (inside the global raster and in this rank's memory)
+  const bool all_in = dt_readable(w, y0 - 1, x0 - 1) && dt_readable(w, y0 + HT, x0 + HT);
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    const int i = threadIdx.x + 256 * k;
+    v[k] = outside;
+    if (i < HLD * HLD) {
+      const int r = i / HLD, c = i - r * HLD;
+      const int y = y0 - 1 + r, x = x0 - 1 + c;
+      // inside the global raster and in this rank's memory (its core or its halo); a tile of a ragged last row /
+      // column reaches beyond the core into the halo, which is fine: those cells are read, never written
+      if (all_in || dt_readable(w, y, x)) v[k] = src[(long long)y * w.ld + x];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    const int i = threadIdx.x + 256 * k;
+    if (i < HLD * HLD) s[i] = v[k];
   }
 }
 
