@@ -78,6 +78,8 @@ _SIGS = {
     "dt_dev_gfi": (ci, [vp, vp, vp, i64, f64, f64, f64, vp]),
     "dt_dev_lnhlh": (ci, [vp, vp, vp, i64, f64, f64, f64, vp]),
     "dt_dev_downslope": (ci, [vp, vp, vp, i64, i64, f64, f64, ci, vp]),
+    "dt_downslope_lift_workspace": (i64, [i64, i64]),
+    "dt_dev_downslope_lift": (ci, [vp, vp, vp, i64, i64, f64, f64, ci, vp, vp, i64]),
     "dt_dev_confusion_multi": (ci, [vp, vp, vp, i64, f64, c_f64p, ci, ci, vp]),
     "dt_perim_cells": (i64, [i64, i64]),
     "dt_dev_slope_d8_w": (ci, [vp, vp, vp, f64, vp, vp, vp]),

@@ -46,7 +46,7 @@ class Chain:
 
     def __init__(self, H, W, ctx=None, px=10.0, n_top=0.1, n_gfi=0.4, b=0.1, dz=5.0,
                  river_threshold=None, alloc=None, want_slope_rad=True, side_ctx=None, overlap=True,
-                 condition=False, condition_rounds=64, tune_placement=True, release=None):
+                 condition=False, condition_rounds=64, tune_placement=True, release=None, long_walks=False):
         """overlap (the default): downslope and the slope + TI + MTI stencil run as a second branch on their own stream
         (side_ctx, created on demand) beside the flow-accumulation / HAND kernels: ~3 % faster end to end at 16384^2.  overlap=False: one stream, kernels back to back (what per-kernel timings need:
         ops(serial=True) gives that order on a chain built either way).
@@ -55,6 +55,11 @@ class Chain:
         flats; the descriptors themselves keep using the DEM as given (as the reference's example does with a D8
         raster from a GIS tool, Example/example.py:36).  Nothing synchronises: `condition_rounds` fill / flat rounds
         are enqueued, and check_status() raises afterwards if that budget was too small for the raster."""
+        # long_walks: downslope with the long-walk workspace (dt_dev_downslope_lift, 40 B/cell): for real, conditioned
+        # terrain, whose flats and valley floors make walks thousands of moves long (the bundled Example: 9.5 -> under
+        # 1 ms); the synthetic benchmark terrain has no such walks and runs without it
+        self.long_walks = bool(long_walks)
+        self._lift = None
         self.condition, self.condition_rounds = bool(condition), int(condition_rounds)
         self._alloc, self._release = alloc, release
         self.want_slope_rad = want_slope_rad
@@ -125,6 +130,12 @@ class Chain:
                 b.dtype = np.dtype(dts[name])  # a block is just memory: it takes the dtype of the role it serves
             self.buf[name] = b
 
+    def _lift_ptr(self):
+        if self._lift is None:
+            self._lift_bytes = int(_lib.lib().dt_downslope_lift_workspace(self.H, self.W))
+            self._lift = self.ctx.empty((self._lift_bytes,), np.uint8)
+        return self._lift.ptr
+
     def p(self, name):
         b = self.buf[name]
         return b.ptr if hasattr(b, "ptr") else b
@@ -147,8 +158,10 @@ class Chain:
                                                                              p("fdr"), self.condition_rounds))
         return [
             first,
-            ("downslope", side, lambda: L.dt_dev_downslope(side.h, dem_ptr, p("fdr"), H, W, self.px, self.dz, 0,
-                                                           p("down"))),
+            ("downslope", side, (lambda: L.dt_dev_downslope_lift(side.h, dem_ptr, p("fdr"), H, W, self.px, self.dz, 0,
+                                                                  p("down"), self._lift_ptr(), self._lift_bytes))
+             if self.long_walks else
+             (lambda: L.dt_dev_downslope(side.h, dem_ptr, p("fdr"), H, W, self.px, self.dz, 0, p("down")))),
             ("flowacc_flowhand_local", c, lambda: L.dt_dev_flowacc_river_flowhand_local(
                 c.h, p("fdr"), dem_ptr, H, W, self.river_threshold, p("fac"), p("river"))),
             ("slope_twi", side, lambda: L.dt_dev_slope_twi(side.h, dem_ptr, p("fac"), H, W, self.px, self.n_top,
@@ -216,6 +229,9 @@ class Chain:
             if hasattr(b, "free"):
                 b.free()
         self.buf = {}
+        if self._lift is not None:
+            self._lift.free()
+            self._lift = None
 
 
 class Graph:

@@ -607,6 +607,23 @@ extern "C" int dt_dev_downslope(dt_ctx *c, const float *dem, const uint8_t *fdr,
   return DT_OK;
 }
 
+extern "C" int64_t dt_downslope_lift_workspace(int64_t H, int64_t W) {
+  return (H <= 0 || W <= 0) ? 0 : (int64_t)dt_downslope_lift_bytes(H, W);
+}
+// dt_dev_downslope with the long-walk acceleration (dt_kernels.hip, DsQueue): `work` = dt_downslope_lift_workspace
+// bytes of device memory, the caller's for the duration of the call's kernels
+extern "C" int dt_dev_downslope_lift(dt_ctx *c, const float *dem, const uint8_t *fdr, int64_t H, int64_t W, double px,
+                                     double dz, int raw, float *out, void *work, int64_t work_bytes) {
+  DT_CTX(c);
+  DT_TRY(dt_check_hw(H, W));
+  DT_REQUIRE((dem && fdr && out) || H * W == 0, "NULL raster");
+  DT_REQUIRE(work != nullptr && work_bytes >= dt_downslope_lift_workspace(H, W), "downslope workspace missing or too small");
+  DT_TRY(dt_launch_downslope(c->stream, dt_full_window(H, W), dem, fdr, px, dz, raw, out, nullptr, work,
+                             (size_t)work_bytes));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+
 extern "C" int dt_dev_confusion_multi(dt_ctx *c, const double *desc, const int8_t *flood, int64_t N,
                                       double nodata_value, const double *th_host, int nth, int under,
                                       int64_t *counts4_dev) {
@@ -1402,13 +1419,21 @@ extern "C" int dt_downslope(const float *dem, const uint8_t *fdr, int64_t H, int
   size_t n = (size_t)H * W;
   if (n == 0) return DT_OK;
   DT_REQUIRE(dem && fdr && out, "NULL raster");
-  DevBuf d_dem, d_f, d_o;
+  DevBuf d_dem, d_f, d_o, d_w;
   DT_TRY(d_dem.alloc(n * 4));
   DT_TRY(d_f.alloc(n));
   DT_TRY(d_o.alloc(n * 4));
   H2D(d_dem, dem, n * 4, c);
   H2D(d_f, fdr, n, c);
-  DT_TRY(dt_dev_downslope(c, d_dem.as<float>(), d_f.as<uint8_t>(), H, W, px, dz, raw, d_o.as<float>()));
+  // with the long-walk workspace when the device has room for it (real, conditioned rasters walk thousands of moves
+  // through flats and along valley floors); the plain kernel otherwise
+  const size_t lift = dt_flow_impl() == 1 ? 0 : (size_t)dt_downslope_lift_workspace(H, W);
+  if (lift && d_w.alloc(lift) == DT_OK) {
+    DT_TRY(dt_dev_downslope_lift(c, d_dem.as<float>(), d_f.as<uint8_t>(), H, W, px, dz, raw, d_o.as<float>(), d_w.p,
+                                 (int64_t)lift));
+  } else {
+    DT_TRY(dt_dev_downslope(c, d_dem.as<float>(), d_f.as<uint8_t>(), H, W, px, dz, raw, d_o.as<float>()));
+  }
   D2H(out, d_o, n * 4, c);
   return dt_ctx_sync(c);
 }

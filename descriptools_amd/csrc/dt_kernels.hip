@@ -498,6 +498,30 @@ __global__ __launch_bounds__(256) void k_downslope(const float *__restrict__ dem
   if (raw && failed) out[i] = -50.0f;
   else out[i] = dist == 0.0 ? 0.0f : (float)((double)drop / dist);
 }
+// Long walks.  On real, conditioned terrain (the bundled Example with its GIS D8 raster: 9.5 ms for 1.6 M valid cells,
+// against 2.1 ms for the 268 M cells of the synthetic benchmark DEM) the cells of flats and valley floors walk
+// thousands of moves before the elevation has dropped by dz, far outside the LDS window, one dependent global load per
+// move -- and the kernel lasts as long as its longest walk.  With a workspace (dt_downslope_lift_bytes) such walks
+// are queued after DS_Q_MOVES global moves and finished by k_ds_finish with a SKIP TABLE: for every cell, where the
+// walk stands 64 moves on (or where it cannot go on), how many of those moves are diagonal, and the lowest height on
+// the way -- built by six rounds of pointer doubling, only when the queue holds at least DS_LIFT_MIN walks.  A skip is
+// taken when no cell of it can end the walk: the lowest height still leaves the drop below dz (the float32
+// subtraction is monotone in the height, so the test on the minimum is exact), no move of it fails, and the 5000-move
+// cap is not reached within it; the moves that remain (< 64 + 64) are made one by one by the code above, so every
+// exit of the reference's walk keeps its exact meaning.
+#define DS_Q_MOVES 32u
+#define DS_LIFT_MIN 256u
+#define DS_LIFT_LOG 6
+struct DsQueue {
+  uint4 *entries;     // {start cell, cell the walk stands on (both y * W + x), moves made, diagonal moves}
+  uint32_t *count;    // walks queued (may exceed capacity: the excess stayed in the main kernel)
+  uint32_t capacity;
+  __host__ __device__ DsQueue() : entries(nullptr), count(nullptr), capacity(0) {}
+};
+// skip-table entry: x = cell reached, y = float bits of the lowest height on the way (-inf for a NaN height),
+// z = moves | diagonal moves << 16, w = 1 when the walk cannot go on from the cell reached
+#define DS_LIFT_STOP 1u
+
 // What one cell's fast walk in the LDS window hands over, turned into the stored value.  drop: z0 - z(cell the walk stands on) (+inf: it stepped onto nodata); loop / nd: moves
 // made / diagonal ones; stop_fail: the walk stopped on a cell that cannot be left (non-D8 code, move off the raster);
 // (y, x): rank coordinates of the cell it stands on.
@@ -505,7 +529,7 @@ __device__ __forceinline__ void ds_finish_cell(const DtWin &w, const float *__re
                                                const uint8_t *__restrict__ fdr, int y0, int x0, float z0, float drop,
                                                uint32_t loop, uint32_t nd, bool stop_fail, int y, int x, double dcard,
                                                double ddiag, double dz, float dzf, int raw, float *__restrict__ outp,
-                                               int *__restrict__ n_unresolved) {
+                                               int *__restrict__ n_unresolved, DsQueue q = DsQueue()) {
   bool failed = false, slow = false, unresolved = false;
   bool cont = false;  // continue on global memory from the cell the fast walk stopped on
   if (drop < dzf) {
@@ -521,8 +545,20 @@ __device__ __forceinline__ void ds_finish_cell(const DtWin &w, const float *__re
     // The few walks that reach the window ring (0.006 % of the cells of the 16384^2 DEM, but one in seven
     // windows has one) go on from where they are, still only counting moves: a handful of global loads
     // instead of the whole walk again.
+    uint32_t budget = q.entries ? DS_Q_MOVES : 0xFFFFFFFFu;  // global moves before the walk is handed to the queue
     while ((double)drop < dz) {
       if (!dt_readable(w, y, x)) { unresolved = true; break; }  // beyond this rank's halo
+      if (budget-- == 0u) {
+        // A LONG walk (a flat, a valley floor: real conditioned terrain has walks of thousands of moves, each a
+        // dependent global load here): handed to k_ds_finish, which crosses it in skips of 64 moves.  A full queue
+        // keeps the walk here.
+        const uint32_t slot = atomicAdd(q.count, 1u);
+        if (slot < q.capacity) {
+          q.entries[slot] = make_uint4((uint32_t)((long long)y0 * w.W + x0), (uint32_t)((long long)y * w.W + x), loop, nd);
+          return;
+        }
+        budget = 0xFFFFFFFFu;
+      }
       uint32_t code = fdr[(long long)y * w.ld + x];
       if (!dt_d8_valid(code)) { failed = true; break; }
       int dy, dx;
@@ -626,12 +662,12 @@ __device__ __forceinline__ void ds_finish_cell(const DtWin &w, const float *__re
 #define MW_RING 0x2000u
 #define MW_STOP 0x8000u
 
-template <int DW_M>
-__global__ __launch_bounds__(1024, 8) void k_downslope_win(const float *__restrict__ dem,
+template <int DW_M, bool QUEUE>
+__device__ __forceinline__ void ds_win_body(const float *__restrict__ dem,
                                                        const uint8_t *__restrict__ fdr, DtWin w,
                                                        double px, double dz, float dzf, int raw,
                                                        float *__restrict__ out, int tiles_x, int ntiles,
-                                                       int *__restrict__ n_unresolved) {
+                                                       int *__restrict__ n_unresolved, DsQueue queue) {
   constexpr int DW_WIN = DW_CORE + 2 * DW_M, DW_LD = DW_WIN + 4;
   // one LDS block: heights at byte 0, move words at byte DW_LD*DW_WIN*4 (the walk reads both from one
   // address register)
@@ -834,12 +870,109 @@ __global__ __launch_bounds__(1024, 8) void k_downslope_win(const float *__restri
     uint32_t nd = ((acc & 0x7FFFFu) - (q2 - q2_0) - (uint32_t)MW_BIAS * loop) / MW_DIAG;
     const uint32_t pos = (q2 - lds0) >> 1;
     ds_finish_cell(w, dem, fdr, y0, x0, z0, drop, loop, nd, (mw & (MW_BADCODE | MW_EDGE)) != 0u,
-                   wy0 + (int)(pos / DW_LD), wx0 + (int)(pos % DW_LD), dcard, ddiag, dz, dzf, raw, out + o, n_unresolved);
+                   wy0 + (int)(pos / DW_LD), wx0 + (int)(pos % DW_LD), dcard, ddiag, dz, dzf, raw, out + o, n_unresolved,
+                   QUEUE ? queue : DsQueue());  // without a queue the code of the hand-over is not even compiled in
   }
 }
 
+template <int DW_M>
+__global__ __launch_bounds__(1024, 8) void k_downslope_win(const float *__restrict__ dem,
+                                                       const uint8_t *__restrict__ fdr, DtWin w, double px, double dz,
+                                                       float dzf, int raw, float *__restrict__ out, int tiles_x,
+                                                       int ntiles, int *__restrict__ n_unresolved) {
+  ds_win_body<DW_M, false>(dem, fdr, w, px, dz, dzf, raw, out, tiles_x, ntiles, n_unresolved, DsQueue());
+}
+// the same with the hand-over of long walks to the queue (a kernel of its own: the plain one keeps its registers)
+__global__ __launch_bounds__(1024, 8) void k_downslope_win_q(const float *__restrict__ dem,
+                                                         const uint8_t *__restrict__ fdr, DtWin w, double px,
+                                                         double dz, float dzf, int raw, float *__restrict__ out,
+                                                         int tiles_x, int ntiles, int *__restrict__ n_unresolved,
+                                                         DsQueue queue) {
+  ds_win_body<24, true>(dem, fdr, w, px, dz, dzf, raw, out, tiles_x, ntiles, n_unresolved, queue);
+}
+
+// ---- skip table ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float ds_lift_z(float z) { return z != z ? -__builtin_inff() : z; }  // a NaN height ends a walk
+// one move from every cell (single raster: w is the full window)
+__global__ __launch_bounds__(256) void k_ds_lift_init(const float *__restrict__ dem, const uint8_t *__restrict__ fdr,
+                                                     DtWin w, uint4 *__restrict__ T, const uint32_t *__restrict__ qcount) {
+  if (*qcount < DS_LIFT_MIN) return;
+  const long long n = (long long)w.H * w.W;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int y = (int)(i / w.W), x = (int)(i - (long long)y * w.W);
+  uint4 e = make_uint4((uint32_t)i, __float_as_uint(__builtin_inff()), 0u, DS_LIFT_STOP);
+  const uint32_t code = fdr[i];
+  if (dt_d8_valid(code)) {
+    int dy, dx;
+    dt_d8_delta(code, dy, dx);
+    const int ny = y + dy, nx = x + dx;
+    if (ny >= 0 && ny < w.H && nx >= 0 && nx < w.W) {
+      const float zt = dem[(long long)ny * w.W + nx];
+      if (zt != DT_NODATA)
+        e = make_uint4((uint32_t)((long long)ny * w.W + nx), __float_as_uint(ds_lift_z(zt)),
+                       1u | ((dy != 0 && dx != 0) ? 0x10000u : 0u), 0u);
+    }
+  }
+  T[i] = e;
+}
+// skips of 2 L moves from skips of L
+__global__ __launch_bounds__(256) void k_ds_lift_double(const uint4 *__restrict__ A, uint4 *__restrict__ B, long long n,
+                                                       const uint32_t *__restrict__ qcount) {
+  if (*qcount < DS_LIFT_MIN) return;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint4 a = A[i];
+  if (!(a.w & DS_LIFT_STOP)) {
+    const uint4 b = A[a.x];
+    a.x = b.x;
+    a.y = __float_as_uint(fminf(__uint_as_float(a.y), __uint_as_float(b.y)));
+    a.z += b.z;  // moves and diagonal moves, two 16-bit fields (<= 64 each)
+    a.w = b.w;
+  }
+  B[i] = a;
+}
+// the queued walks: skips while no cell of a skip can end the walk, then the moves that remain, one by one
+__global__ __launch_bounds__(256) void k_ds_finish(const float *__restrict__ dem, const uint8_t *__restrict__ fdr, DtWin w,
+                                                  double px, double dz, float dzf, int raw, float *__restrict__ out,
+                                                  DsQueue queue, const uint4 *__restrict__ T,
+                                                  int *__restrict__ n_unresolved) {
+  const uint32_t total = min(*queue.count, queue.capacity);
+  const bool lifted = T != nullptr && *queue.count >= DS_LIFT_MIN;
+  const double dcard = px, ddiag = px * sqrt(2.0);
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const uint4 e = queue.entries[i];
+    const int y0 = (int)(e.x / (uint32_t)w.W), x0 = (int)(e.x - (uint32_t)y0 * (uint32_t)w.W);
+    const float z0 = dem[e.x];
+    uint32_t pos = e.y, loop = e.z, nd = e.w;
+    if (lifted) {
+      for (;;) {
+        const uint4 t = T[pos];
+        const uint32_t len = t.z & 0xFFFFu;
+        // every cell of the skip leaves the drop below dz (the lowest one does), and the cap is beyond it
+        if (len == 0u || !(z0 - __uint_as_float(t.y) < dzf) || loop + len > 4999u) break;
+        pos = t.x;
+        loop += len;
+        nd += t.z >> 16;
+      }
+    }
+    const int y = (int)(pos / (uint32_t)w.W), x = (int)(pos - (uint32_t)y * (uint32_t)w.W);
+    const float drop = z0 - dem[pos];
+    ds_finish_cell(w, dem, fdr, y0, x0, z0, drop, loop, nd, false, y, x, dcard, ddiag, dz, dzf, raw, out + e.x,
+                   n_unresolved);
+  }
+}
+
+// workspace of the long-walk acceleration for an H x W raster: counter | queue (one entry per two cells) | two
+// skip tables
+static size_t ds_queue_capacity(int64_t H, int64_t W) { return (size_t)((H * W + 1) / 2); }
+size_t dt_downslope_lift_bytes(int64_t H, int64_t W) {
+  return 256 + dt_align256(ds_queue_capacity(H, W) * 16) + 2 * dt_align256((size_t)H * W * 16);
+}
+// lift (optional, dt_downslope_lift_bytes; single rasters only -- a rank window's walks leave its memory): long walks
+// are queued and finished with a skip table (see DsQueue)
 int dt_launch_downslope(hipStream_t s, const DtWin &w, const float *dem, const uint8_t *fdr, double px,
-                        double dz, int raw, float *out, int *n_unresolved) {
+                        double dz, int raw, float *out, int *n_unresolved, void *lift, size_t lift_bytes) {
   const int64_t H = w.H, W = w.W;
   int64_t n = H * W;
   if (n == 0) return DT_OK;
@@ -848,17 +981,44 @@ int dt_launch_downslope(hipStream_t s, const DtWin &w, const float *dem, const u
   // (double)drop < dz  <=>  drop < dzf with dzf the smallest float >= dz
   float dzf = (float)dz;
   if ((double)dzf < dz) dzf = nextafterf(dzf, INFINITY);
+  DsQueue q;
+  uint4 *tab[2] = {nullptr, nullptr};
+  const bool single = w.halo == 0 && w.gy0 == 0 && w.gx0 == 0 && w.Hg == w.H && w.Wg == w.W && w.ld == w.W;
+  if (lift && single && n < 0x7FFFFFFFll) {
+    DT_REQUIRE(lift_bytes >= dt_downslope_lift_bytes(H, W), "downslope workspace too small");
+    q.count = (uint32_t *)lift;
+    q.entries = (uint4 *)((char *)lift + 256);
+    q.capacity = (uint32_t)ds_queue_capacity(H, W);
+    tab[0] = (uint4 *)((char *)lift + 256 + dt_align256((size_t)q.capacity * 16));
+    tab[1] = (uint4 *)((char *)tab[0] + dt_align256((size_t)n * 16));
+    DT_HIP(hipMemsetAsync(q.count, 0, sizeof(uint32_t), s));
+  }
   // margin of the LDS window around the 64 x 64 core: walks that reach the window's ring carry on in global memory
   const int m = dt_debug_get(DT_DBG_DS_MARGIN);
+  if (m == 16 || m == 20) q = DsQueue();  // the A/B margins run without the queue
   if (m == 16)
     hipLaunchKernelGGL(k_downslope_win<16>, dim3((unsigned)ntiles), dim3(1024), 0, s, dem, fdr, w, px, dz, dzf, raw,
                        out, tiles_x, (int)ntiles, n_unresolved);
   else if (m == 20)
     hipLaunchKernelGGL(k_downslope_win<20>, dim3((unsigned)ntiles), dim3(1024), 0, s, dem, fdr, w, px, dz, dzf, raw,
                        out, tiles_x, (int)ntiles, n_unresolved);
+  else if (q.entries)
+    hipLaunchKernelGGL(k_downslope_win_q, dim3((unsigned)ntiles), dim3(1024), 0, s, dem, fdr, w, px, dz, dzf, raw, out,
+                       tiles_x, (int)ntiles, n_unresolved, q);
   else
     hipLaunchKernelGGL(k_downslope_win<24>, dim3((unsigned)ntiles), dim3(1024), 0, s, dem, fdr, w, px, dz, dzf, raw,
                        out, tiles_x, (int)ntiles, n_unresolved);
+  if (q.entries) {
+    // every kernel of the table returns at once when fewer than DS_LIFT_MIN walks were queued
+    const dim3 gn((unsigned)((n + 255) / 256)), b(256);
+    hipLaunchKernelGGL(k_ds_lift_init, gn, b, 0, s, dem, fdr, w, tab[0], (const uint32_t *)q.count);
+    for (int k = 0; k < DS_LIFT_LOG; k++)
+      hipLaunchKernelGGL(k_ds_lift_double, gn, b, 0, s, (const uint4 *)tab[k & 1], tab[(k + 1) & 1], (long long)n,
+                         (const uint32_t *)q.count);
+    const unsigned fin_blocks = (unsigned)std::min<size_t>((q.capacity + 255) / 256, 8192);
+    hipLaunchKernelGGL(k_ds_finish, dim3(fin_blocks), b, 0, s, dem, fdr, w, px, dz, dzf, raw, out, q,
+                       (const uint4 *)tab[DS_LIFT_LOG & 1], n_unresolved);
+  }
   return DT_OK;
 }
 int dt_launch_downslope_v1(hipStream_t s, const float *dem, const uint8_t *fdr, int64_t H, int64_t W,

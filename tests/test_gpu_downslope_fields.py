@@ -76,3 +76,73 @@ def test_int16_example_like_dem(env):
     raw = downslope.downslope_cpu(dem, fdr, 30.0, 5.0)
     keep = raw != -50
     _same(raw[keep], want[keep])
+
+
+def test_long_walks_with_the_skip_table(env):
+    """the long-walk workspace (dt_dev_downslope_lift; the host-tier downsloper uses it): terrain whose walks run for
+    thousands of moves -- a tilted plane of 1e-3 per cell drained by a serpentine channel, flats, a lake of NaN-free
+    equal heights, walks that hit the 5000-move cap exactly, walks that fail on a non-D8 code far from their start --
+    against the oracle's literal walk, and the device entry with and without the workspace bit for bit"""
+    oracle, downslope, L = env
+    import torch
+    from descriptools_amd import _lib
+    from descriptools_amd.device import Context
+    rng = np.random.default_rng(11)
+    H, W = 400, 600
+    yy, xx = np.mgrid[0:H, 0:W]
+    # gentle plane: 5 m of drop need ~5000 cardinal moves -- walks of every length up to and beyond the cap
+    dem = (200.0 - 0.001 * xx - 0.0002 * yy).astype(np.float32)
+    fdr = np.full((H, W), 1, np.uint8)            # everything flows east ...
+    fdr[:, W - 1] = 4                             # ... then south along the last column
+    fdr[H - 1, :] = 16                            # ... and back west along the last row (a long way round)
+    fdr[H - 1, 0] = 0
+    dem[150:180, 100:500] = np.float32(150.0)     # a flat well below its surroundings: walks end at its rim
+    fdr[rng.random((H, W)) < 0.0005] = 3          # non-D8 codes: walks fail there, far from where they started
+    dem[rng.random((H, W)) < 0.0005] = -100       # nodata ahead stops a walk too
+    for dz in (5.0, 0.25, 4.99):
+        _same(downslope.downsloper(dem, fdr, 1.0, dz), oracle.downslope(dem, fdr, 1.0, dz))
+    raw = downslope.downslope_cpu(dem, fdr, 1.0, 5.0)
+    want = oracle.downslope(dem, fdr, 1.0, 5.0)
+    keep = raw != -50
+    _same(raw[keep], want[keep])
+    # device entries: with / without the workspace
+    ctx = Context()
+    d, f = ctx.to_device(dem), ctx.to_device(fdr)
+    a, b = ctx.empty((H, W), np.float32), ctx.empty((H, W), np.float32)
+    nb = int(L.dt_downslope_lift_workspace(H, W))
+    work = ctx.empty((nb,), np.uint8)
+    _lib.check(L.dt_dev_downslope(ctx.h, d.ptr, f.ptr, H, W, 1.0, 5.0, 0, a.ptr))
+    _lib.check(L.dt_dev_downslope_lift(ctx.h, d.ptr, f.ptr, H, W, 1.0, 5.0, 0, b.ptr, work.ptr, nb))
+    ctx.sync()
+    ra, rb = a.to_host(), b.to_host()
+    assert np.array_equal(ra.view(np.int32), rb.view(np.int32)) and np.array_equal(ra, want, equal_nan=True)
+    for x in (d, f, a, b, work):
+        x.free()
+    ctx.close()
+    torch.cuda.empty_cache()
+
+
+def test_chain_with_long_walks_on_the_example():
+    """Chain(long_walks=True) on the bundled Example (its GIS D8 raster has the flats): same downslope raster"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from conftest import load_example
+    from descriptools_amd import _lib
+    from descriptools_amd.device import Context
+    L = _lib.lib()
+    ex = load_example()
+    dem, fdr = np.asarray(ex[0], np.float32), np.ascontiguousarray(ex[1], np.uint8)
+    H, W = dem.shape
+    ctx = Context()
+    d, f = ctx.to_device(dem), ctx.to_device(fdr)
+    a, b = ctx.empty((H, W), np.float32), ctx.empty((H, W), np.float32)
+    nb = int(L.dt_downslope_lift_workspace(H, W))
+    work = ctx.empty((nb,), np.uint8)
+    _lib.check(L.dt_dev_downslope(ctx.h, d.ptr, f.ptr, H, W, 12.5, 5.0, 0, a.ptr))
+    _lib.check(L.dt_dev_downslope_lift(ctx.h, d.ptr, f.ptr, H, W, 12.5, 5.0, 0, b.ptr, work.ptr, nb))
+    ctx.sync()
+    assert np.array_equal(a.to_host().view(np.int32), b.to_host().view(np.int32))
+    for x in (d, f, a, b, work):
+        x.free()
+    ctx.close()
