@@ -504,13 +504,14 @@ __global__ __launch_bounds__(256) void k_downslope(const float *__restrict__ dem
 // move -- and the kernel lasts as long as its longest walk.  With a workspace (dt_downslope_lift_bytes) such walks
 // are queued after DS_Q_MOVES global moves and finished by k_ds_finish with a SKIP TABLE: for every cell, where the
 // walk stands 64 moves on (or where it cannot go on), how many of those moves are diagonal, and the lowest height on
-// the way -- built by six rounds of pointer doubling, only when the queue holds at least DS_LIFT_MIN walks.  A skip is
+// the way -- built by six rounds of pointer doubling, only when the queue holds at least DS_LIFT_MIN walks and one
+// cell in 128 (fewer are walked out move by move by k_ds_finish: the table costs a pass over the raster).  A skip is
 // taken when no cell of it can end the walk: the lowest height still leaves the drop below dz (the float32
 // subtraction is monotone in the height, so the test on the minimum is exact), no move of it fails, and the 5000-move
 // cap is not reached within it; the moves that remain (< 64 + 64) are made one by one by the code above, so every
 // exit of the reference's walk keeps its exact meaning.
 #define DS_Q_MOVES 32u
-#define DS_LIFT_MIN 256u
+#define DS_LIFT_MIN 256u /* and at least one cell in 128: the table costs ~340 bytes of traffic per CELL of the raster */
 #define DS_LIFT_LOG 6
 struct DsQueue {
   uint4 *entries;     // {start cell, cell the walk stands on (both y * W + x), moves made, diagonal moves}
@@ -895,8 +896,8 @@ __global__ __launch_bounds__(1024, 8) void k_downslope_win_q(const float *__rest
 __device__ __forceinline__ float ds_lift_z(float z) { return z != z ? -__builtin_inff() : z; }  // a NaN height ends a walk
 // one move from every cell (single raster: w is the full window)
 __global__ __launch_bounds__(256) void k_ds_lift_init(const float *__restrict__ dem, const uint8_t *__restrict__ fdr,
-                                                     DtWin w, uint4 *__restrict__ T, const uint32_t *__restrict__ qcount) {
-  if (*qcount < DS_LIFT_MIN) return;
+                                                     DtWin w, uint4 *__restrict__ T, const uint32_t *__restrict__ qcount, uint32_t lift_min) {
+  if (*qcount < lift_min) return;
   const long long n = (long long)w.H * w.W;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
@@ -918,8 +919,8 @@ __global__ __launch_bounds__(256) void k_ds_lift_init(const float *__restrict__ 
 }
 // skips of 2 L moves from skips of L
 __global__ __launch_bounds__(256) void k_ds_lift_double(const uint4 *__restrict__ A, uint4 *__restrict__ B, long long n,
-                                                       const uint32_t *__restrict__ qcount) {
-  if (*qcount < DS_LIFT_MIN) return;
+                                                       const uint32_t *__restrict__ qcount, uint32_t lift_min) {
+  if (*qcount < lift_min) return;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   uint4 a = A[i];
@@ -936,9 +937,9 @@ __global__ __launch_bounds__(256) void k_ds_lift_double(const uint4 *__restrict_
 __global__ __launch_bounds__(256) void k_ds_finish(const float *__restrict__ dem, const uint8_t *__restrict__ fdr, DtWin w,
                                                   double px, double dz, float dzf, int raw, float *__restrict__ out,
                                                   DsQueue queue, const uint4 *__restrict__ T,
-                                                  int *__restrict__ n_unresolved) {
+                                                  int *__restrict__ n_unresolved, uint32_t lift_min) {
   const uint32_t total = min(*queue.count, queue.capacity);
-  const bool lifted = T != nullptr && *queue.count >= DS_LIFT_MIN;
+  const bool lifted = T != nullptr && *queue.count >= lift_min;
   const double dcard = px, ddiag = px * sqrt(2.0);
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
     const uint4 e = queue.entries[i];
@@ -1011,13 +1012,14 @@ int dt_launch_downslope(hipStream_t s, const DtWin &w, const float *dem, const u
   if (q.entries) {
     // every kernel of the table returns at once when fewer than DS_LIFT_MIN walks were queued
     const dim3 gn((unsigned)((n + 255) / 256)), b(256);
-    hipLaunchKernelGGL(k_ds_lift_init, gn, b, 0, s, dem, fdr, w, tab[0], (const uint32_t *)q.count);
+    const uint32_t lift_min = (uint32_t)std::max<int64_t>(DS_LIFT_MIN, n / 128);
+    hipLaunchKernelGGL(k_ds_lift_init, gn, b, 0, s, dem, fdr, w, tab[0], (const uint32_t *)q.count, lift_min);
     for (int k = 0; k < DS_LIFT_LOG; k++)
       hipLaunchKernelGGL(k_ds_lift_double, gn, b, 0, s, (const uint4 *)tab[k & 1], tab[(k + 1) & 1], (long long)n,
-                         (const uint32_t *)q.count);
+                         (const uint32_t *)q.count, lift_min);
     const unsigned fin_blocks = (unsigned)std::min<size_t>((q.capacity + 255) / 256, 8192);
     hipLaunchKernelGGL(k_ds_finish, dim3(fin_blocks), b, 0, s, dem, fdr, w, px, dz, dzf, raw, out, q,
-                       (const uint4 *)tab[DS_LIFT_LOG & 1], n_unresolved);
+                       (const uint4 *)tab[DS_LIFT_LOG & 1], n_unresolved, lift_min);
   }
   return DT_OK;
 }

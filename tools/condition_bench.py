@@ -55,7 +55,8 @@ def bench(name, dem, px):
     assert ctx.status() == 0
     times = {}
     for cond in (False, True):
-        ch = chain.Chain(H, W, ctx=ctx, px=px, condition=cond, condition_rounds=budget, tune_placement=False)
+        ch = chain.Chain(H, W, ctx=ctx, px=px, condition=cond, condition_rounds=budget, tune_placement=False,
+                         long_walks=cond)  # conditioned terrain has flats: downslope with the long-walk workspace
         for _ in range(3):
             ch.run(d_dem.ptr)
         ctx.sync()
