@@ -569,7 +569,8 @@ def end_to_end(n, seed):
     d.free()
     ctx.close()
     t4 = time.perf_counter()
-    rh = chain.run_host(dem, px, river_threshold=thr, want_slope_rad=False)  # warm pools: the steady-state call
+    rh_t = {}
+    rh = chain.run_host(dem, px, timings=rh_t, river_threshold=thr, want_slope_rad=False)  # warm pools: steady state
     t5 = time.perf_counter()
     del rh
     # (b) the reference's call sequence through the drop-in API
@@ -614,7 +615,7 @@ def end_to_end(n, seed):
         "run_host_split": {"h2d_dem_pageable_ms": round((t1 - t0) * 1e3, 1), "kernels_ms": round((t2 - t1) * 1e3, 1),
                            "d2h_11_rasters_pinned_ms": round((t3 - t2) * 1e3, 1), "d2h_GBs": round(nbytes_out / (t3 - t2) / 1e9, 1),
                            "note": "first call of the process: includes locking the host pages of the 11 outputs"},
-        "run_host": {"seconds": round(t5 - t4, 3), "Mcells_s": round(cells / (t5 - t4) / 1e6, 1),
+        "run_host": {"seconds": round(t5 - t4, 3), "Mcells_s": round(cells / (t5 - t4) / 1e6, 1), "phases": rh_t,
                      "note": "chain.run_host, numpy DEM in, 13 numpy rasters out (fac / idx widened to int64), warm "
                              "page-locked pool"},
         "dropin_api": {"seconds": round(t7 - t6, 3), "Mcells_s": round(cells / (t7 - t6) / 1e6, 1),

@@ -258,15 +258,20 @@ class Graph:
         self.chain = None
 
 
-def run_host(dem, px, **kw):
-    """Convenience: host DEM in, dict of host rasters out (fac / idx widened to int64 on the device)."""
+def run_host(dem, px, timings=None, **kw):
+    """Convenience: host DEM in, dict of host rasters out (fac / idx widened to int64 on the device).
+    timings (optional dict): filled with the seconds spent per phase (set-up, H2D, host blocks + copies, release)."""
+    import time
+    t0 = time.perf_counter()
     dem32 = _lib.dem_f32(dem)
     H, W = dem32.shape
     ctx = Context()
     kw.setdefault("tune_placement", False)  # one step: the ~0.1 s of measurement would buy 0.3 ms
     ch = Chain(H, W, ctx=ctx, px=px, **kw)
+    t1 = time.perf_counter()
     d_dem = ctx.to_device(dem32)
     wide = {k: ctx.empty((H, W), np.int64) for k in ("fac", "idx")}  # the reference's dtypes for these are int64
+    t2 = t3 = t4 = time.perf_counter()
     try:
         ch.run(d_dem.ptr)
         # rasters come back into page-locked host memory from a recycling pool (device.PinnedPool): the copies are
@@ -279,11 +284,17 @@ def run_host(dem, px, **kw):
                 out[k] = wide[k].to_host_async()
             else:
                 out[k] = ch.buf[k].to_host_async()
+        t3 = time.perf_counter()
         ctx.sync()
+        t4 = time.perf_counter()
     finally:
         d_dem.free()
         for w_ in wide.values():
             w_.free()
         ch.free()
         ctx.close()
+    if timings is not None:
+        timings.update({"setup_s": round(t1 - t0, 4), "h2d_s": round(t2 - t1, 4),
+                        "host_blocks_and_enqueue_s": round(t3 - t2, 4), "wait_for_copies_s": round(t4 - t3, 4),
+                        "release_s": round(time.perf_counter() - t4, 4)})
     return out

@@ -3,6 +3,8 @@
 #include <stdlib.h>
 
 #include <sys/mman.h>
+#include <atomic>
+#include <chrono>
 #include <mutex>
 #include <thread>
 #include <utility>
@@ -1125,6 +1127,9 @@ struct HostMap {
 static std::mutex g_hostmap_mu;
 static std::vector<std::pair<void *, HostMap>> g_hostmaps;  // registered blocks by their aligned address
 static const size_t DT_HUGE = (size_t)2 << 20;
+// Huge pages are asked for until one such block takes longer to map and touch than plain pages would (a host whose
+// memory is fragmented compacts it inside the page faults: seconds per GiB have been seen); 4 KiB pages from then on.
+static std::atomic<bool> g_host_thp{true};
 
 extern "C" int dt_host_alloc(int64_t bytes, void **out) {
   DT_REQUIRE(out && bytes >= 0, "bad arguments");
@@ -1134,7 +1139,9 @@ extern "C" int dt_host_alloc(int64_t bytes, void **out) {
     void *m = mmap(nullptr, n + DT_HUGE, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
     if (m != MAP_FAILED) {
       char *a = (char *)(((uintptr_t)m + DT_HUGE - 1) & ~(uintptr_t)(DT_HUGE - 1));
-      (void)madvise(a, n, MADV_HUGEPAGE);
+      const bool thp = g_host_thp.load();
+      if (thp) (void)madvise(a, n, MADV_HUGEPAGE);
+      const auto t_touch = std::chrono::steady_clock::now();
       unsigned hc = std::thread::hardware_concurrency();
       const int threads = (int)(hc == 0 ? 1 : (hc > 8 ? 8 : hc));
       const size_t per = ((n / (size_t)threads) + DT_HUGE - 1) & ~(DT_HUGE - 1);
@@ -1144,6 +1151,8 @@ extern "C" int dt_host_alloc(int64_t bytes, void **out) {
           for (size_t o = per * (size_t)t; o < n && o < per * (size_t)(t + 1); o += 4096) a[o] = 0;
         });
       for (auto &t : th) t.join();
+      const double touch_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_touch).count();
+      if (thp && touch_s > 0.1 * ((double)n / (double)(1ull << 30)) + 0.02) g_host_thp.store(false);
       if (hipHostRegister(a, n, hipHostRegisterPortable) == hipSuccess) {
         std::lock_guard<std::mutex> lk(g_hostmap_mu);
         g_hostmaps.push_back({(void *)a, HostMap{m, n + DT_HUGE}});

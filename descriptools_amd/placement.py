@@ -33,6 +33,7 @@ class WriteClassifier:
         self.n = n // 65536 * 65536          # the write kernel walks rows of 16384 floats in groups of 4
         self.reps = []                        # one representative pointer per class found so far
         self.single_ms = None
+        self.ratios = []                      # pair time / single-stream time of every comparison made (diagnostics)
 
     def usable(self):
         return self.n * 4 >= MIN_BYTES
@@ -58,7 +59,9 @@ class WriteClassifier:
         if self.single_ms is None:
             self.single_ms = min(self._time([ptr]), self._time([ptr]))
         for k, r in enumerate(self.reps):
-            if self._time([r, ptr]) > PAIR_CONFLICT * self.single_ms:
+            ratio = self._time([r, ptr]) / self.single_ms
+            self.ratios.append(round(ratio, 3))
+            if ratio > PAIR_CONFLICT:
                 return k
         self.reps.append(ptr)
         return len(self.reps) - 1
@@ -156,10 +159,21 @@ def assign(ctx, nbytes, blocks, groups, extra_alloc=None, extra_release=None, bu
         if spacer_release is not None:
             for h in spacers:
                 spacer_release(h)
+    # Everything in ONE class after a search over tens of GiB is more likely a bad yardstick than a property of the
+    # memory: classes are defined by conflict with a representative, and a representative that straddles two runs (the
+    # first blocks a process allocates often do) conflicts with everybody.  Label once more, starting from the other end.
+    relabelled = False
+    if len(cl.reps) == 1 and len(labels) >= 6:
+        cl2 = WriteClassifier(ctx, nbytes)
+        cl2.single_ms = cl.single_ms
+        labels2 = {b: cl2.label(b) for b in reversed(list(labels))}
+        if len(cl2.reps) > 1:
+            labels, cl, relabelled = {b: labels2[b] for b in labels}, cl2, True
     roles, left = spread(labels, groups)
     if extra_release is not None:
         for b in left:
             extra_release(b)
     classes = {r: labels[b] for r, b in roles.items()}
     return roles, {"tuned": True, "classes": classes, "candidates_tried": tried, "blocks": len(labels),
-                   "spacer_GiB": spaced >> 30, "single_stream_ms": round(cl.single_ms, 4), "n_classes": len(cl.reps)}
+                   "spacer_GiB": spaced >> 30, "single_stream_ms": round(cl.single_ms, 4), "n_classes": len(cl.reps),
+                   "relabelled": relabelled, "pair_ratio_min_max": [min(cl.ratios), max(cl.ratios)] if getattr(cl, "ratios", None) else None}

@@ -81,3 +81,42 @@ def test_placement_search_without_spacers_is_the_old_back_to_back_search(monkeyp
     roles, info = placement.assign(None, 1 << 30, list(range(73, 85)), [list(g) for g in chain.WRITE_GROUPS], extra_alloc,
                                    lambda q: None, budget=16)
     assert info["spacer_GiB"] == 0 and info["candidates_tried"] == 16 and info["n_classes"] == 1  # the run is 32 long
+
+
+class _MixedFirstBlock:
+    """conflict-based stand-in: two blocks conflict when their letters are equal -- and block 0 (a block that straddles
+    two runs) conflicts with everybody"""
+    letters = "XBBBBBBBBBBBCCCCAAAABBBBCCCCAAAAAAAA"
+
+    def __init__(self, ctx, nbytes):
+        self.reps, self.single_ms, self.ratios = [], 0.167, []
+
+    def usable(self):
+        return True
+
+    def label(self, p):
+        p = int(p)
+        for k, r in enumerate(self.reps):
+            conflict = r == 0 or p == 0 or self.letters[r] == self.letters[p]
+            self.ratios.append(2.07 if conflict else 1.8)
+            if conflict:
+                return k
+        self.reps.append(p)
+        return len(self.reps) - 1
+
+
+def test_a_representative_that_conflicts_with_everybody_is_replaced(monkeypatch):
+    from descriptools_amd import chain, placement
+    monkeypatch.setattr(placement, "WriteClassifier", _MixedFirstBlock)
+    pos = [12]
+
+    def extra_alloc():
+        pos[0] += 1
+        return pos[0] - 1
+    groups = [list(g) for g in chain.WRITE_GROUPS]
+    roles, info = placement.assign(None, 1 << 30, list(range(12)), groups, extra_alloc, lambda q: None,
+                                   spacer_alloc=None, spacer_release=None)
+    assert info["relabelled"] and info["n_classes"] >= 2
+    for g in groups:
+        if len(g) > 1:
+            assert len({info["classes"][r] for r in g}) >= 2, (g, info)
