@@ -55,7 +55,7 @@ class Chain:
         flats; the descriptors themselves keep using the DEM as given (as the reference's example does with a D8
         raster from a GIS tool, Example/example.py:36).  Nothing synchronises: `condition_rounds` fill / flat rounds
         are enqueued, and check_status() raises afterwards if that budget was too small for the raster."""
-        # long_walks: downslope with the long-walk workspace (dt_dev_downslope_lift, 40 B/cell): for real, conditioned
+        # long_walks: downslope with the long-walk workspace (dt_dev_downslope_lift, 56 B/cell): for real, conditioned
         # terrain, whose flats and valley floors make walks thousands of moves long (the bundled Example: 9.5 -> under
         # 1 ms); the synthetic benchmark terrain has no such walks and runs without it
         self.long_walks = bool(long_walks)

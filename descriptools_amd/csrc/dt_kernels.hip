@@ -502,15 +502,16 @@ __global__ __launch_bounds__(256) void k_downslope(const float *__restrict__ dem
 // against 2.1 ms for the 268 M cells of the synthetic benchmark DEM) the cells of flats and valley floors walk
 // thousands of moves before the elevation has dropped by dz, far outside the LDS window, one dependent global load per
 // move -- and the kernel lasts as long as its longest walk.  With a workspace (dt_downslope_lift_bytes) such walks
-// are queued after DS_Q_MOVES global moves and finished by k_ds_finish with a SKIP TABLE: for every cell, where the
+// are queued as soon as they leave the window and finished by k_ds_finish with a SKIP TABLE: for every cell, where the
 // walk stands 64 moves on (or where it cannot go on), how many of those moves are diagonal, and the lowest height on
 // the way -- built by six rounds of pointer doubling, only when the queue holds at least DS_LIFT_MIN walks and one
 // cell in 128 (fewer are walked out move by move by k_ds_finish: the table costs a pass over the raster).  A skip is
 // taken when no cell of it can end the walk: the lowest height still leaves the drop below dz (the float32
 // subtraction is monotone in the height, so the test on the minimum is exact), no move of it fails, and the 5000-move
-// cap is not reached within it; the moves that remain (< 64 + 64) are made one by one by the code above, so every
+// cap is not reached within it; skips of 8 moves (the table of the third round, kept) follow, and the moves that
+// remain (< 8 + 8) are made one by one by the code above, so every
 // exit of the reference's walk keeps its exact meaning.
-#define DS_Q_MOVES 32u
+#define DS_Q_MOVES 0u /* global moves a walk makes in the window kernel before it is queued (the kernel's waves wait for them) */
 #define DS_LIFT_MIN 256u /* and at least one cell in 128: the table costs ~340 bytes of traffic per CELL of the raster */
 #define DS_LIFT_LOG 6
 struct DsQueue {
@@ -547,27 +548,37 @@ __device__ __forceinline__ void ds_finish_cell(const DtWin &w, const float *__re
     // windows has one) go on from where they are, still only counting moves: a handful of global loads
     // instead of the whole walk again.
     uint32_t budget = q.entries ? DS_Q_MOVES : 0xFFFFFFFFu;  // global moves before the walk is handed to the queue
+    // the code of the cell the walk stands on is fetched together with the height of the cell before it: one memory
+    // round trip per move on the walk's dependent chain, not two
+    uint32_t code = dt_readable(w, y, x) ? (uint32_t)fdr[(long long)y * w.ld + x] : 0u;
     while ((double)drop < dz) {
       if (!dt_readable(w, y, x)) { unresolved = true; break; }  // beyond this rank's halo
       if (budget-- == 0u) {
         // A LONG walk (a flat, a valley floor: real conditioned terrain has walks of thousands of moves, each a
         // dependent global load here): handed to k_ds_finish, which crosses it in skips of 64 moves.  A full queue
         // keeps the walk here.
-        const uint32_t slot = atomicAdd(q.count, 1u);
+        // one atomic per wave: the lanes that arrive here together count themselves, the first of them reserves
+        const unsigned long long act = __ballot(1);
+        const int leader = __ffsll((long long)act) - 1, lane = (int)(threadIdx.x & 63u);
+        uint32_t base = 0u;
+        if (lane == leader) base = atomicAdd(q.count, (uint32_t)__popcll(act));
+        base = (uint32_t)__shfl((int)base, leader);
+        const uint32_t slot = base + (uint32_t)__popcll(act & ((1ull << lane) - 1ull));
         if (slot < q.capacity) {
           q.entries[slot] = make_uint4((uint32_t)((long long)y0 * w.W + x0), (uint32_t)((long long)y * w.W + x), loop, nd);
           return;
         }
         budget = 0xFFFFFFFFu;
       }
-      uint32_t code = fdr[(long long)y * w.ld + x];
       if (!dt_d8_valid(code)) { failed = true; break; }
       int dy, dx;
       dt_d8_delta(code, dy, dx);
       int ny = y + dy, nx = x + dx;
       if (!dt_in_global(w, ny, nx)) { failed = true; break; }
       if (!dt_readable(w, ny, nx)) { unresolved = true; break; }
-      float zt = dem[(long long)ny * w.ld + nx];
+      const long long on = (long long)ny * w.ld + nx;
+      float zt = dem[on];
+      code = fdr[on];
       if (zt == DT_NODATA) { failed = true; break; }
       y = ny;
       x = nx;
@@ -937,7 +948,8 @@ __global__ __launch_bounds__(256) void k_ds_lift_double(const uint4 *__restrict_
 __global__ __launch_bounds__(256) void k_ds_finish(const float *__restrict__ dem, const uint8_t *__restrict__ fdr, DtWin w,
                                                   double px, double dz, float dzf, int raw, float *__restrict__ out,
                                                   DsQueue queue, const uint4 *__restrict__ T,
-                                                  int *__restrict__ n_unresolved, uint32_t lift_min) {
+                                                  const uint4 *__restrict__ T8, int *__restrict__ n_unresolved,
+                                                  uint32_t lift_min) {
   const uint32_t total = min(*queue.count, queue.capacity);
   const bool lifted = T != nullptr && *queue.count >= lift_min;
   const double dcard = px, ddiag = px * sqrt(2.0);
@@ -947,14 +959,20 @@ __global__ __launch_bounds__(256) void k_ds_finish(const float *__restrict__ dem
     const float z0 = dem[e.x];
     uint32_t pos = e.y, loop = e.z, nd = e.w;
     if (lifted) {
-      for (;;) {
-        const uint4 t = T[pos];
-        const uint32_t len = t.z & 0xFFFFu;
-        // every cell of the skip leaves the drop below dz (the lowest one does), and the cap is beyond it
-        if (len == 0u || !(z0 - __uint_as_float(t.y) < dzf) || loop + len > 4999u) break;
-        pos = t.x;
-        loop += len;
-        nd += t.z >> 16;
+      // skips of 64 moves, then of 8 (the table of the third doubling round is kept): < 16 moves are left for the
+      // move-by-move code
+#pragma unroll
+      for (int level = 0; level < 2; level++) {
+        const uint4 *__restrict__ tab = level ? T8 : T;
+        for (;;) {
+          const uint4 t = tab[pos];
+          const uint32_t len = t.z & 0xFFFFu;
+          // every cell of the skip leaves the drop below dz (the lowest one does), and the cap is beyond it
+          if (len == 0u || !(z0 - __uint_as_float(t.y) < dzf) || loop + len > 4999u) break;
+          pos = t.x;
+          loop += len;
+          nd += t.z >> 16;
+        }
       }
     }
     const int y = (int)(pos / (uint32_t)w.W), x = (int)(pos - (uint32_t)y * (uint32_t)w.W);
@@ -968,7 +986,7 @@ __global__ __launch_bounds__(256) void k_ds_finish(const float *__restrict__ dem
 // skip tables
 static size_t ds_queue_capacity(int64_t H, int64_t W) { return (size_t)((H * W + 1) / 2); }
 size_t dt_downslope_lift_bytes(int64_t H, int64_t W) {
-  return 256 + dt_align256(ds_queue_capacity(H, W) * 16) + 2 * dt_align256((size_t)H * W * 16);
+  return 256 + dt_align256(ds_queue_capacity(H, W) * 16) + 3 * dt_align256((size_t)H * W * 16);
 }
 // lift (optional, dt_downslope_lift_bytes; single rasters only -- a rank window's walks leave its memory): long walks
 // are queued and finished with a skip table (see DsQueue)
@@ -983,7 +1001,7 @@ int dt_launch_downslope(hipStream_t s, const DtWin &w, const float *dem, const u
   float dzf = (float)dz;
   if ((double)dzf < dz) dzf = nextafterf(dzf, INFINITY);
   DsQueue q;
-  uint4 *tab[2] = {nullptr, nullptr};
+  uint4 *tab[3] = {nullptr, nullptr, nullptr};  // two ping-pong tables and the 8-move table that is kept
   const bool single = w.halo == 0 && w.gy0 == 0 && w.gx0 == 0 && w.Hg == w.H && w.Wg == w.W && w.ld == w.W;
   if (lift && single && n < 0x7FFFFFFFll) {
     DT_REQUIRE(lift_bytes >= dt_downslope_lift_bytes(H, W), "downslope workspace too small");
@@ -992,6 +1010,7 @@ int dt_launch_downslope(hipStream_t s, const DtWin &w, const float *dem, const u
     q.capacity = (uint32_t)ds_queue_capacity(H, W);
     tab[0] = (uint4 *)((char *)lift + 256 + dt_align256((size_t)q.capacity * 16));
     tab[1] = (uint4 *)((char *)tab[0] + dt_align256((size_t)n * 16));
+    tab[2] = (uint4 *)((char *)tab[1] + dt_align256((size_t)n * 16));
     DT_HIP(hipMemsetAsync(q.count, 0, sizeof(uint32_t), s));
   }
   // margin of the LDS window around the 64 x 64 core: walks that reach the window's ring carry on in global memory
@@ -1014,12 +1033,23 @@ int dt_launch_downslope(hipStream_t s, const DtWin &w, const float *dem, const u
     const dim3 gn((unsigned)((n + 255) / 256)), b(256);
     const uint32_t lift_min = (uint32_t)std::max<int64_t>(DS_LIFT_MIN, n / 128);
     hipLaunchKernelGGL(k_ds_lift_init, gn, b, 0, s, dem, fdr, w, tab[0], (const uint32_t *)q.count, lift_min);
-    for (int k = 0; k < DS_LIFT_LOG; k++)
-      hipLaunchKernelGGL(k_ds_lift_double, gn, b, 0, s, (const uint4 *)tab[k & 1], tab[(k + 1) & 1], (long long)n,
-                         (const uint32_t *)q.count, lift_min);
+    // 1 -> 2 -> 4 -> 8 (kept in tab[2]) -> 16 -> 32 -> 64 moves per skip
+    uint4 *src = tab[0], *dst = tab[1];
+    for (int k = 0; k < DS_LIFT_LOG; k++) {
+      uint4 *to = k == 2 ? tab[2] : dst;
+      hipLaunchKernelGGL(k_ds_lift_double, gn, b, 0, s, (const uint4 *)src, to, (long long)n, (const uint32_t *)q.count,
+                         lift_min);
+      if (k == 2) {
+        src = tab[2];  // the next round reads the kept table and writes a ping-pong one
+      } else {
+        uint4 *was = src;
+        src = to;
+        dst = was == tab[2] ? (to == tab[0] ? tab[1] : tab[0]) : was;
+      }
+    }
     const unsigned fin_blocks = (unsigned)std::min<size_t>((q.capacity + 255) / 256, 8192);
-    hipLaunchKernelGGL(k_ds_finish, dim3(fin_blocks), b, 0, s, dem, fdr, w, px, dz, dzf, raw, out, q,
-                       (const uint4 *)tab[DS_LIFT_LOG & 1], n_unresolved, lift_min);
+    hipLaunchKernelGGL(k_ds_finish, dim3(fin_blocks), b, 0, s, dem, fdr, w, px, dz, dzf, raw, out, q, (const uint4 *)src,
+                       (const uint4 *)tab[2], n_unresolved, lift_min);
   }
   return DT_OK;
 }

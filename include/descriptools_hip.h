@@ -260,7 +260,7 @@ int dt_dev_downslope(dt_ctx *ctx, const float *dem, const uint8_t *fdr, int64_t 
  * difference after 32 further moves are queued and finished with a skip table (64 moves per skip, built on the device
  * when at least 256 walks were queued) -- on real, conditioned terrain, where flats and valley floors make walks
  * thousands of moves long, an order of magnitude faster; same results.  `work`: dt_downslope_lift_workspace(H, W)
- * bytes of device memory (40 bytes per cell), the library's for the duration of the call's kernels. */
+ * bytes of device memory (56 bytes per cell), the library's for the duration of the call's kernels. */
 int64_t dt_downslope_lift_workspace(int64_t H, int64_t W);
 int dt_dev_downslope_lift(dt_ctx *ctx, const float *dem, const uint8_t *fdr, int64_t H, int64_t W, double px,
                           double dz, int raw, float *out, void *work, int64_t work_bytes);
