@@ -423,7 +423,7 @@ def main_tiled(args, torch, dist, world, rank, local_rank, dev):
     kern = {n: k for n, _, k in chain.OPS}
     op_defs = []
     for name, bpc in tiling.RANK_OPS:
-        k = {"d8": kern["d8"], "downslope": kern["downslope"], "slope_twi": kern["slope_twi"],
+        k = {"d8": kern["d8"], "downslope": ["k_downslope_win_r"], "slope_twi": kern["slope_twi"],
              "flowacc_local": ["k_fa_tile1", "k_fa_reduce", "k_fa_nxt_init", "k_fa_rank_summary"],
              "flowacc_finish_flowhand_local": ["k_rk_fa_*", "k_fa_propagate", "k_fa_poison", "k_fa3fh1", "k_fh_tile1",
                                                "k_fh_ghost_init", "k_fh_node_jump", "k_fh_rank_summary"],

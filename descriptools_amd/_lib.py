@@ -85,6 +85,7 @@ _SIGS = {
     "dt_dev_slope_d8_w": (ci, [vp, vp, vp, f64, vp, vp, vp]),
     "dt_dev_slope_twi_w": (ci, [vp, vp, vp, vp, f64, f64, vp, vp, vp, vp]),
     "dt_dev_downslope_w": (ci, [vp, vp, vp, vp, f64, f64, ci, vp, vp]),
+    "dt_dev_downslope_walkers_w": (ci, [vp, vp, vp, vp, f64, f64, i64, vp, vp, vp, vp, vp, vp, vp]),
     "dt_dev_flowacc_local_w": (ci, [vp, vp, vp, vp, vp, vp, vp]),
     "dt_dev_flowacc_finish_w": (ci, [vp, vp, vp, vp, vp, i64, vp, vp]),
     "dt_dev_flowhand_local_w": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),

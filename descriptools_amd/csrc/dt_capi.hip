@@ -758,6 +758,21 @@ extern "C" int dt_dev_downslope_w(dt_ctx *c, const dt_window *win, const float *
   return DT_OK;
 }
 
+// walkers of downslope walks that cross rank borders (dt_kernels.hip, k_ds_walkers; tiling.finish_downslope): the ones
+// standing in this rank's memory are advanced until they finish (status 1, value) or must be handed on (status 0)
+extern "C" int dt_dev_downslope_walkers_w(dt_ctx *c, const dt_window *win, const float *dem, const uint8_t *fdr,
+                                          double px, double dz, int64_t n, int32_t *gy, int32_t *gx, int32_t *moves,
+                                          double *dist, const float *z0, float *value, int32_t *status) {
+  DT_CTX(c);
+  DtWin w;
+  DT_TRY(dt_convert_window(win, &w));
+  DT_REQUIRE(n >= 0, "negative count");
+  DT_REQUIRE(n == 0 || (dem && fdr && gy && gx && moves && dist && z0 && value && status), "NULL pointer");
+  DT_TRY(dt_launch_ds_walkers(c->stream, w, dem, fdr, px, dz, n, gy, gx, moves, dist, z0, value, status));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+
 extern "C" int dt_dev_flowacc_local_w(dt_ctx *c, const dt_window *win, const uint8_t *fdr, int32_t *acc32,
                                       int64_t *A_perim, int32_t *xr_perim, uint8_t *code_perim) {
   DT_CTX(c);

@@ -109,6 +109,15 @@ __host__ __device__ __forceinline__ bool dt_readable(const DtWin &w, int y, int 
   return gy >= 0 && gy < w.Hg && gx >= 0 && gx < w.Wg && y >= -w.halo && y < w.H + w.halo && x >= -w.halo &&
          x < w.W + w.halo;
 }
+// readable AND its D8 code is in memory: a rank computes the codes of its core and of its halo minus the outermost
+// ring (a code needs the cell's eight neighbours), so a cell on the ring of the rank's memory has a height but no code
+// -- unless that ring is the edge of the global raster, where the border rule gave it one
+__host__ __device__ __forceinline__ bool dt_has_code(const DtWin &w, int y, int x) {
+  if (!dt_readable(w, y, x)) return false;
+  const int gy = w.gy0 + y, gx = w.gx0 + x;
+  return (y > -w.halo || gy == 0) && (y < w.H + w.halo - 1 || gy == w.Hg - 1) && (x > -w.halo || gx == 0) &&
+         (x < w.W + w.halo - 1 || gx == w.Wg - 1);
+}
 __host__ __device__ __forceinline__ bool dt_in_global(const DtWin &w, int y, int x) {
   int gy = w.gy0 + y, gx = w.gx0 + x;
   return gy >= 0 && gy < w.Hg && gx >= 0 && gx < w.Wg;

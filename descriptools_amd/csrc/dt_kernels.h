@@ -26,6 +26,9 @@ int dt_launch_gfi_i64(hipStream_t s, const float *hand, const int64_t *area, int
                       double b, double size, float *out, int own_cell);
 int dt_launch_river_acc_i64(hipStream_t s, const int64_t *fac, const int64_t *idx, int64_t n,
                             int64_t *out);
+int dt_launch_ds_walkers(hipStream_t s, const DtWin &w, const float *dem, const uint8_t *fdr, double px, double dz,
+                         int64_t n, int32_t *gy, int32_t *gx, int32_t *moves, double *dist, const float *z0, float *value,
+                         int32_t *status);
 size_t dt_downslope_lift_bytes(int64_t H, int64_t W);
 int dt_launch_downslope(hipStream_t s, const DtWin &w, const float *dem, const uint8_t *fdr, double px,
                         double dz, int raw, float *out, int *n_unresolved, void *lift = nullptr,

@@ -527,6 +527,9 @@ struct DsQueue {
 // What one cell's fast walk in the LDS window hands over, turned into the stored value.  drop: z0 - z(cell the walk stands on) (+inf: it stepped onto nodata); loop / nd: moves
 // made / diagonal ones; stop_fail: the walk stopped on a cell that cannot be left (non-D8 code, move off the raster);
 // (y, x): rank coordinates of the cell it stands on.
+// RANKED: the window is a rank's (core + halo inside a larger raster): the last ring of its memory has heights but no
+// D8 codes (dt_has_code), and a walk that gets there belongs to another rank.  A single raster needs none of that.
+template <bool RANKED = true>
 __device__ __forceinline__ void ds_finish_cell(const DtWin &w, const float *__restrict__ dem,
                                                const uint8_t *__restrict__ fdr, int y0, int x0, float z0, float drop,
                                                uint32_t loop, uint32_t nd, bool stop_fail, int y, int x, double dcard,
@@ -550,9 +553,11 @@ __device__ __forceinline__ void ds_finish_cell(const DtWin &w, const float *__re
     uint32_t budget = q.entries ? DS_Q_MOVES : 0xFFFFFFFFu;  // global moves before the walk is handed to the queue
     // the code of the cell the walk stands on is fetched together with the height of the cell before it: one memory
     // round trip per move on the walk's dependent chain, not two
-    uint32_t code = dt_readable(w, y, x) ? (uint32_t)fdr[(long long)y * w.ld + x] : 0u;
+    auto has_code = [&](int yy, int xx) { return RANKED ? dt_has_code(w, yy, xx) : dt_readable(w, yy, xx); };
+    uint32_t code = has_code(y, x) ? (uint32_t)fdr[(long long)y * w.ld + x] : 0u;
     while ((double)drop < dz) {
-      if (!dt_readable(w, y, x)) { unresolved = true; break; }  // beyond this rank's halo
+      // at the end of this rank's memory (the last ring of the halo has heights, not codes): another rank's walk
+      if (!has_code(y, x)) { unresolved = true; break; }
       if (budget-- == 0u) {
         // A LONG walk (a flat, a valley floor: real conditioned terrain has walks of thousands of moves, each a
         // dependent global load here): handed to k_ds_finish, which crosses it in skips of 64 moves.  A full queue
@@ -619,7 +624,7 @@ __device__ __forceinline__ void ds_finish_cell(const DtWin &w, const float *__re
     unresolved = false;
     uint32_t moves = 0;
     while ((double)drop < dz) {
-      if (!dt_readable(w, y, x)) { unresolved = true; break; }  // beyond this rank's halo
+      if (!(RANKED ? dt_has_code(w, y, x) : dt_readable(w, y, x))) { unresolved = true; break; }  // the end of this rank's memory
       uint32_t code = fdr[(long long)y * w.ld + x];
       if (!dt_d8_valid(code)) { failed = true; break; }
       int dy, dx;
@@ -674,7 +679,7 @@ __device__ __forceinline__ void ds_finish_cell(const DtWin &w, const float *__re
 #define MW_RING 0x2000u
 #define MW_STOP 0x8000u
 
-template <int DW_M, bool QUEUE>
+template <int DW_M, bool QUEUE, bool RANKED>
 __device__ __forceinline__ void ds_win_body(const float *__restrict__ dem,
                                                        const uint8_t *__restrict__ fdr, DtWin w,
                                                        double px, double dz, float dzf, int raw,
@@ -711,8 +716,11 @@ __device__ __forceinline__ void ds_win_body(const float *__restrict__ dem,
   // readable cells (inside the global raster and in memory): rows [ya, yb), columns [xa, xb)
   const int ya = max(-w.halo, -w.gy0), yb = min(w.H + w.halo, w.Hg - w.gy0);
   const int xa = max(-w.halo, -w.gx0), xb = min(w.W + w.halo, w.Wg - w.gx0);
-  // block-uniform: every window cell is in memory and no move from it can leave the global raster
-  const bool interior = vec && wy0 >= ya && wy0 + DW_WIN <= yb && wx0 >= xa && wx0 + DW_WIN <= xb &&
+  // cells whose D8 code is in memory (dt_has_code): the last ring of the halo is not, unless it is the raster's edge
+  const int yca = (RANKED && -w.halo > -w.gy0) ? ya + 1 : ya, ycb = (RANKED && w.H + w.halo < w.Hg - w.gy0) ? yb - 1 : yb;
+  const int xca = (RANKED && -w.halo > -w.gx0) ? xa + 1 : xa, xcb = (RANKED && w.W + w.halo < w.Wg - w.gx0) ? xb - 1 : xb;
+  // block-uniform: every window cell is in memory with its code and no move from it can leave the global raster
+  const bool interior = vec && wy0 >= yca && wy0 + DW_WIN <= ycb && wx0 >= xca && wx0 + DW_WIN <= xcb &&
                         w.gy0 + wy0 >= 1 && w.gy0 + wy0 + DW_WIN <= w.Hg - 1 && w.gx0 + wx0 >= 1 &&
                         w.gx0 + wx0 + DW_WIN <= w.Wg - 1;
   const float ninf = -__builtin_inff();
@@ -805,6 +813,9 @@ __device__ __forceinline__ void ds_win_body(const float *__restrict__ dem,
         }
         // ring of the window, or the edge of what is in memory: hand over to the global walk
         if (r == 0 || r == DW_WIN - 1 || rx == 0 || rx == DW_WIN - 1 || !rd[k]) mw |= MW_RING | MW_STOP;
+        // a cell of the halo's last ring has a height but no code (0 in memory is not "a non-D8 code" there): the
+        // walk may step onto it, and goes on in another rank's memory
+        if (RANKED && rd[k] && !(gy >= yca && gy < ycb && gx + k >= xca && gx + k < xcb)) mw = MW_RING | MW_STOP | MW_BIAS;
         mwv[k] = mw;
       }
       v.x = v.x == DT_NODATA ? ninf : v.x;
@@ -881,7 +892,7 @@ __device__ __forceinline__ void ds_win_body(const float *__restrict__ dem,
     // sum of the move words = (q2 - q2_0) + MW_BIAS * moves + MW_DIAG * diagonal moves
     uint32_t nd = ((acc & 0x7FFFFu) - (q2 - q2_0) - (uint32_t)MW_BIAS * loop) / MW_DIAG;
     const uint32_t pos = (q2 - lds0) >> 1;
-    ds_finish_cell(w, dem, fdr, y0, x0, z0, drop, loop, nd, (mw & (MW_BADCODE | MW_EDGE)) != 0u,
+    ds_finish_cell<RANKED>(w, dem, fdr, y0, x0, z0, drop, loop, nd, (mw & (MW_BADCODE | MW_EDGE)) != 0u,
                    wy0 + (int)(pos / DW_LD), wx0 + (int)(pos % DW_LD), dcard, ddiag, dz, dzf, raw, out + o, n_unresolved,
                    QUEUE ? queue : DsQueue());  // without a queue the code of the hand-over is not even compiled in
   }
@@ -892,7 +903,14 @@ __global__ __launch_bounds__(1024, 8) void k_downslope_win(const float *__restri
                                                        const uint8_t *__restrict__ fdr, DtWin w, double px, double dz,
                                                        float dzf, int raw, float *__restrict__ out, int tiles_x,
                                                        int ntiles, int *__restrict__ n_unresolved) {
-  ds_win_body<DW_M, false>(dem, fdr, w, px, dz, dzf, raw, out, tiles_x, ntiles, n_unresolved, DsQueue());
+  ds_win_body<DW_M, false, false>(dem, fdr, w, px, dz, dzf, raw, out, tiles_x, ntiles, n_unresolved, DsQueue());
+}
+// a rank's window (core + halo inside a larger raster): see ds_finish_cell
+__global__ __launch_bounds__(1024, 8) void k_downslope_win_r(const float *__restrict__ dem,
+                                                         const uint8_t *__restrict__ fdr, DtWin w, double px,
+                                                         double dz, float dzf, int raw, float *__restrict__ out,
+                                                         int tiles_x, int ntiles, int *__restrict__ n_unresolved) {
+  ds_win_body<24, false, true>(dem, fdr, w, px, dz, dzf, raw, out, tiles_x, ntiles, n_unresolved, DsQueue());
 }
 // the same with the hand-over of long walks to the queue (a kernel of its own: the plain one keeps its registers)
 __global__ __launch_bounds__(1024, 8) void k_downslope_win_q(const float *__restrict__ dem,
@@ -900,7 +918,7 @@ __global__ __launch_bounds__(1024, 8) void k_downslope_win_q(const float *__rest
                                                          double dz, float dzf, int raw, float *__restrict__ out,
                                                          int tiles_x, int ntiles, int *__restrict__ n_unresolved,
                                                          DsQueue queue) {
-  ds_win_body<24, true>(dem, fdr, w, px, dz, dzf, raw, out, tiles_x, ntiles, n_unresolved, queue);
+  ds_win_body<24, true, false>(dem, fdr, w, px, dz, dzf, raw, out, tiles_x, ntiles, n_unresolved, queue);
 }
 
 // ---- skip table ------------------------------------------------------------------------------------------------
@@ -977,9 +995,69 @@ __global__ __launch_bounds__(256) void k_ds_finish(const float *__restrict__ dem
     }
     const int y = (int)(pos / (uint32_t)w.W), x = (int)(pos - (uint32_t)y * (uint32_t)w.W);
     const float drop = z0 - dem[pos];
-    ds_finish_cell(w, dem, fdr, y0, x0, z0, drop, loop, nd, false, y, x, dcard, ddiag, dz, dzf, raw, out + e.x,
-                   n_unresolved);
+    ds_finish_cell<false>(w, dem, fdr, y0, x0, z0, drop, loop, nd, false, y, x, dcard, ddiag, dz, dzf, raw, out + e.x,
+                          n_unresolved);
   }
+}
+
+// ---- walks across rank borders ---------------------------------------------------------------------------------------
+// A walk that leaves a rank's memory (core + halo) is marked -50 and counted by the window kernel; on real terrain,
+// where walks run for thousands of moves, that happens along every border.  descriptools_amd/tiling.py
+// (finish_downslope) re-walks such cells as WALKERS that travel from rank to rank: global position, moves made, the
+// path length as the reference accumulates it (a sequential float64 sum: the state carries the sum itself, so the
+// result is the reference's own arithmetic whatever the route), the start cell's height.  This kernel advances the
+// walkers that stand in this rank's memory until they finish (status 1: value = downslope), or must be handed on
+// (status 0: position / moves / sum updated).
+__global__ __launch_bounds__(256) void k_ds_walkers(const float *__restrict__ dem, const uint8_t *__restrict__ fdr,
+                                                   DtWin w, double px, double dz, int64_t n, int32_t *__restrict__ gy,
+                                                   int32_t *__restrict__ gx, int32_t *__restrict__ moves,
+                                                   double *__restrict__ dist, const float *__restrict__ z0s,
+                                                   float *__restrict__ value, int32_t *__restrict__ status) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  if (status[i] != 0) return;
+  int y = gy[i] - w.gy0, x = gx[i] - w.gx0;
+  if (!dt_has_code(w, y, x)) return;  // not mine: somebody else's walker
+  const double dcard = px, ddiag = px * sqrt(2.0);
+  const float z0 = z0s[i];
+  int m = moves[i];
+  double d = dist[i];
+  float drop = m > 0 ? z0 - dem[(long long)y * w.ld + x] : 0.0f;
+  bool done = false;
+  while ((double)drop < dz) {
+    if (!dt_has_code(w, y, x)) break;  // the end of my memory: (y, x) lies in a neighbour's core -- hand over
+    uint32_t code = fdr[(long long)y * w.ld + x];
+    if (!dt_d8_valid(code)) { done = true; break; }  // failed: the walk so far is the result (non-raw form)
+    int dy, dx;
+    dt_d8_delta(code, dy, dx);
+    const int ny = y + dy, nx = x + dx;
+    if (!dt_in_global(w, ny, nx)) { done = true; break; }
+    if (!dt_readable(w, ny, nx)) break;  // hand over: (y, x) lies in a neighbour's core
+    const float zt = dem[(long long)ny * w.ld + nx];
+    if (zt == DT_NODATA) { done = true; break; }
+    y = ny;
+    x = nx;
+    d += (dy != 0 && dx != 0) ? ddiag : dcard;
+    drop = z0 - zt;
+    if (++m == 5000) { done = true; break; }  // downslope.py:303-304
+  }
+  if (!((double)drop < dz)) done = true;
+  gy[i] = y + w.gy0;
+  gx[i] = x + w.gx0;
+  moves[i] = m;
+  dist[i] = d;
+  if (done) {
+    value[i] = d == 0.0 ? 0.0f : (float)((double)drop / d);
+    status[i] = 1;
+  }
+}
+int dt_launch_ds_walkers(hipStream_t s, const DtWin &w, const float *dem, const uint8_t *fdr, double px, double dz,
+                         int64_t n, int32_t *gy, int32_t *gx, int32_t *moves, double *dist, const float *z0, float *value,
+                         int32_t *status) {
+  if (n > 0)
+    hipLaunchKernelGGL(k_ds_walkers, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dem, fdr, w, px, dz, n, gy, gx,
+                       moves, dist, z0, value, status);
+  return DT_OK;
 }
 
 // workspace of the long-walk acceleration for an H x W raster: counter | queue (one entry per two cells) | two
@@ -1022,6 +1100,9 @@ int dt_launch_downslope(hipStream_t s, const DtWin &w, const float *dem, const u
   else if (m == 20)
     hipLaunchKernelGGL(k_downslope_win<20>, dim3((unsigned)ntiles), dim3(1024), 0, s, dem, fdr, w, px, dz, dzf, raw,
                        out, tiles_x, (int)ntiles, n_unresolved);
+  else if (!(w.halo == 0 && w.gy0 == 0 && w.gx0 == 0 && w.Hg == w.H && w.Wg == w.W))
+    hipLaunchKernelGGL(k_downslope_win_r, dim3((unsigned)ntiles), dim3(1024), 0, s, dem, fdr, w, px, dz, dzf, raw, out,
+                       tiles_x, (int)ntiles, n_unresolved);
   else if (q.entries)
     hipLaunchKernelGGL(k_downslope_win_q, dim3((unsigned)ntiles), dim3(1024), 0, s, dem, fdr, w, px, dz, dzf, raw, out,
                        tiles_x, (int)ntiles, n_unresolved, q);

@@ -950,6 +950,66 @@ class LocalComm:
         return out
 
 
+def finish_downslope(tile, comm, max_iters=200):
+    """Downslope walks that left a rank's memory (dt_dev_downslope_w marks such cells -50 and counts them: none on the
+    synthetic benchmark terrain, thousands along every border on real terrain, whose walks run for kilometres through
+    flats and along valley floors).  Every rank calls this after its step.  The marked cells are walked again as
+    WALKERS that travel from rank to rank -- global position, moves made, the path length as the reference
+    accumulates it (a sequential float64 sum, carried in the state, so the result is the reference's own arithmetic
+    whatever the route), the start cell's height: each iteration every rank advances the walkers standing in its
+    core (dt_dev_downslope_walkers_w) until they finish or reach the end of its halo, the updates are all-gathered
+    (`comm`: DistComm / LocalComm, small host arrays), and the owner of a finished walker's start cell writes the
+    value.  Returns the number of cells resolved (over all ranks); 0 without a single exchange when no rank had any."""
+    tc, L, layout = tile.torch, tile.L, tile.layout
+    n_local = tile.unresolved_downslope()
+    total = int(sum(int(np.asarray(v).reshape(-1)[0]) for v in comm.all_gather(np.asarray([n_local], np.int64))))
+    if total == 0:
+        return 0
+    with tile.on_stream():
+        core = tile.core("down")
+        ys, xs = (core == -50.0).nonzero(as_tuple=True)
+        z0 = tile.core("dem")[ys, xs].float()
+    tile.ctx.sync()
+    mine = np.zeros((len(ys), 3), np.float64)
+    mine[:, 0], mine[:, 1], mine[:, 2] = ys.cpu().numpy() + tile.gy0, xs.cpu().numpy() + tile.gx0, z0.cpu().numpy()
+    rows = np.concatenate([np.asarray(r, np.float64).reshape(-1, 3) for r in comm.all_gather(mine)], axis=0)
+    n = len(rows)
+    sy, sx = rows[:, 0].astype(np.int32), rows[:, 1].astype(np.int32)     # start cells: the same list on every rank
+    gy, gx = sy.copy(), sx.copy()                                          # where each walker stands
+    moves, dist = np.zeros(n, np.int32), np.zeros(n, np.float64)
+    zs = rows[:, 2].astype(np.float32)
+    value, status = np.zeros(n, np.float32), np.zeros(n, np.int32)
+    dev = lambda a: tc.as_tensor(a, device=tile.dev)
+    for _ in range(max_iters):
+        sel = np.nonzero((status == 0) & (layout.owner(gy.astype(np.int64), gx.astype(np.int64)) == tile.rank))[0]
+        upd = np.zeros((0, 7), np.float64)
+        if len(sel):
+            with tile.on_stream():
+                d = [dev(np.ascontiguousarray(a[sel])) for a in (gy, gx, moves, dist, zs, value, status)]
+                tile._chk(L.dt_dev_downslope_walkers_w(tile.ctx.h, C.byref(tile.win), tile.p("dem"), tile.p("fdr"),
+                                                       tile.px, tile.dz, len(sel), *[x.data_ptr() for x in d]))
+            tile.ctx.sync()
+            h = [x.cpu().numpy() for x in d]
+            upd = np.stack([sel.astype(np.float64), h[0], h[1], h[2], h[3], h[5], h[6]], axis=1).astype(np.float64)
+        for u in comm.all_gather(upd):
+            u = np.asarray(u, np.float64).reshape(-1, 7)
+            if len(u):
+                k = u[:, 0].astype(np.int64)
+                gy[k], gx[k], moves[k], dist[k] = u[:, 1].astype(np.int32), u[:, 2].astype(np.int32), u[:, 3].astype(np.int32), u[:, 4]
+                value[k], status[k] = u[:, 5].astype(np.float32), u[:, 6].astype(np.int32)
+        if (status != 0).all():
+            break
+    else:
+        raise RuntimeError("finish_downslope: walkers still on their way after %d exchanges" % max_iters)
+    own = np.nonzero(layout.owner(sy.astype(np.int64), sx.astype(np.int64)) == tile.rank)[0]
+    if len(own):
+        with tile.on_stream():
+            tile.core("down")[dev(sy[own].astype(np.int64) - tile.gy0), dev(sx[own].astype(np.int64) - tile.gx0)] = dev(value[own])
+            tile.n_unres.zero_()
+        tile.ctx.sync()
+    return total
+
+
 def evaluate_rank(tile, flood_core, comm, name="hand", under="under", class_map=False):
     """Example/example.py:113-147 on ONE rank's core window of a tiled descriptor raster (default: the HAND this
     tile's step left in tile.t["hand"]), every rank calling it at the same time: the np.unique extremes are

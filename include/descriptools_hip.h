@@ -289,6 +289,14 @@ int dt_dev_slope_twi_w(dt_ctx *ctx, const dt_window *win, const float *dem, cons
 /* n_unresolved_dev (device int32, may be NULL): walks that left this rank's halo (marked -50) */
 int dt_dev_downslope_w(dt_ctx *ctx, const dt_window *win, const float *dem, const uint8_t *fdr, double px,
                        double elevation_difference, int raw, float *out, int32_t *n_unresolved_dev);
+/* Walks that leave a rank's memory (dt_dev_downslope_w marks them -50 and counts them) travel on as WALKERS: global
+ * position (gy, gx), moves made, the path length as the reference's sequential float64 sum, the start cell's height.
+ * The walkers with status 0 that stand in this rank's memory are advanced until they finish (status 1: value = the
+ * downslope of their start cell) or must be handed to a neighbour (status stays 0, state updated).  All arrays on the
+ * device, n entries.  Driver: descriptools_amd/tiling.py, finish_downslope. */
+int dt_dev_downslope_walkers_w(dt_ctx *ctx, const dt_window *win, const float *dem, const uint8_t *fdr, double px,
+                               double dz, int64_t n, int32_t *gy, int32_t *gx, int32_t *moves, double *dist,
+                               const float *z0, float *value, int32_t *status);
 /* phase 1: in-rank accumulation; per ring cell: A = cells of this rank draining OUT through it (0 unless
  * its D8 step leaves the core), code = that step's D8 code, xr = ring index of the rank exit reached by
  * a path ENTERING at this cell (-1 none, -2 cycle inside the rank).  acc32 is not touched by this phase (the raster

@@ -349,3 +349,60 @@ def test_two_phase_state_is_guarded():
         t.fa_finish(None)      # the HAND state replaced the flow-accumulation state
     t.fh_finish(None)
     t.ctx.sync()
+
+
+@pytest.mark.parametrize("heights,widths", [([256, 256], [384, 384]), ([512], [192, 320, 256])])
+def test_downslope_walks_across_rank_borders(heights, widths):
+    """terrain whose walks run for thousands of moves (a 1 per mille plane, a flat, nodata): on every rank border the
+    window kernel marks the cells whose walk leaves the rank's memory; tiling.finish_downslope sends them on as
+    walkers from rank to rank (LocalComm: one thread per logical rank) -- the result equals the oracle's walk on the
+    whole raster, cell for cell"""
+    import threading
+    import torch
+    import oracle
+    from descriptools_amd import tiling
+    layout = tiling.Layout(heights, widths)
+    Hg, Wg = layout.Hg, layout.Wg
+    yy, xx = np.mgrid[0:Hg, 0:Wg]
+    dem = (200.0 - 0.001 * xx - 0.0002 * yy).astype(np.float32)
+    dem[150:180, 100:500] = np.float32(150.0)
+    rng = np.random.default_rng(4)
+    dem[rng.random((Hg, Wg)) < 0.0005] = -100
+    _, fdr = oracle.slope_d8(dem, 1.0)
+    want = oracle.downslope(dem, fdr, 1.0, 5.0)
+    h = tiling.HALO
+    pad = np.full((Hg + 2 * h, Wg + 2 * h), -100.0, np.float32)
+    pad[h:h + Hg, h:h + Wg] = dem
+    tiles = []
+    for r in range(layout.size):
+        tl = tiling.RankTile(layout, r, device=0, px=1.0, dz=5.0, river_threshold=Hg * Wg // 64)
+        y0, x0 = layout.origin(r)
+        tl.set_dem_ext(pad[y0:y0 + tl.He, x0:x0 + tl.We])
+        tiles.append(tl)
+    tiling.simulate_dev(tiles, layout)
+    marked = sum(tl.unresolved_downslope() for tl in tiles)
+    assert marked > 1000, "the terrain is meant to send many walks across the borders"
+    comms = tiling.LocalComm.create(layout.size)
+    done, errors = [None] * layout.size, []
+
+    def work(r):
+        try:
+            done[r] = tiling.finish_downslope(tiles[r], comms[r])
+        except BaseException as e:  # noqa: BLE001 - reported below
+            errors.append(e)
+            comms[r].sh.barrier.abort()
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(layout.size)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    assert all(d == marked for d in done)
+    for tl in tiles:
+        y0, x0 = layout.origin(tl.rank)
+        got = tl.host("down")
+        ref = want[y0:y0 + tl.H, x0:x0 + tl.W]
+        assert tl.unresolved_downslope() == 0
+        assert np.array_equal(got, ref, equal_nan=True), (tl.rank, int((got != ref).sum()))
+        tl.free()
+    torch.cuda.empty_cache()
