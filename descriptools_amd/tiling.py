@@ -882,9 +882,10 @@ def simulate(tiles, layout):
         t.pointwise()
 
 
-def simulate_dev(tiles, layout):
+def simulate_dev(tiles, layout, d8=True):
     """Same as simulate(), but with the product's rank-level solves on the GPU: the gathered buffer is
-    the concatenation of the logical ranks' summary rows, exactly what the RCCL all-gather delivers."""
+    the concatenation of the logical ranks' summary rows, exactly what the RCCL all-gather delivers.
+    d8=False: the tiles already hold their D8 codes (condition_local / condition_ranks)."""
     import torch
 
     def gather(rows):  # the logical ranks own one stream each: order them around the copy by hand
@@ -894,7 +895,8 @@ def simulate_dev(tiles, layout):
         torch.cuda.synchronize()
         return out
     for t in tiles:
-        t.d8()
+        if d8:
+            t.d8()
         t.fa_local(sync=False)
         t.fill_ring_codes()
     rows = gather([t.fa_row for t in tiles])

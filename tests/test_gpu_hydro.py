@@ -238,3 +238,67 @@ def test_conditioning_tiled_over_ranks_equals_untiled(heights, widths):
     for t in tiles:
         t.free()
     torch.cuda.empty_cache()
+
+
+def test_example_conditioned_chain_in_ranks_equals_untiled():
+    """REAL terrain end to end over ranks: the bundled Example DEM, conditioned over 2 x 2 logical ranks
+    (tiling.condition_local), the rank step on the conditioned codes (flats and valley floors: flow paths and downslope
+    walks of thousands of cells across the rank borders), the walks that leave a rank finished as walkers
+    (tiling.finish_downslope) -- every raster equals the untiled chain's (Chain(condition=True, long_walks=True))"""
+    import threading
+    import torch
+    from conftest import load_example
+    from descriptools_amd import chain, tiling
+    from descriptools_amd.device import Context
+    dem = np.asarray(load_example()[0], np.float32)
+    Hg, Wg = dem.shape
+    px = 12.5
+    ctx = Context()
+    d = ctx.to_device(dem)
+    ch = chain.Chain(Hg, Wg, ctx=ctx, px=px, condition=True, condition_rounds=96, long_walks=True, tune_placement=False)
+    ch.run(d.ptr)
+    ch.check_status()
+    names = ["fdr", "fac", "river", "fdist", "hand", "slope", "ti", "mti", "gfi", "lnhlh", "down"]
+    ref = {k: ch.buf[k].to_host() for k in names}
+    ch.free()
+    d.free()
+    ctx.close()
+    layout = tiling.Layout([1088, Hg - 1088], [768, Wg - 768])
+    h = tiling.HALO
+    pad = np.zeros((Hg + 2 * h, Wg + 2 * h), np.float32)
+    pad[h:h + Hg, h:h + Wg] = dem
+    tiles = []
+    for r in range(layout.size):
+        t = tiling.RankTile(layout, r, device=0, px=px)
+        y0, x0 = layout.origin(r)
+        t.set_dem_ext(pad[y0:y0 + t.He, x0:x0 + t.We])
+        tiles.append(t)
+    left, _, _ = tiling.condition_local(tiles, layout)
+    assert left == 0
+    tiling.simulate_dev(tiles, layout, d8=False)
+    marked = sum(t.unresolved_downslope() for t in tiles)
+    assert marked > 0, "the Example's valley floors send walks across the rank borders"
+    comms = tiling.LocalComm.create(layout.size)
+    errors = []
+
+    def work(r):
+        try:
+            tiling.finish_downslope(tiles[r], comms[r])
+        except BaseException as e:  # noqa: BLE001 - reported below
+            errors.append(e)
+            comms[r].sh.barrier.abort()
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(layout.size)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for t in tiles:
+        t.check_status()
+        y0, x0 = layout.origin(t.rank)
+        sl = (slice(y0, y0 + t.H), slice(x0, x0 + t.W))
+        for k in names:
+            got, want = t.host(k), ref[k][sl]
+            assert np.array_equal(got, want.astype(got.dtype), equal_nan=True), (t.rank, k, int((got != want).sum()))
+        t.free()
+    torch.cuda.empty_cache()
