@@ -180,6 +180,10 @@ def main():
                      side_ctx=ctx2 if args.overlap else None, overlap=args.overlap, want_slope_rad=False,
                      tune_placement=not args.no_placement)
     torch.cuda.empty_cache()  # the candidates the chain did not keep go back to the device
+    if (ch.placement or {}).get("spacer_GiB"):
+        # the runtime defers the release of what the search allocated: the next allocation of >= 2 GiB would wait for it
+        # (seconds) -- take that wait here, as part of the chain's set-up, not inside a timed region further down
+        ctx.empty((2 << 30,), np.uint8).free()
     tdt = {np.float32: torch.float32, np.uint8: torch.uint8, np.int8: torch.int8, np.int32: torch.int32}
     rasters = {name: bufs[ch.p(name)].view(tdt[dt]) for name, dt in chain.OUTPUTS}
     N = H * W

@@ -121,6 +121,13 @@ class Chain:
                                        spacer_alloc=spacer_alloc if can_grow else None,
                                        spacer_release=spacer_release if can_grow else None)
         self.placement = info
+        if info.get("spacer_GiB"):
+            # the runtime defers the release of the spacers: take the wait here, where it was caused
+            for gib in (2, 16):
+                try:
+                    self.ctx.empty((gib << 30,), np.uint8).free()
+                except (MemoryError, RuntimeError):
+                    break
         if roles is None:
             return
         dts = dict(OUTPUTS)

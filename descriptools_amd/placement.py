@@ -92,7 +92,7 @@ def spread(labels, groups):
 
 
 def assign(ctx, nbytes, blocks, groups, extra_alloc=None, extra_release=None, budget=24, spacer_alloc=None,
-           spacer_release=None, spacer_budget=160 << 30):
+           spacer_release=None, spacer_budget=96 << 30):
     """blocks: device pointers of equally sized blocks (>= one per role); groups: role names written together.
     Returns ({role: pointer}, info) -- or (None, info) when the rasters are too small to bother.  When the blocks
     span fewer classes than the largest group could use and `extra_alloc()` -> pointer is given, up to `budget`
@@ -102,7 +102,10 @@ def assign(ctx, nbytes, blocks, groups, extra_alloc=None, extra_release=None, bu
     one box read ABBAABBBBBBBBBBBB AAAAAAAA B x16 C x16 A x16 B x32 A x15), so candidates allocated back to back can
     all be alike: with `spacer_alloc(nbytes)` -> handle a candidate that adds nothing is followed by a spacer
     (4, 8, 16, 16, ... GiB, `spacer_budget` bytes in all, released at the end) that moves the next candidate on,
-    and one that does add a class is followed by its neighbours, which share its run."""
+    and one that does add a class is followed by its neighbours, which share its run.  Spacers are not free: the
+    runtime takes ~0.2 s to allocate 16 GiB and DEFERS the release -- some later allocation of the process pays for it
+    (4.9 s after 160 GiB, measured) -- which is why the budget is 96 GiB and why Chain / bench.py allocate and free a
+    block right after the search (the wait then belongs to the set-up that caused it, not to an innocent caller)."""
     blocks = [b.value if hasattr(b, "value") else int(b) for b in blocks]
     cl = WriteClassifier(ctx, nbytes)
     if not cl.usable():

@@ -384,6 +384,11 @@ class RankTile:
         objs.clear()
         self.ctx.sync()
         tc.cuda.empty_cache()
+        if info.get("spacer_GiB"):  # the runtime defers the release of the spacers: take the wait here (placement.assign)
+            try:
+                self.ctx.empty((2 << 30,), np.uint8).free()
+            except (MemoryError, RuntimeError):
+                pass
 
     def on_stream(self):
         """context manager: torch ops inside run on this tile's context stream"""
