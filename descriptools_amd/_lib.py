@@ -80,6 +80,12 @@ _SIGS = {
     "dt_dev_downslope": (ci, [vp, vp, vp, i64, i64, f64, f64, ci, vp]),
     "dt_downslope_lift_workspace": (i64, [i64, i64]),
     "dt_dev_downslope_lift": (ci, [vp, vp, vp, i64, i64, f64, f64, ci, vp, vp, i64]),
+    "dt_downslope_queue_workspace": (i64, [i64, i64]),
+    "dt_downslope_tables_workspace": (i64, [i64, i64]),
+    "dt_downslope_tables_threshold": (i64, [i64, i64]),
+    "dt_dev_downslope_queue": (ci, [vp, vp, vp, i64, i64, f64, f64, ci, vp, vp, i64]),
+    "dt_dev_downslope_queued": (ci, [vp, vp, C.POINTER(i64)]),
+    "dt_dev_downslope_finish": (ci, [vp, vp, vp, i64, i64, f64, f64, ci, vp, vp, i64, vp, i64]),
     "dt_dev_confusion_multi": (ci, [vp, vp, vp, i64, f64, c_f64p, ci, ci, vp]),
     "dt_perim_cells": (i64, [i64, i64]),
     "dt_dev_slope_d8_w": (ci, [vp, vp, vp, f64, vp, vp, vp]),

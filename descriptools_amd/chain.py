@@ -55,11 +55,15 @@ class Chain:
         flats; the descriptors themselves keep using the DEM as given (as the reference's example does with a D8
         raster from a GIS tool, Example/example.py:36).  Nothing synchronises: `condition_rounds` fill / flat rounds
         are enqueued, and check_status() raises afterwards if that budget was too small for the raster."""
-        # long_walks: downslope with the long-walk workspace (dt_dev_downslope_lift, 56 B/cell): for real, conditioned
-        # terrain, whose flats and valley floors make walks thousands of moves long (the bundled Example: 9.5 -> under
-        # 1 ms); the synthetic benchmark terrain has no such walks and runs without it
-        self.long_walks = bool(long_walks)
-        self._lift = None
+        # long_walks: for real, conditioned terrain, whose flats and valley floors make downslope walks thousands of
+        # moves long (the bundled Example: 9.6 -> 1.4 ms).  True: the whole long-walk workspace up front
+        # (dt_dev_downslope_lift, 56 B/cell), nothing synchronises.  "auto": the walks are queued (8 B/cell) and
+        # finish_long_walks() -- a synchronisation point -- finishes them, with skip tables (48 B/cell more) only when
+        # the raster has enough of them; run_host does this.  False: the plain kernel (the synthetic benchmark terrain
+        # has no long walks).
+        assert long_walks in (False, True, "auto")
+        self.long_walks = long_walks
+        self._lift = self._lift_q = self._lift_dem = None
         self.condition, self.condition_rounds = bool(condition), int(condition_rounds)
         self._alloc, self._release = alloc, release
         self.want_slope_rad = want_slope_rad
@@ -143,6 +147,40 @@ class Chain:
             self._lift = self.ctx.empty((self._lift_bytes,), np.uint8)
         return self._lift.ptr
 
+    def _queue_downslope(self, side, dem_ptr):
+        L = _lib.lib()
+        if self._lift_q is None:
+            self._lift_q_bytes = int(L.dt_downslope_queue_workspace(self.H, self.W))
+            self._lift_q = self.ctx.empty((self._lift_q_bytes,), np.uint8)
+        self._lift_dem = dem_ptr
+        return L.dt_dev_downslope_queue(side.h, dem_ptr, self.p("fdr"), self.H, self.W, self.px, self.dz, 0,
+                                        self.p("down"), self._lift_q.ptr, self._lift_q_bytes)
+
+    def finish_long_walks(self):
+        """long_walks="auto": wait for the step, look at the queue of long downslope walks and finish them (skip tables
+        only when there are enough of them to pay for a pass over the raster).  Returns the number of walks queued."""
+        if self.long_walks != "auto" or self._lift_q is None:
+            return 0
+        L, c = _lib.lib(), self.ctx
+        n = C.c_int64(0)
+        check(L.dt_dev_downslope_queued(c.h, self._lift_q.ptr, C.byref(n)))
+        if n.value == 0:
+            return 0
+        tables, tb = None, 0
+        if n.value >= int(L.dt_downslope_tables_threshold(self.H, self.W)):
+            tb = int(L.dt_downslope_tables_workspace(self.H, self.W))
+            try:
+                tables = c.empty((tb,), np.uint8)
+            except (MemoryError, RuntimeError):
+                tables, tb = None, 0
+        check(L.dt_dev_downslope_finish(c.h, self._lift_dem, self.p("fdr"), self.H, self.W, self.px, self.dz, 0,
+                                        self.p("down"), self._lift_q.ptr, self._lift_q_bytes,
+                                        tables.ptr if tables is not None else None, tb))
+        c.sync()
+        if tables is not None:
+            tables.free()
+        return int(n.value)
+
     def p(self, name):
         b = self.buf[name]
         return b.ptr if hasattr(b, "ptr") else b
@@ -167,7 +205,8 @@ class Chain:
             first,
             ("downslope", side, (lambda: L.dt_dev_downslope_lift(side.h, dem_ptr, p("fdr"), H, W, self.px, self.dz, 0,
                                                                   p("down"), self._lift_ptr(), self._lift_bytes))
-             if self.long_walks else
+             if self.long_walks is True else
+             (lambda: self._queue_downslope(side, dem_ptr)) if self.long_walks == "auto" else
              (lambda: L.dt_dev_downslope(side.h, dem_ptr, p("fdr"), H, W, self.px, self.dz, 0, p("down")))),
             ("flowacc_flowhand_local", c, lambda: L.dt_dev_flowacc_river_flowhand_local(
                 c.h, p("fdr"), dem_ptr, H, W, self.river_threshold, p("fac"), p("river"))),
@@ -236,9 +275,10 @@ class Chain:
             if hasattr(b, "free"):
                 b.free()
         self.buf = {}
-        if self._lift is not None:
-            self._lift.free()
-            self._lift = None
+        for name in ("_lift", "_lift_q"):
+            if getattr(self, name) is not None:
+                getattr(self, name).free()
+                setattr(self, name, None)
 
 
 class Graph:
@@ -274,6 +314,7 @@ def run_host(dem, px, timings=None, **kw):
     H, W = dem32.shape
     ctx = Context()
     kw.setdefault("tune_placement", False)  # one step: the ~0.1 s of measurement would buy 0.3 ms
+    kw.setdefault("long_walks", "auto")     # real terrain: long downslope walks are finished with skip tables
     ch = Chain(H, W, ctx=ctx, px=px, **kw)
     t1 = time.perf_counter()
     d_dem = ctx.to_device(dem32)
@@ -281,6 +322,7 @@ def run_host(dem, px, timings=None, **kw):
     t2 = t3 = t4 = time.perf_counter()
     try:
         ch.run(d_dem.ptr)
+        ch.finish_long_walks()
         # rasters come back into page-locked host memory from a recycling pool (device.PinnedPool): the copies are
         # the cost of this call, not the kernels.  Copies are only enqueued: raster k crosses PCIe while the host
         # block of raster k + 1 is being mapped and touched; one synchronisation at the end.

@@ -612,6 +612,15 @@ extern "C" int dt_dev_downslope(dt_ctx *c, const float *dem, const uint8_t *fdr,
 extern "C" int64_t dt_downslope_lift_workspace(int64_t H, int64_t W) {
   return (H <= 0 || W <= 0) ? 0 : (int64_t)dt_downslope_lift_bytes(H, W);
 }
+extern "C" int64_t dt_downslope_queue_workspace(int64_t H, int64_t W) {
+  return (H <= 0 || W <= 0) ? 0 : (int64_t)dt_downslope_queue_bytes(H, W);
+}
+extern "C" int64_t dt_downslope_tables_workspace(int64_t H, int64_t W) {
+  return (H <= 0 || W <= 0) ? 0 : (int64_t)dt_downslope_tables_bytes(H, W);
+}
+extern "C" int64_t dt_downslope_tables_threshold(int64_t H, int64_t W) {
+  return (H <= 0 || W <= 0) ? 0 : (int64_t)dt_downslope_lift_min(H, W);
+}
 // dt_dev_downslope with the long-walk acceleration (dt_kernels.hip, DsQueue): `work` = dt_downslope_lift_workspace
 // bytes of device memory, the caller's for the duration of the call's kernels
 extern "C" int dt_dev_downslope_lift(dt_ctx *c, const float *dem, const uint8_t *fdr, int64_t H, int64_t W, double px,
@@ -621,7 +630,43 @@ extern "C" int dt_dev_downslope_lift(dt_ctx *c, const float *dem, const uint8_t 
   DT_REQUIRE((dem && fdr && out) || H * W == 0, "NULL raster");
   DT_REQUIRE(work != nullptr && work_bytes >= dt_downslope_lift_workspace(H, W), "downslope workspace missing or too small");
   DT_TRY(dt_launch_downslope(c->stream, dt_full_window(H, W), dem, fdr, px, dz, raw, out, nullptr, work,
-                             (size_t)work_bytes));
+                             (char *)work + dt_downslope_queue_bytes(H, W), 0));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+// The same in two steps, for callers that may synchronise in between and want the 48 bytes per cell of the tables only
+// for rasters that need them: dt_dev_downslope_queue runs the window kernel and queues the long walks (qwork:
+// dt_downslope_queue_workspace bytes), dt_dev_downslope_queued waits and says how many there are,
+// dt_dev_downslope_finish finishes them -- with skip tables when twork (dt_downslope_tables_workspace bytes) is given
+// and at least dt_downslope_tables_threshold walks are queued, move by move otherwise.
+extern "C" int dt_dev_downslope_queue(dt_ctx *c, const float *dem, const uint8_t *fdr, int64_t H, int64_t W, double px,
+                                      double dz, int raw, float *out, void *qwork, int64_t qbytes) {
+  DT_CTX(c);
+  DT_TRY(dt_check_hw(H, W));
+  DT_REQUIRE((dem && fdr && out) || H * W == 0, "NULL raster");
+  DT_REQUIRE(qwork != nullptr && qbytes >= dt_downslope_queue_workspace(H, W), "queue workspace missing or too small");
+  DT_TRY(dt_launch_downslope(c->stream, dt_full_window(H, W), dem, fdr, px, dz, raw, out, nullptr, qwork, nullptr, 1));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+extern "C" int dt_dev_downslope_queued(dt_ctx *c, const void *qwork, int64_t *count) {
+  DT_CTX(c);
+  DT_REQUIRE(qwork && count, "NULL pointer");
+  uint32_t n = 0;
+  DT_HIP(hipMemcpyAsync(&n, qwork, sizeof(n), hipMemcpyDeviceToHost, c->stream));
+  DT_HIP(hipStreamSynchronize(c->stream));
+  *count = (int64_t)n;
+  return DT_OK;
+}
+extern "C" int dt_dev_downslope_finish(dt_ctx *c, const float *dem, const uint8_t *fdr, int64_t H, int64_t W, double px,
+                                       double dz, int raw, float *out, void *qwork, int64_t qbytes, void *twork,
+                                       int64_t tbytes) {
+  DT_CTX(c);
+  DT_TRY(dt_check_hw(H, W));
+  DT_REQUIRE((dem && fdr && out) || H * W == 0, "NULL raster");
+  DT_REQUIRE(qwork != nullptr && qbytes >= dt_downslope_queue_workspace(H, W), "queue workspace missing or too small");
+  DT_REQUIRE(twork == nullptr || tbytes >= dt_downslope_tables_workspace(H, W), "tables workspace too small");
+  DT_TRY(dt_launch_downslope(c->stream, dt_full_window(H, W), dem, fdr, px, dz, raw, out, nullptr, qwork, twork, 2));
   DT_HIP(hipGetLastError());
   return DT_OK;
 }
@@ -1449,12 +1494,24 @@ extern "C" int dt_downslope(const float *dem, const uint8_t *fdr, int64_t H, int
   DT_TRY(d_o.alloc(n * 4));
   H2D(d_dem, dem, n * 4, c);
   H2D(d_f, fdr, n, c);
-  // with the long-walk workspace when the device has room for it (real, conditioned rasters walk thousands of moves
-  // through flats and along valley floors); the plain kernel otherwise
-  const size_t lift = dt_flow_impl() == 1 ? 0 : (size_t)dt_downslope_lift_workspace(H, W);
-  if (lift && d_w.alloc(lift) == DT_OK) {
-    DT_TRY(dt_dev_downslope_lift(c, d_dem.as<float>(), d_f.as<uint8_t>(), H, W, px, dz, raw, d_o.as<float>(), d_w.p,
-                                 (int64_t)lift));
+  // Long walks (real, conditioned rasters walk thousands of moves through flats and along valley floors) are queued;
+  // this call is synchronous anyway, so it looks at the queue and allocates the skip tables only for a raster that
+  // has enough of them.  The plain kernel when the device has no room for the queue.
+  const size_t qb = dt_flow_impl() == 1 ? 0 : (size_t)dt_downslope_queue_workspace(H, W);
+  if (qb && d_w.alloc(qb) == DT_OK) {
+    DT_TRY(dt_dev_downslope_queue(c, d_dem.as<float>(), d_f.as<uint8_t>(), H, W, px, dz, raw, d_o.as<float>(), d_w.p,
+                                  (int64_t)qb));
+    int64_t queued = 0;
+    DT_TRY(dt_dev_downslope_queued(c, d_w.p, &queued));
+    if (queued > 0) {
+      DevBuf d_t;
+      const size_t tb = (size_t)dt_downslope_tables_workspace(H, W);
+      const bool tables = queued >= dt_downslope_tables_threshold(H, W) && d_t.alloc(tb) == DT_OK;
+      DT_TRY(dt_dev_downslope_finish(c, d_dem.as<float>(), d_f.as<uint8_t>(), H, W, px, dz, raw, d_o.as<float>(), d_w.p,
+                                     (int64_t)qb, tables ? d_t.p : nullptr, tables ? (int64_t)tb : 0));
+      D2H(out, d_o, n * 4, c);
+      return dt_ctx_sync(c);  // (d_t lives until here)
+    }
   } else {
     DT_TRY(dt_dev_downslope(c, d_dem.as<float>(), d_f.as<uint8_t>(), H, W, px, dz, raw, d_o.as<float>()));
   }

@@ -30,9 +30,12 @@ int dt_launch_ds_walkers(hipStream_t s, const DtWin &w, const float *dem, const 
                          int64_t n, int32_t *gy, int32_t *gx, int32_t *moves, double *dist, const float *z0, float *value,
                          int32_t *status);
 size_t dt_downslope_lift_bytes(int64_t H, int64_t W);
+size_t dt_downslope_queue_bytes(int64_t H, int64_t W);
+size_t dt_downslope_tables_bytes(int64_t H, int64_t W);
+uint32_t dt_downslope_lift_min(int64_t H, int64_t W);
 int dt_launch_downslope(hipStream_t s, const DtWin &w, const float *dem, const uint8_t *fdr, double px,
-                        double dz, int raw, float *out, int *n_unresolved, void *lift = nullptr,
-                        size_t lift_bytes = 0);
+                        double dz, int raw, float *out, int *n_unresolved, void *qwork = nullptr,
+                        void *twork = nullptr, int phase = 0);
 int dt_launch_downslope_v1(hipStream_t s, const float *dem, const uint8_t *fdr, int64_t H, int64_t W,
                            double px, double dz, int raw, float *out);
 int dt_launch_hand_i64(hipStream_t s, const float *dem, const int64_t *idx, int64_t n, float *hand);

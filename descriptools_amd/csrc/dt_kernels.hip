@@ -1060,16 +1060,22 @@ int dt_launch_ds_walkers(hipStream_t s, const DtWin &w, const float *dem, const 
   return DT_OK;
 }
 
-// workspace of the long-walk acceleration for an H x W raster: counter | queue (one entry per two cells) | two
-// skip tables
+// workspaces of the long-walk acceleration for an H x W raster: the QUEUE (counter | one entry per two cells) and the
+// TABLES (two ping-pong skip tables and the 8-move table that is kept); dt_downslope_lift_bytes = both, back to back
 static size_t ds_queue_capacity(int64_t H, int64_t W) { return (size_t)((H * W + 1) / 2); }
+size_t dt_downslope_queue_bytes(int64_t H, int64_t W) { return 256 + dt_align256(ds_queue_capacity(H, W) * 16); }
+size_t dt_downslope_tables_bytes(int64_t H, int64_t W) { return 3 * dt_align256((size_t)H * W * 16); }
 size_t dt_downslope_lift_bytes(int64_t H, int64_t W) {
-  return 256 + dt_align256(ds_queue_capacity(H, W) * 16) + 3 * dt_align256((size_t)H * W * 16);
+  return dt_downslope_queue_bytes(H, W) + dt_downslope_tables_bytes(H, W);
 }
-// lift (optional, dt_downslope_lift_bytes; single rasters only -- a rank window's walks leave its memory): long walks
-// are queued and finished with a skip table (see DsQueue)
+uint32_t dt_downslope_lift_min(int64_t H, int64_t W) { return (uint32_t)std::max<int64_t>(DS_LIFT_MIN, H * W / 128); }
+// qwork / twork (optional; single rasters only -- a rank window's walks leave its memory): long walks are queued and
+// finished with skip tables (see DsQueue).  phase 0: everything; 1: the window kernel with the queue only; 2: the
+// tables (when twork is given; built only if enough walks were queued) and the queued walks -- so that a caller who may
+// synchronise can look at the queue's counter (the first word of qwork) after phase 1 and allocate tables only when a
+// raster needs them.
 int dt_launch_downslope(hipStream_t s, const DtWin &w, const float *dem, const uint8_t *fdr, double px,
-                        double dz, int raw, float *out, int *n_unresolved, void *lift, size_t lift_bytes) {
+                        double dz, int raw, float *out, int *n_unresolved, void *qwork, void *twork, int phase) {
   const int64_t H = w.H, W = w.W;
   int64_t n = H * W;
   if (n == 0) return DT_OK;
@@ -1081,51 +1087,58 @@ int dt_launch_downslope(hipStream_t s, const DtWin &w, const float *dem, const u
   DsQueue q;
   uint4 *tab[3] = {nullptr, nullptr, nullptr};  // two ping-pong tables and the 8-move table that is kept
   const bool single = w.halo == 0 && w.gy0 == 0 && w.gx0 == 0 && w.Hg == w.H && w.Wg == w.W && w.ld == w.W;
-  if (lift && single && n < 0x7FFFFFFFll) {
-    DT_REQUIRE(lift_bytes >= dt_downslope_lift_bytes(H, W), "downslope workspace too small");
-    q.count = (uint32_t *)lift;
-    q.entries = (uint4 *)((char *)lift + 256);
-    q.capacity = (uint32_t)ds_queue_capacity(H, W);
-    tab[0] = (uint4 *)((char *)lift + 256 + dt_align256((size_t)q.capacity * 16));
-    tab[1] = (uint4 *)((char *)tab[0] + dt_align256((size_t)n * 16));
-    tab[2] = (uint4 *)((char *)tab[1] + dt_align256((size_t)n * 16));
-    DT_HIP(hipMemsetAsync(q.count, 0, sizeof(uint32_t), s));
-  }
   // margin of the LDS window around the 64 x 64 core: walks that reach the window's ring carry on in global memory
   const int m = dt_debug_get(DT_DBG_DS_MARGIN);
-  if (m == 16 || m == 20) q = DsQueue();  // the A/B margins run without the queue
-  if (m == 16)
-    hipLaunchKernelGGL(k_downslope_win<16>, dim3((unsigned)ntiles), dim3(1024), 0, s, dem, fdr, w, px, dz, dzf, raw,
-                       out, tiles_x, (int)ntiles, n_unresolved);
-  else if (m == 20)
-    hipLaunchKernelGGL(k_downslope_win<20>, dim3((unsigned)ntiles), dim3(1024), 0, s, dem, fdr, w, px, dz, dzf, raw,
-                       out, tiles_x, (int)ntiles, n_unresolved);
-  else if (!(w.halo == 0 && w.gy0 == 0 && w.gx0 == 0 && w.Hg == w.H && w.Wg == w.W))
-    hipLaunchKernelGGL(k_downslope_win_r, dim3((unsigned)ntiles), dim3(1024), 0, s, dem, fdr, w, px, dz, dzf, raw, out,
-                       tiles_x, (int)ntiles, n_unresolved);
-  else if (q.entries)
-    hipLaunchKernelGGL(k_downslope_win_q, dim3((unsigned)ntiles), dim3(1024), 0, s, dem, fdr, w, px, dz, dzf, raw, out,
-                       tiles_x, (int)ntiles, n_unresolved, q);
-  else
-    hipLaunchKernelGGL(k_downslope_win<24>, dim3((unsigned)ntiles), dim3(1024), 0, s, dem, fdr, w, px, dz, dzf, raw,
-                       out, tiles_x, (int)ntiles, n_unresolved);
-  if (q.entries) {
-    // every kernel of the table returns at once when fewer than DS_LIFT_MIN walks were queued
+  if (qwork && single && n < 0x7FFFFFFFll && m != 16 && m != 20) {  // (the A/B margins run without the queue)
+    q.count = (uint32_t *)qwork;
+    q.entries = (uint4 *)((char *)qwork + 256);
+    q.capacity = (uint32_t)ds_queue_capacity(H, W);
+    if (twork) {
+      tab[0] = (uint4 *)twork;
+      tab[1] = (uint4 *)((char *)tab[0] + dt_align256((size_t)n * 16));
+      tab[2] = (uint4 *)((char *)tab[1] + dt_align256((size_t)n * 16));
+    }
+  }
+  DT_REQUIRE(phase == 0 || q.entries, "the phases of the long-walk form need a single raster and its queue workspace");
+  if (phase != 2) {
+    if (q.entries) DT_HIP(hipMemsetAsync(q.count, 0, sizeof(uint32_t), s));
+    if (m == 16)
+      hipLaunchKernelGGL(k_downslope_win<16>, dim3((unsigned)ntiles), dim3(1024), 0, s, dem, fdr, w, px, dz, dzf, raw,
+                         out, tiles_x, (int)ntiles, n_unresolved);
+    else if (m == 20)
+      hipLaunchKernelGGL(k_downslope_win<20>, dim3((unsigned)ntiles), dim3(1024), 0, s, dem, fdr, w, px, dz, dzf, raw,
+                         out, tiles_x, (int)ntiles, n_unresolved);
+    else if (!(w.halo == 0 && w.gy0 == 0 && w.gx0 == 0 && w.Hg == w.H && w.Wg == w.W))
+      hipLaunchKernelGGL(k_downslope_win_r, dim3((unsigned)ntiles), dim3(1024), 0, s, dem, fdr, w, px, dz, dzf, raw,
+                         out, tiles_x, (int)ntiles, n_unresolved);
+    else if (q.entries)
+      hipLaunchKernelGGL(k_downslope_win_q, dim3((unsigned)ntiles), dim3(1024), 0, s, dem, fdr, w, px, dz, dzf, raw,
+                         out, tiles_x, (int)ntiles, n_unresolved, q);
+    else
+      hipLaunchKernelGGL(k_downslope_win<24>, dim3((unsigned)ntiles), dim3(1024), 0, s, dem, fdr, w, px, dz, dzf, raw,
+                         out, tiles_x, (int)ntiles, n_unresolved);
+  }
+  if (q.entries && phase != 1) {
     const dim3 gn((unsigned)((n + 255) / 256)), b(256);
-    const uint32_t lift_min = (uint32_t)std::max<int64_t>(DS_LIFT_MIN, n / 128);
-    hipLaunchKernelGGL(k_ds_lift_init, gn, b, 0, s, dem, fdr, w, tab[0], (const uint32_t *)q.count, lift_min);
-    // 1 -> 2 -> 4 -> 8 (kept in tab[2]) -> 16 -> 32 -> 64 moves per skip
-    uint4 *src = tab[0], *dst = tab[1];
-    for (int k = 0; k < DS_LIFT_LOG; k++) {
-      uint4 *to = k == 2 ? tab[2] : dst;
-      hipLaunchKernelGGL(k_ds_lift_double, gn, b, 0, s, (const uint4 *)src, to, (long long)n, (const uint32_t *)q.count,
-                         lift_min);
-      if (k == 2) {
-        src = tab[2];  // the next round reads the kept table and writes a ping-pong one
-      } else {
-        uint4 *was = src;
-        src = to;
-        dst = was == tab[2] ? (to == tab[0] ? tab[1] : tab[0]) : was;
+    const uint32_t lift_min = dt_downslope_lift_min(H, W);
+    uint4 *src = nullptr;
+    if (tab[0]) {
+      // every kernel of the tables returns at once when fewer than lift_min walks were queued
+      hipLaunchKernelGGL(k_ds_lift_init, gn, b, 0, s, dem, fdr, w, tab[0], (const uint32_t *)q.count, lift_min);
+      // 1 -> 2 -> 4 -> 8 (kept in tab[2]) -> 16 -> 32 -> 64 moves per skip
+      uint4 *dst = tab[1];
+      src = tab[0];
+      for (int k = 0; k < DS_LIFT_LOG; k++) {
+        uint4 *to = k == 2 ? tab[2] : dst;
+        hipLaunchKernelGGL(k_ds_lift_double, gn, b, 0, s, (const uint4 *)src, to, (long long)n,
+                           (const uint32_t *)q.count, lift_min);
+        if (k == 2) {
+          src = tab[2];  // the next round reads the kept table and writes a ping-pong one
+        } else {
+          uint4 *was = src;
+          src = to;
+          dst = was == tab[2] ? (to == tab[0] ? tab[1] : tab[0]) : was;
+        }
       }
     }
     const unsigned fin_blocks = (unsigned)std::min<size_t>((q.capacity + 255) / 256, 8192);

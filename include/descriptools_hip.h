@@ -264,6 +264,19 @@ int dt_dev_downslope(dt_ctx *ctx, const float *dem, const uint8_t *fdr, int64_t 
 int64_t dt_downslope_lift_workspace(int64_t H, int64_t W);
 int dt_dev_downslope_lift(dt_ctx *ctx, const float *dem, const uint8_t *fdr, int64_t H, int64_t W, double px,
                           double dz, int raw, float *out, void *work, int64_t work_bytes);
+/* The same in two steps, for callers that may synchronise in between and want the tables' 48 bytes per cell only for
+ * rasters that need them: dt_dev_downslope_queue runs the window kernel and queues the long walks (qwork:
+ * dt_downslope_queue_workspace bytes, 8 per cell); dt_dev_downslope_queued waits for it and returns their number;
+ * dt_dev_downslope_finish finishes them -- with skip tables when twork (dt_downslope_tables_workspace bytes) is given
+ * and at least dt_downslope_tables_threshold walks are queued, move by move otherwise (twork may be NULL). */
+int64_t dt_downslope_queue_workspace(int64_t H, int64_t W);
+int64_t dt_downslope_tables_workspace(int64_t H, int64_t W);
+int64_t dt_downslope_tables_threshold(int64_t H, int64_t W);
+int dt_dev_downslope_queue(dt_ctx *ctx, const float *dem, const uint8_t *fdr, int64_t H, int64_t W, double px,
+                           double dz, int raw, float *out, void *qwork, int64_t qbytes);
+int dt_dev_downslope_queued(dt_ctx *ctx, const void *qwork, int64_t *count);
+int dt_dev_downslope_finish(dt_ctx *ctx, const float *dem, const uint8_t *fdr, int64_t H, int64_t W, double px,
+                            double dz, int raw, float *out, void *qwork, int64_t qbytes, void *twork, int64_t tbytes);
 /* counts4_dev: device int64[nth*4], zeroed by the call */
 int dt_dev_confusion_multi(dt_ctx *ctx, const double *desc, const int8_t *flood, int64_t N,
                            double nodata_value, const double *th_host, int nth, int under,

@@ -146,3 +146,20 @@ def test_chain_with_long_walks_on_the_example():
     for x in (d, f, a, b, work):
         x.free()
     ctx.close()
+
+
+def test_run_host_finishes_long_walks_by_itself():
+    """chain.run_host (long_walks="auto"): the walks are queued by the step and finished before the rasters come back
+    -- with tables on terrain full of long walks, without on terrain that has none; same downslope raster as the
+    host-tier function in both cases"""
+    import oracle
+    import descriptools_amd.downslope as downslope
+    from descriptools_amd import chain
+    H, W = 400, 600
+    yy, xx = np.mgrid[0:H, 0:W]
+    gentle = (200.0 - 0.001 * xx - 0.0002 * yy).astype(np.float32)   # every walk is long
+    rough = oracle.synth_dem(3, 2048, 2048, 100, 100, H, W, 2)        # none is
+    for dem in (gentle, rough):
+        out = chain.run_host(dem, 1.0)
+        _same(out["down"], downslope.downsloper(dem, out["fdr"], 1.0, 5.0))
+        _same(out["down"], oracle.downslope(dem, out["fdr"], 1.0, 5.0))
