@@ -862,7 +862,7 @@ __device__ __forceinline__ void ds_win_body(const float *__restrict__ dem,
       uint64_t sv;
       asm volatile(
           "s_mov_b64 %[sv], exec\n\t"
-          "s_movk_i32 %[cnt], 255\n\t"
+          "s_movk_i32 %[cnt], %[cap]\n\t"
           "v_cmpx_gt_f32 vcc, %[dzf], %[drop]\n\t"
           "v_cmpx_gt_u32 vcc, 0x8000, %[mw]\n\t"
           "s_cbranch_execz 2f\n"
@@ -885,7 +885,10 @@ __device__ __forceinline__ void ds_win_body(const float *__restrict__ dem,
           : [q2] "+v"(q2), [mw] "+v"(mw), [acc] "+v"(acc), [drop] "+v"(drop), [t] "=&v"(t), [zt] "=&v"(zt),
             [sv] "=&s"(sv), [cnt] "=&s"(cnt)
           : [z0] "v"(z0), [dzf] "s"(dzf), [nbias] "s"(0u - (uint32_t)MW_BIAS), [n2l] "s"(neg2lds0),
-            [k19] "s"(1u << 19), [woff] "n"(DW_LD * DW_WIN * 4)
+            [k19] "s"(1u << 19), [woff] "n"(DW_LD * DW_WIN * 4),
+            // with the queue a walk still running after 32 moves is a long one: hand it over at once (the lanes that
+            // are done wait for the wave's longest walk)
+            [cap] "n"(QUEUE ? 31 : 255)
           : "vcc", "scc", "memory");
     }
     uint32_t loop = acc >> 19;  // moves made
