@@ -28,6 +28,13 @@
 #define H_INF_DIST 0x7FFFFFFFu
 
 __device__ __forceinline__ bool hy_nodata(float z) { return z == DT_NODATA; }
+// v of the lane before / after mine; `edge` for lane 0 / 63 (wave_shr:1 / wave_shl:1 keep the old value there)
+__device__ __forceinline__ float hy_from_prev_lane(float edge, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), 0x138, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float hy_from_next_lane(float edge, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), 0x130, 0xF, 0xF, false));
+}
 
 // W = z on outlets (edge of the GLOBAL raster / next to nodata), +inf on the other valid cells, nodata stays nodata.
 // Windowed like every tile kernel: the core of `w`, neighbours read from the halo where the core ends inside the raster.
@@ -145,24 +152,46 @@ __global__ __launch_bounds__(256) void k_fill_relax(const float *__restrict__ de
   // (it is in its own 3 x 3 neighbourhood), so iterating it to its local fixed point here only re-proves, with one
   // more round of sweeps, what the next visit proves as well (Example: 3.7 -> 2.1 ms, rough 8192^2: 25 -> 18 ms, a few
   // more global rounds, the same surface).
+  // A step's dependent chain is short: the line the sweep comes from is in REGISTERS (a lane's own previous result,
+  // its two neighbours' through DPP; the halo cells beside the edge lanes from LDS), the line it stands on and the
+  // line ahead were fetched a step earlier (the line ahead of this step IS the next step's line), and the one fresh
+  // read of the cell itself -- another wave may have lowered it since -- only gates the store.  ~15 vector
+  // instructions per step instead of two LDS round trips.
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bool by_rows = !(wave & 2);                 // waves 0 / 1 walk rows (a lane per column), 2 / 3 columns
+  const int dir = (wave & 1) ? -1 : 1;
+  const int SA = by_rows ? dir * HLD : dir;         // one step along the sweep
+  const int SC = by_rows ? 1 : HLD;                 // one lane across it
+  const int ZA = by_rows ? dir * HT : dir;
+  const int k0 = (wave & 1) ? HT - 1 : 0;
+  int p = by_rows ? (k0 + 1) * HLD + lane + 1 : (lane + 1) * HLD + k0 + 1;
+  int zi = by_rows ? k0 * HT + lane : lane * HT + k0;
+  float up = s_w[p - SA];                              // the line before the tile (halo: nobody writes it)
+  float hl = s_w[p - SA - SC], hr = s_w[p - SA + SC];  // its cells beside lanes 0 / 63
+  float cur = s_w[p], lf = s_w[p - SC], rt = s_w[p + SC];
   int any = 0;
   {
     int ch = 0;
     for (int step = 0; step < HT; step++) {
-      const int k = (wave & 1) ? HT - 1 - step : step;
-      const int ly = (wave & 2) ? lane : k, lx = (wave & 2) ? k : lane;
-      // all ten reads of a step are issued together (one LDS round trip on the step's dependent chain, not two)
-      const int p = (ly + 1) * HLD + lx + 1;
-      const float zc = s_z[ly * HT + lx];
-      const float cur = s_w[p];
-      const float m = fminf(fminf(fminf(s_w[p - HLD - 1], s_w[p - HLD]), fminf(s_w[p - HLD + 1], s_w[p - 1])),
-                            fminf(fminf(s_w[p + 1], s_w[p + HLD - 1]), fminf(s_w[p + HLD], s_w[p + HLD + 1])));
+      const float fresh = s_w[p];
+      const float d0 = s_w[p + SA - SC], d1 = s_w[p + SA], d2 = s_w[p + SA + SC];
+      const float zc = s_z[zi];
+      const float upm = hy_from_prev_lane(hl, up), upp = hy_from_next_lane(hr, up);
+      const float m = fminf(fminf(fminf(upm, up), fminf(upp, lf)), fminf(fminf(rt, d0), fminf(d1, d2)));
       const float nw = fmaxf(zc, m);
-      if (!hy_nodata(zc) && nw < cur) {  // (cur == zc cannot get lower: nw >= zc)
+      const bool valid = !hy_nodata(zc);
+      if (valid && nw < fresh) {  // (a value equal to its height cannot get lower: nw >= zc)
         s_w[p] = nw;
         ch = 1;
       }
+      up = (valid && nw < cur) ? nw : cur;  // what this lane leaves behind, without waiting for `fresh`
+      hl = lf;   // the next step's line before is this line: beside lanes 0 / 63 lie its halo cells
+      hr = rt;
+      cur = d1;
+      lf = d0;
+      rt = d2;
+      p += SA;
+      zi += ZA;
     }
     any = __syncthreads_or(ch);
   }
