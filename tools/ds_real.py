@@ -14,7 +14,7 @@ L = _lib.lib()
 ex = load_example()
 dem0, fdr0 = np.asarray(ex[0], np.float32), np.ascontiguousarray(ex[1], np.uint8)
 ctx = Context()
-for rep in (1, 4):
+for rep in ((1, 4, 8) if len(sys.argv) > 1 and sys.argv[1] == 'big' else (1, 4)):
     dem, fdr = np.tile(dem0, (rep, rep)), np.tile(fdr0, (rep, rep))
     H, W = dem.shape
     d, f = ctx.to_device(dem), ctx.to_device(fdr)
