@@ -504,7 +504,7 @@ __global__ __launch_bounds__(256) void k_downslope(const float *__restrict__ dem
 // move -- and the kernel lasts as long as its longest walk.  With a workspace (dt_downslope_lift_bytes) such walks
 // are queued as soon as they leave the window and finished by k_ds_finish with a SKIP TABLE: for every cell, where the
 // walk stands 64 moves on (or where it cannot go on), how many of those moves are diagonal, and the lowest height on
-// the way -- built by six rounds of pointer doubling, only when the queue holds at least DS_LIFT_MIN walks and one
+// the way -- the 8-move table by walking, three rounds of pointer doubling from there, only when the queue holds at least DS_LIFT_MIN walks and one
 // cell in 128 (fewer are walked out move by move by k_ds_finish: the table costs a pass over the raster).  A skip is
 // taken when no cell of it can end the walk: the lowest height still leaves the drop below dz (the float32
 // subtraction is monotone in the height, so the test on the minimum is exact), no move of it fails, and the 5000-move
@@ -513,7 +513,6 @@ __global__ __launch_bounds__(256) void k_downslope(const float *__restrict__ dem
 // exit of the reference's walk keeps its exact meaning.
 #define DS_Q_MOVES 0u /* global moves a walk makes in the window kernel before it is queued (the kernel's waves wait for them) */
 #define DS_LIFT_MIN 256u /* and at least one cell in 128: the table costs ~340 bytes of traffic per CELL of the raster */
-#define DS_LIFT_LOG 6
 struct DsQueue {
   uint4 *entries;     // {start cell, cell the walk stands on (both y * W + x), moves made, diagonal moves}
   uint32_t *count;    // walks queued (may exceed capacity: the excess stayed in the main kernel)
@@ -926,28 +925,39 @@ __global__ __launch_bounds__(1024, 8) void k_downslope_win_q(const float *__rest
 
 // ---- skip table ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float ds_lift_z(float z) { return z != z ? -__builtin_inff() : z; }  // a NaN height ends a walk
-// one move from every cell (single raster: w is the full window)
+// the 8-move table straight from the rasters (single raster: w is the full window): a lane walks its cell's eight
+// moves itself -- neighbouring cells, cache hits -- instead of three rounds of doubling over one-move entries (each
+// round moves 48 bytes per cell)
 __global__ __launch_bounds__(256) void k_ds_lift_init(const float *__restrict__ dem, const uint8_t *__restrict__ fdr,
                                                      DtWin w, uint4 *__restrict__ T, const uint32_t *__restrict__ qcount, uint32_t lift_min) {
   if (*qcount < lift_min) return;
   const long long n = (long long)w.H * w.W;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const int y = (int)(i / w.W), x = (int)(i - (long long)y * w.W);
-  uint4 e = make_uint4((uint32_t)i, __float_as_uint(__builtin_inff()), 0u, DS_LIFT_STOP);
-  const uint32_t code = fdr[i];
-  if (dt_d8_valid(code)) {
+  int y = (int)(i / w.W), x = (int)(i - (long long)y * w.W);
+  long long pos = i;
+  float minz = __builtin_inff();
+  uint32_t len = 0, nd = 0, stop = 0;
+  uint32_t code = fdr[i];
+#pragma unroll 1
+  for (int k = 0; k < 8; k++) {
+    if (!dt_d8_valid(code)) { stop = DS_LIFT_STOP; break; }
     int dy, dx;
     dt_d8_delta(code, dy, dx);
     const int ny = y + dy, nx = x + dx;
-    if (ny >= 0 && ny < w.H && nx >= 0 && nx < w.W) {
-      const float zt = dem[(long long)ny * w.W + nx];
-      if (zt != DT_NODATA)
-        e = make_uint4((uint32_t)((long long)ny * w.W + nx), __float_as_uint(ds_lift_z(zt)),
-                       1u | ((dy != 0 && dx != 0) ? 0x10000u : 0u), 0u);
-    }
+    if (!(ny >= 0 && ny < w.H && nx >= 0 && nx < w.W)) { stop = DS_LIFT_STOP; break; }
+    const long long on = (long long)ny * w.W + nx;
+    const float zt = dem[on];
+    code = fdr[on];
+    if (zt == DT_NODATA) { stop = DS_LIFT_STOP; break; }
+    y = ny;
+    x = nx;
+    pos = on;
+    len++;
+    nd += (dy != 0 && dx != 0) ? 1u : 0u;
+    minz = fminf(minz, ds_lift_z(zt));
   }
-  T[i] = e;
+  T[i] = make_uint4((uint32_t)pos, __float_as_uint(minz), len | (nd << 16), stop);
 }
 // skips of 2 L moves from skips of L
 __global__ __launch_bounds__(256) void k_ds_lift_double(const uint4 *__restrict__ A, uint4 *__restrict__ B, long long n,
@@ -1127,22 +1137,15 @@ int dt_launch_downslope(hipStream_t s, const DtWin &w, const float *dem, const u
     uint4 *src = nullptr;
     if (tab[0]) {
       // every kernel of the tables returns at once when fewer than lift_min walks were queued
-      hipLaunchKernelGGL(k_ds_lift_init, gn, b, 0, s, dem, fdr, w, tab[0], (const uint32_t *)q.count, lift_min);
-      // 1 -> 2 -> 4 -> 8 (kept in tab[2]) -> 16 -> 32 -> 64 moves per skip
-      uint4 *dst = tab[1];
+      // 8 moves per skip (tab[2], kept) -> 16 -> 32 -> 64
+      hipLaunchKernelGGL(k_ds_lift_init, gn, b, 0, s, dem, fdr, w, tab[2], (const uint32_t *)q.count, lift_min);
+      hipLaunchKernelGGL(k_ds_lift_double, gn, b, 0, s, (const uint4 *)tab[2], tab[0], (long long)n,
+                         (const uint32_t *)q.count, lift_min);
+      hipLaunchKernelGGL(k_ds_lift_double, gn, b, 0, s, (const uint4 *)tab[0], tab[1], (long long)n,
+                         (const uint32_t *)q.count, lift_min);
+      hipLaunchKernelGGL(k_ds_lift_double, gn, b, 0, s, (const uint4 *)tab[1], tab[0], (long long)n,
+                         (const uint32_t *)q.count, lift_min);
       src = tab[0];
-      for (int k = 0; k < DS_LIFT_LOG; k++) {
-        uint4 *to = k == 2 ? tab[2] : dst;
-        hipLaunchKernelGGL(k_ds_lift_double, gn, b, 0, s, (const uint4 *)src, to, (long long)n,
-                           (const uint32_t *)q.count, lift_min);
-        if (k == 2) {
-          src = tab[2];  // the next round reads the kept table and writes a ping-pong one
-        } else {
-          uint4 *was = src;
-          src = to;
-          dst = was == tab[2] ? (to == tab[0] ? tab[1] : tab[0]) : was;
-        }
-      }
     }
     const unsigned fin_blocks = (unsigned)std::min<size_t>((q.capacity + 255) / 256, 8192);
     hipLaunchKernelGGL(k_ds_finish, dim3(fin_blocks), b, 0, s, dem, fdr, w, px, dz, dzf, raw, out, q, (const uint4 *)src,
