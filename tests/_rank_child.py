@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--halo", default="synth", choices=["synth", "exchange"])
     ap.add_argument("--overlap", type=int, default=0)
     ap.add_argument("--force-world", type=int, default=0)
+    ap.add_argument("--terrain", default="synth", choices=["synth", "plane"])
     a = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -35,7 +36,13 @@ def main():
     layout = tiling.Layout.uniform(world, a.h, a.w)
     thr = (layout.Hg * layout.Wg) // 512
     tile = tiling.RankTile(layout, rank, device=0, px=10.0, river_threshold=thr)
-    if a.halo == "synth":
+    if a.terrain == "plane":
+        # a 1 per mille plane: every downslope walk is thousands of moves long and crosses the rank borders
+        h = tiling.HALO
+        y0, x0 = layout.origin(rank)
+        yy, xx = np.mgrid[y0 - h:y0 + tile.H + h, x0 - h:x0 + tile.W + h]
+        tile.set_dem_ext((200.0 - 0.001 * xx - 0.0002 * yy).astype(np.float32))
+    elif a.halo == "synth":
         tile.synth_dem(a.seed, a.nodata)
     else:
         import oracle  # test infrastructure: the same generator on the host
@@ -50,6 +57,9 @@ def main():
     for _ in range(2):  # twice: the step reuses its buffers
         tiling.run_rank(tile, layout, exchange, overlap=bool(a.overlap))
     tile.check_status()
+    # walks that left this rank's memory travel on as walkers (none on the synthetic terrain: returns 0 at once)
+    sent = tiling.finish_downslope(tile, tiling.DistComm())
+    assert (sent > 0) == (a.terrain == "plane")
     assert tile.unresolved_downslope() == 0
     names = ["dem", "fdr", "fac", "river", "fdist", "idx", "hand", "slope", "ti", "mti", "gfi", "lnhlh", "down"]
     np.savez(os.path.join(a.out, "rank%d.npz" % rank), origin=np.array(layout.origin(rank)),

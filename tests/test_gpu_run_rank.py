@@ -38,9 +38,10 @@ def _launch(tmp_path, world, h, w, **kw):
     return [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
 
 
-def _check(parts, Hg, Wg, seed, nodata):
+def _check(parts, Hg, Wg, seed, nodata, dem=None):
     from descriptools_amd import chain
-    dem = oracle.synth_dem(seed, Hg, Wg, 0, 0, Hg, Wg, nodata)
+    if dem is None:
+        dem = oracle.synth_dem(seed, Hg, Wg, 0, 0, Hg, Wg, nodata)
     ref = chain.run_host(dem, 10.0, river_threshold=(Hg * Wg) // 512)
     for r, p in enumerate(parts):
         y0, x0 = (int(v) for v in p["origin"])
@@ -65,6 +66,17 @@ def test_run_rank_gloo_ranks_sharing_the_gpu(tmp_path, world, h, w, nodata, halo
     from descriptools_amd import tiling
     layout = tiling.Layout.uniform(world, h, w)
     _check(parts, layout.Hg, layout.Wg, 5, nodata)
+
+
+def test_long_walks_travel_between_real_processes(tmp_path):
+    """a 1 per mille plane: every downslope walk leaves its rank; tiling.finish_downslope with DistComm (gloo) between
+    two real processes sends the walkers on -- all rasters equal the untiled chain's (chain.run_host finishes its own
+    long walks with the skip tables)"""
+    parts = _launch(tmp_path, 2, 256, 384, seed=1, nodata=0, terrain="plane")
+    from descriptools_amd import tiling
+    layout = tiling.Layout.uniform(2, 256, 384)
+    yy, xx = np.mgrid[0:layout.Hg, 0:layout.Wg]
+    _check(parts, layout.Hg, layout.Wg, 1, 0, dem=(200.0 - 0.001 * xx - 0.0002 * yy).astype(np.float32))
 
 
 def test_run_rank_rccl_single_rank(tmp_path):
