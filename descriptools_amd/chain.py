@@ -322,6 +322,7 @@ def run_host(dem, px, timings=None, **kw):
     t2 = t3 = t4 = time.perf_counter()
     try:
         ch.run(d_dem.ptr)
+        ch.check_status()  # (condition=True: raises when the budget of conditioning rounds was too small)
         ch.finish_long_walks()
         # rasters come back into page-locked host memory from a recycling pool (device.PinnedPool): the copies are
         # the cost of this call, not the kernels.  Copies are only enqueued: raster k crosses PCIe while the host

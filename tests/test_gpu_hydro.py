@@ -302,3 +302,28 @@ def test_example_conditioned_chain_in_ranks_equals_untiled():
             assert np.array_equal(got, want.astype(got.dtype), equal_nan=True), (t.rank, k, int((got != want).sum()))
         t.free()
     torch.cuda.empty_cache()
+
+
+def test_run_host_with_conditioning_on_the_example():
+    """chain.run_host(dem, px, condition=True): conditioning, the chain on the conditioned codes and the long downslope
+    walks (queued, finished with skip tables) in one host call -- the rasters of Chain(condition=True, long_walks=True);
+    a budget of rounds that is too small raises instead of returning unconditioned rasters"""
+    from conftest import load_example
+    from descriptools_amd import chain
+    from descriptools_amd.device import Context
+    dem = np.asarray(load_example()[0], np.float32)
+    H, W = dem.shape
+    out = chain.run_host(dem, 12.5, condition=True, condition_rounds=96)
+    ctx = Context()
+    d = ctx.to_device(dem)
+    ch = chain.Chain(H, W, ctx=ctx, px=12.5, condition=True, condition_rounds=96, long_walks=True, tune_placement=False)
+    ch.run(d.ptr)
+    ch.check_status()
+    for k in ("fdr", "fac", "hand", "down", "gfi"):
+        ref = ch.buf[k].to_host()
+        assert np.array_equal(out[k], ref.astype(out[k].dtype), equal_nan=True), k
+    ch.free()
+    d.free()
+    ctx.close()
+    with pytest.raises(RuntimeError, match="NOT_CONVERGED"):
+        chain.run_host(dem, 12.5, condition=True, condition_rounds=3)
