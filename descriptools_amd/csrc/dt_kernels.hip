@@ -511,7 +511,6 @@ __global__ __launch_bounds__(256) void k_downslope(const float *__restrict__ dem
 // cap is not reached within it; skips of 8 moves (the table of the third round, kept) follow, and the moves that
 // remain (< 8 + 8) are made one by one by the code above, so every
 // exit of the reference's walk keeps its exact meaning.
-#define DS_Q_MOVES 0u /* global moves a walk makes in the window kernel before it is queued (the kernel's waves wait for them) */
 #define DS_LIFT_MIN 256u /* and at least one cell in 128: the table costs ~340 bytes of traffic per CELL of the raster */
 struct DsQueue {
   uint4 *entries;     // {start cell, cell the walk stands on (both y * W + x), moves made, diagonal moves}
@@ -533,7 +532,7 @@ __device__ __forceinline__ void ds_finish_cell(const DtWin &w, const float *__re
                                                const uint8_t *__restrict__ fdr, int y0, int x0, float z0, float drop,
                                                uint32_t loop, uint32_t nd, bool stop_fail, int y, int x, double dcard,
                                                double ddiag, double dz, float dzf, int raw, float *__restrict__ outp,
-                                               int *__restrict__ n_unresolved, DsQueue q = DsQueue()) {
+                                               int *__restrict__ n_unresolved) {
   bool failed = false, slow = false, unresolved = false;
   bool cont = false;  // continue on global memory from the cell the fast walk stopped on
   if (drop < dzf) {
@@ -549,7 +548,6 @@ __device__ __forceinline__ void ds_finish_cell(const DtWin &w, const float *__re
     // The few walks that reach the window ring (0.006 % of the cells of the 16384^2 DEM, but one in seven
     // windows has one) go on from where they are, still only counting moves: a handful of global loads
     // instead of the whole walk again.
-    uint32_t budget = q.entries ? DS_Q_MOVES : 0xFFFFFFFFu;  // global moves before the walk is handed to the queue
     // the code of the cell the walk stands on is fetched together with the height of the cell before it: one memory
     // round trip per move on the walk's dependent chain, not two
     auto has_code = [&](int yy, int xx) { return RANKED ? dt_has_code(w, yy, xx) : dt_readable(w, yy, xx); };
@@ -557,23 +555,6 @@ __device__ __forceinline__ void ds_finish_cell(const DtWin &w, const float *__re
     while ((double)drop < dz) {
       // at the end of this rank's memory (the last ring of the halo has heights, not codes): another rank's walk
       if (!has_code(y, x)) { unresolved = true; break; }
-      if (budget-- == 0u) {
-        // A LONG walk (a flat, a valley floor: real conditioned terrain has walks of thousands of moves, each a
-        // dependent global load here): handed to k_ds_finish, which crosses it in skips of 64 moves.  A full queue
-        // keeps the walk here.
-        // one atomic per wave: the lanes that arrive here together count themselves, the first of them reserves
-        const unsigned long long act = __ballot(1);
-        const int leader = __ffsll((long long)act) - 1, lane = (int)(threadIdx.x & 63u);
-        uint32_t base = 0u;
-        if (lane == leader) base = atomicAdd(q.count, (uint32_t)__popcll(act));
-        base = (uint32_t)__shfl((int)base, leader);
-        const uint32_t slot = base + (uint32_t)__popcll(act & ((1ull << lane) - 1ull));
-        if (slot < q.capacity) {
-          q.entries[slot] = make_uint4((uint32_t)((long long)y0 * w.W + x0), (uint32_t)((long long)y * w.W + x), loop, nd);
-          return;
-        }
-        budget = 0xFFFFFFFFu;
-      }
       if (!dt_d8_valid(code)) { failed = true; break; }
       int dy, dx;
       dt_d8_delta(code, dy, dx);
@@ -648,6 +629,17 @@ __device__ __forceinline__ void ds_finish_cell(const DtWin &w, const float *__re
   else *outp = res;
 }
 
+// the rest of a walk that found the queue full, from the cell (of a single raster) it stands on
+__device__ __attribute__((noinline)) void ds_finish_overflow(const DtWin &w, const float *__restrict__ dem,
+                                                             const uint8_t *__restrict__ fdr, int y0, int x0, float z0,
+                                                             uint32_t loop, uint32_t nd, uint32_t pos, double px,
+                                                             double dz, float dzf, int raw, float *__restrict__ out,
+                                                             int *__restrict__ n_unresolved) {
+  const int y = (int)(pos / (uint32_t)w.W), x = (int)(pos - (uint32_t)y * (uint32_t)w.W);
+  ds_finish_cell<false>(w, dem, fdr, y0, x0, z0, z0 - dem[(long long)y * w.ld + x], loop, nd, false, y, x, px,
+                        px * sqrt(2.0), dz, dzf, raw, out + (long long)y0 * w.ld + x0, n_unresolved);
+}
+
 // Windowed version: a 1024-thread workgroup stages a 112 x 112 window (64 x 64 core + 24-cell
 // margin) in LDS as float32 heights plus one pre-decoded 16-bit "move word" per cell
 //   bits 0-9  BYTE offset of the D8 successor's move word from this cell's, biased by 512
@@ -689,6 +681,7 @@ __device__ __forceinline__ void ds_win_body(const float *__restrict__ dem,
   // address register)
   __shared__ __attribute__((aligned(16))) unsigned char smem[DW_LD * DW_WIN * 6];
   __shared__ uint16_t s_lut[256];
+  __shared__ uint32_t s_queued[2];  // QUEUE: walks this workgroup hands over, and where its block of the queue starts
   float *s_z = reinterpret_cast<float *>(smem);
   uint16_t *s_w = reinterpret_cast<uint16_t *>(smem + DW_LD * DW_WIN * 4);
   // LDS byte address of smem (0 when it is the kernel's only LDS object, but do not rely on it)
@@ -754,6 +747,7 @@ __device__ __forceinline__ void ds_win_body(const float *__restrict__ dem,
     }
     s_lut[code] = (uint16_t)mw;
   }
+  if (QUEUE && threadIdx.x == 0) s_queued[0] = 0u;
   __syncthreads();
   if (interior) {
 #pragma unroll
@@ -829,6 +823,9 @@ __device__ __forceinline__ void ds_win_body(const float *__restrict__ dem,
   __syncthreads();
   const double dcard = px, ddiag = px * sqrt(2.0);
   const uint32_t neg2lds0 = 0u - 2u * lds0 + lds0;  // z address = 2 * (q2 - lds0) + lds0 = (q2 << 1) + neg2lds0
+  // QUEUE: a thread's walks to hand over (bit j of pend: its j-th cell), where each stands and moves | diagonal ones << 16
+  uint32_t pend = 0u, pq0 = 0u, pq1 = 0u, pq2 = 0u, pq3 = 0u, pl0 = 0u, pl1 = 0u, pl2 = 0u, pl3 = 0u;
+  static_assert((DW_CORE * DW_CORE) / 1024 == 4, "four cells per thread");
   for (int j = 0; j < (DW_CORE * DW_CORE) / 1024; j++) {
     int c = threadIdx.x + 1024 * j;
     int cy = c / DW_CORE, cx = c - cy * DW_CORE;
@@ -894,9 +891,49 @@ __device__ __forceinline__ void ds_win_body(const float *__restrict__ dem,
     // sum of the move words = (q2 - q2_0) + MW_BIAS * moves + MW_DIAG * diagonal moves
     uint32_t nd = ((acc & 0x7FFFFu) - (q2 - q2_0) - (uint32_t)MW_BIAS * loop) / MW_DIAG;
     const uint32_t pos = (q2 - lds0) >> 1;
-    ds_finish_cell<RANKED>(w, dem, fdr, y0, x0, z0, drop, loop, nd, (mw & (MW_BADCODE | MW_EDGE)) != 0u,
-                   wy0 + (int)(pos / DW_LD), wx0 + (int)(pos % DW_LD), dcard, ddiag, dz, dzf, raw, out + o, n_unresolved,
-                   QUEUE ? queue : DsQueue());  // without a queue the code of the hand-over is not even compiled in
+    const int ys = wy0 + (int)(pos / DW_LD), xs = wx0 + (int)(pos % DW_LD);
+    const bool stop_fail = (mw & (MW_BADCODE | MW_EDGE)) != 0u;
+    if (QUEUE && drop < dzf && !stop_fail && dt_readable(w, ys, xs)) {
+      // A LONG walk (a flat, a valley floor: real conditioned terrain has walks of thousands of moves, each a
+      // dependent global load in ds_finish_cell): left for k_ds_finish, which crosses it in skips of 64 moves
+      const uint32_t pq = (uint32_t)((long long)ys * w.W + xs), pl = loop | (nd << 16);
+      if (j == 0) { pq0 = pq; pl0 = pl; }
+      else if (j == 1) { pq1 = pq; pl1 = pl; }
+      else if (j == 2) { pq2 = pq; pl2 = pl; }
+      else { pq3 = pq; pl3 = pl; }
+      pend |= 1u << j;
+      continue;
+    }
+    ds_finish_cell<RANKED>(w, dem, fdr, y0, x0, z0, drop, loop, nd, stop_fail, ys, xs, dcard, ddiag, dz, dzf, raw,
+                           out + o, n_unresolved);
+  }
+  if (QUEUE) {
+    // ONE global atomic per workgroup reserves its block of the queue (one per wave and pass -- 3 M of them on one
+    // address for a 214 M-cell raster -- took 4.3 of the kernel's 6.7 ms); inside the block the threads order
+    // themselves with an LDS atomic
+    const uint32_t mine = (uint32_t)__popc(pend);
+    uint32_t slot = 0u;
+    if (mine) slot = atomicAdd(&s_queued[0], mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_queued[0]) s_queued[1] = atomicAdd(queue.count, s_queued[0]);
+    __syncthreads();
+    slot += s_queued[1];
+    for (int j = 0; pend >> j; j++) {
+      if (!((pend >> j) & 1u)) continue;
+      const uint32_t pq = j == 0 ? pq0 : j == 1 ? pq1 : j == 2 ? pq2 : pq3;
+      const uint32_t pl = j == 0 ? pl0 : j == 1 ? pl1 : j == 2 ? pl2 : pl3;
+      const int c = threadIdx.x + 1024 * j;
+      const int cy = c / DW_CORE, cx = c - cy * DW_CORE;
+      const int y0 = tyi * DW_CORE + cy, x0 = txi * DW_CORE + cx;
+      if (slot < queue.capacity) {
+        queue.entries[slot] = make_uint4((uint32_t)((long long)y0 * w.W + x0), pq, pl & 0xFFFFu, pl >> 16);
+      } else {
+        // a full queue (more than half the raster's cells): the walk is made here after all
+        const float z0 = s_z[(cy + DW_M) * DW_LD + cx + DW_M];
+        ds_finish_overflow(w, dem, fdr, y0, x0, z0, pl & 0xFFFFu, pl >> 16, pq, px, dz, dzf, raw, out, n_unresolved);
+      }
+      slot++;
+    }
   }
 }
 

@@ -116,6 +116,10 @@ def test_long_walks_with_the_skip_table(env):
     ctx.sync()
     ra, rb = a.to_host(), b.to_host()
     assert np.array_equal(ra.view(np.int32), rb.view(np.int32)) and np.array_equal(ra, want, equal_nan=True)
+    # nearly every walk of this plane is a long one: more than the queue holds (half the cells), so this case also
+    # covers the walks a full queue leaves to the window kernel
+    queued = int(work.to_host()[:4].view(np.uint32)[0])
+    assert queued > (H * W + 1) // 2, queued
     for x in (d, f, a, b, work):
         x.free()
     ctx.close()
