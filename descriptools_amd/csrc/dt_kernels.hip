@@ -511,16 +511,26 @@ __global__ __launch_bounds__(256) void k_downslope(const float *__restrict__ dem
 // cap is not reached within it; skips of 8 moves (the table of the third round, kept) follow, and the moves that
 // remain (< 8 + 8) are made one by one by the code above, so every
 // exit of the reference's walk keeps its exact meaning.
-#define DS_LIFT_MIN 256u /* and at least one cell in 128: the table costs ~340 bytes of traffic per CELL of the raster */
+#define DS_LIFT_MIN 256u /* and at least one cell in 128: the table costs ~170 bytes of traffic per CELL of the raster */
 struct DsQueue {
   uint4 *entries;     // {start cell, cell the walk stands on (both y * W + x), moves made, diagonal moves}
   uint32_t *count;    // walks queued (may exceed capacity: the excess stayed in the main kernel)
   uint32_t capacity;
   __host__ __device__ DsQueue() : entries(nullptr), count(nullptr), capacity(0) {}
 };
-// skip-table entry: x = cell reached, y = float bits of the lowest height on the way (-inf for a NaN height),
-// z = moves | diagonal moves << 16, w = 1 when the walk cannot go on from the cell reached
-#define DS_LIFT_STOP 1u
+// skip-table entry, 8 bytes: y = float bits of the lowest height on the way (-inf for a NaN height); x = where the walk
+// stands after the skip RELATIVE to its start (a skip is at most 64 moves: row and column offsets + 64 in bits 0-7 and
+// 8-15), moves in bits 16-22, the diagonal ones in bits 23-29, bit 30 when the walk cannot go on from there.  (Round 3
+// began with 16-byte entries holding the cell index: every kernel of this path is bound by the bytes of its table.)
+#define DS_LIFT_STOP (1u << 30)
+#define DS_LIFT_BIAS2 (64u | (64u << 8))
+__device__ __forceinline__ uint32_t ds_lift_pack(int dy, int dx, uint32_t len, uint32_t nd) {
+  return (uint32_t)(dy + 64) | ((uint32_t)(dx + 64) << 8) | (len << 16) | (nd << 23);
+}
+__device__ __forceinline__ int ds_lift_dy(uint32_t e) { return (int)(e & 0xFFu) - 64; }
+__device__ __forceinline__ int ds_lift_dx(uint32_t e) { return (int)((e >> 8) & 0xFFu) - 64; }
+__device__ __forceinline__ uint32_t ds_lift_len(uint32_t e) { return (e >> 16) & 0x7Fu; }
+__device__ __forceinline__ uint32_t ds_lift_nd(uint32_t e) { return (e >> 23) & 0x7Fu; }
 
 // What one cell's fast walk in the LDS window hands over, turned into the stored value.  drop: z0 - z(cell the walk stands on) (+inf: it stepped onto nodata); loop / nd: moves
 // made / diagonal ones; stop_fail: the walk stopped on a cell that cannot be left (non-D8 code, move off the raster);
@@ -966,57 +976,60 @@ __device__ __forceinline__ float ds_lift_z(float z) { return z != z ? -__builtin
 // moves itself -- neighbouring cells, cache hits -- instead of three rounds of doubling over one-move entries (each
 // round moves 48 bytes per cell)
 __global__ __launch_bounds__(256) void k_ds_lift_init(const float *__restrict__ dem, const uint8_t *__restrict__ fdr,
-                                                     DtWin w, uint4 *__restrict__ T, const uint32_t *__restrict__ qcount, uint32_t lift_min) {
+                                                     DtWin w, uint2 *__restrict__ T, const uint32_t *__restrict__ qcount, uint32_t lift_min) {
   if (*qcount < lift_min) return;
-  const long long n = (long long)w.H * w.W;
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  int y = (int)(i / w.W), x = (int)(i - (long long)y * w.W);
-  long long pos = i;
-  float minz = __builtin_inff();
-  uint32_t len = 0, nd = 0, stop = 0;
-  uint32_t code = fdr[i];
+  const int x0 = (int)(blockIdx.x * 256u + threadIdx.x);
+  if (x0 >= w.W) return;
+  for (int y0 = (int)blockIdx.y; y0 < w.H; y0 += (int)gridDim.y) {  // a row per workgroup row: no division per cell
+    const long long i = (long long)y0 * w.W + x0;
+    int y = y0, x = x0;
+    float minz = __builtin_inff();
+    uint32_t len = 0, nd = 0, stop = 0;
+    uint32_t code = fdr[i];
 #pragma unroll 1
-  for (int k = 0; k < 8; k++) {
-    if (!dt_d8_valid(code)) { stop = DS_LIFT_STOP; break; }
-    int dy, dx;
-    dt_d8_delta(code, dy, dx);
-    const int ny = y + dy, nx = x + dx;
-    if (!(ny >= 0 && ny < w.H && nx >= 0 && nx < w.W)) { stop = DS_LIFT_STOP; break; }
-    const long long on = (long long)ny * w.W + nx;
-    const float zt = dem[on];
-    code = fdr[on];
-    if (zt == DT_NODATA) { stop = DS_LIFT_STOP; break; }
-    y = ny;
-    x = nx;
-    pos = on;
-    len++;
-    nd += (dy != 0 && dx != 0) ? 1u : 0u;
-    minz = fminf(minz, ds_lift_z(zt));
+    for (int k = 0; k < 8; k++) {
+      if (!dt_d8_valid(code)) { stop = DS_LIFT_STOP; break; }
+      int dy, dx;
+      dt_d8_delta(code, dy, dx);
+      const int ny = y + dy, nx = x + dx;
+      if (!(ny >= 0 && ny < w.H && nx >= 0 && nx < w.W)) { stop = DS_LIFT_STOP; break; }
+      const long long on = (long long)ny * w.W + nx;
+      const float zt = dem[on];
+      code = fdr[on];
+      if (zt == DT_NODATA) { stop = DS_LIFT_STOP; break; }
+      y = ny;
+      x = nx;
+      len++;
+      nd += (dy != 0 && dx != 0) ? 1u : 0u;
+      minz = fminf(minz, ds_lift_z(zt));
+    }
+    T[i] = make_uint2(ds_lift_pack(y - y0, x - x0, len, nd) | stop, __float_as_uint(minz));
   }
-  T[i] = make_uint4((uint32_t)pos, __float_as_uint(minz), len | (nd << 16), stop);
 }
 // skips of 2 L moves from skips of L
-__global__ __launch_bounds__(256) void k_ds_lift_double(const uint4 *__restrict__ A, uint4 *__restrict__ B, long long n,
+__global__ __launch_bounds__(256) void k_ds_lift_double(const uint2 *__restrict__ A, uint2 *__restrict__ B, int H, int W,
                                                        const uint32_t *__restrict__ qcount, uint32_t lift_min) {
   if (*qcount < lift_min) return;
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  uint4 a = A[i];
-  if (!(a.w & DS_LIFT_STOP)) {
-    const uint4 b = A[a.x];
-    a.x = b.x;
-    a.y = __float_as_uint(fminf(__uint_as_float(a.y), __uint_as_float(b.y)));
-    a.z += b.z;  // moves and diagonal moves, two 16-bit fields (<= 64 each)
-    a.w = b.w;
+  const int x = (int)(blockIdx.x * 256u + threadIdx.x);
+  if (x >= W) return;
+  for (int y = (int)blockIdx.y; y < H; y += (int)gridDim.y) {
+    const long long i = (long long)y * W + x;
+    uint2 a = A[i];
+    if (!(a.x & DS_LIFT_STOP)) {
+      const uint2 b = A[(long long)(y + ds_lift_dy(a.x)) * W + (x + ds_lift_dx(a.x))];
+      // the four fields add without carries (offsets within +-64 of the start, <= 64 moves): one addition, less the
+      // second entry's two biases; the stop bit is the second entry's
+      a.x += b.x - DS_LIFT_BIAS2;
+      a.y = __float_as_uint(fminf(__uint_as_float(a.y), __uint_as_float(b.y)));
+    }
+    B[i] = a;
   }
-  B[i] = a;
 }
 // the queued walks: skips while no cell of a skip can end the walk, then the moves that remain, one by one
 __global__ __launch_bounds__(256) void k_ds_finish(const float *__restrict__ dem, const uint8_t *__restrict__ fdr, DtWin w,
                                                   double px, double dz, float dzf, int raw, float *__restrict__ out,
-                                                  DsQueue queue, const uint4 *__restrict__ T,
-                                                  const uint4 *__restrict__ T8, int *__restrict__ n_unresolved,
+                                                  DsQueue queue, const uint2 *__restrict__ T,
+                                                  const uint2 *__restrict__ T8, int *__restrict__ n_unresolved,
                                                   uint32_t lift_min) {
   const uint32_t total = min(*queue.count, queue.capacity);
   const bool lifted = T != nullptr && *queue.count >= lift_min;
@@ -1025,26 +1038,27 @@ __global__ __launch_bounds__(256) void k_ds_finish(const float *__restrict__ dem
     const uint4 e = queue.entries[i];
     const int y0 = (int)(e.x / (uint32_t)w.W), x0 = (int)(e.x - (uint32_t)y0 * (uint32_t)w.W);
     const float z0 = dem[e.x];
-    uint32_t pos = e.y, loop = e.z, nd = e.w;
+    uint32_t loop = e.z, nd = e.w;
+    int y = (int)(e.y / (uint32_t)w.W), x = (int)(e.y - (uint32_t)y * (uint32_t)w.W);
     if (lifted) {
       // skips of 64 moves, then of 8 (the table of the third doubling round is kept): < 16 moves are left for the
       // move-by-move code
 #pragma unroll
       for (int level = 0; level < 2; level++) {
-        const uint4 *__restrict__ tab = level ? T8 : T;
+        const uint2 *__restrict__ tab = level ? T8 : T;
         for (;;) {
-          const uint4 t = tab[pos];
-          const uint32_t len = t.z & 0xFFFFu;
+          const uint2 t = tab[(long long)y * w.W + x];
+          const uint32_t len = ds_lift_len(t.x);
           // every cell of the skip leaves the drop below dz (the lowest one does), and the cap is beyond it
           if (len == 0u || !(z0 - __uint_as_float(t.y) < dzf) || loop + len > 4999u) break;
-          pos = t.x;
+          y += ds_lift_dy(t.x);
+          x += ds_lift_dx(t.x);
           loop += len;
-          nd += t.z >> 16;
+          nd += ds_lift_nd(t.x);
         }
       }
     }
-    const int y = (int)(pos / (uint32_t)w.W), x = (int)(pos - (uint32_t)y * (uint32_t)w.W);
-    const float drop = z0 - dem[pos];
+    const float drop = z0 - dem[(long long)y * w.W + x];
     ds_finish_cell<false>(w, dem, fdr, y0, x0, z0, drop, loop, nd, false, y, x, dcard, ddiag, dz, dzf, raw, out + e.x,
                           n_unresolved);
   }
@@ -1114,7 +1128,7 @@ int dt_launch_ds_walkers(hipStream_t s, const DtWin &w, const float *dem, const 
 // TABLES (two ping-pong skip tables and the 8-move table that is kept); dt_downslope_lift_bytes = both, back to back
 static size_t ds_queue_capacity(int64_t H, int64_t W) { return (size_t)((H * W + 1) / 2); }
 size_t dt_downslope_queue_bytes(int64_t H, int64_t W) { return 256 + dt_align256(ds_queue_capacity(H, W) * 16); }
-size_t dt_downslope_tables_bytes(int64_t H, int64_t W) { return 3 * dt_align256((size_t)H * W * 16); }
+size_t dt_downslope_tables_bytes(int64_t H, int64_t W) { return 3 * dt_align256((size_t)H * W * 8); }
 size_t dt_downslope_lift_bytes(int64_t H, int64_t W) {
   return dt_downslope_queue_bytes(H, W) + dt_downslope_tables_bytes(H, W);
 }
@@ -1135,7 +1149,7 @@ int dt_launch_downslope(hipStream_t s, const DtWin &w, const float *dem, const u
   float dzf = (float)dz;
   if ((double)dzf < dz) dzf = nextafterf(dzf, INFINITY);
   DsQueue q;
-  uint4 *tab[3] = {nullptr, nullptr, nullptr};  // two ping-pong tables and the 8-move table that is kept
+  uint2 *tab[3] = {nullptr, nullptr, nullptr};  // two ping-pong tables and the 8-move table that is kept
   const bool single = w.halo == 0 && w.gy0 == 0 && w.gx0 == 0 && w.Hg == w.H && w.Wg == w.W && w.ld == w.W;
   // margin of the LDS window around the 64 x 64 core: walks that reach the window's ring carry on in global memory
   const int m = dt_debug_get(DT_DBG_DS_MARGIN);
@@ -1144,9 +1158,9 @@ int dt_launch_downslope(hipStream_t s, const DtWin &w, const float *dem, const u
     q.entries = (uint4 *)((char *)qwork + 256);
     q.capacity = (uint32_t)ds_queue_capacity(H, W);
     if (twork) {
-      tab[0] = (uint4 *)twork;
-      tab[1] = (uint4 *)((char *)tab[0] + dt_align256((size_t)n * 16));
-      tab[2] = (uint4 *)((char *)tab[1] + dt_align256((size_t)n * 16));
+      tab[0] = (uint2 *)twork;
+      tab[1] = (uint2 *)((char *)tab[0] + dt_align256((size_t)n * 8));
+      tab[2] = (uint2 *)((char *)tab[1] + dt_align256((size_t)n * 8));
     }
   }
   DT_REQUIRE(phase == 0 || q.entries, "the phases of the long-walk form need a single raster and its queue workspace");
@@ -1169,24 +1183,23 @@ int dt_launch_downslope(hipStream_t s, const DtWin &w, const float *dem, const u
                          out, tiles_x, (int)ntiles, n_unresolved);
   }
   if (q.entries && phase != 1) {
-    const dim3 gn((unsigned)((n + 255) / 256)), b(256);
+    const dim3 b(256);
     const uint32_t lift_min = dt_downslope_lift_min(H, W);
-    uint4 *src = nullptr;
+    uint2 *src = nullptr;
     if (tab[0]) {
       // every kernel of the tables returns at once when fewer than lift_min walks were queued
       // 8 moves per skip (tab[2], kept) -> 16 -> 32 -> 64
-      hipLaunchKernelGGL(k_ds_lift_init, gn, b, 0, s, dem, fdr, w, tab[2], (const uint32_t *)q.count, lift_min);
-      hipLaunchKernelGGL(k_ds_lift_double, gn, b, 0, s, (const uint4 *)tab[2], tab[0], (long long)n,
-                         (const uint32_t *)q.count, lift_min);
-      hipLaunchKernelGGL(k_ds_lift_double, gn, b, 0, s, (const uint4 *)tab[0], tab[1], (long long)n,
-                         (const uint32_t *)q.count, lift_min);
-      hipLaunchKernelGGL(k_ds_lift_double, gn, b, 0, s, (const uint4 *)tab[1], tab[0], (long long)n,
-                         (const uint32_t *)q.count, lift_min);
+      const dim3 g2((unsigned)((W + 255) / 256), (unsigned)std::min<int64_t>(H, 65535));
+      const uint32_t *qc = (const uint32_t *)q.count;
+      hipLaunchKernelGGL(k_ds_lift_init, g2, b, 0, s, dem, fdr, w, tab[2], qc, lift_min);
+      hipLaunchKernelGGL(k_ds_lift_double, g2, b, 0, s, (const uint2 *)tab[2], tab[0], (int)H, (int)W, qc, lift_min);
+      hipLaunchKernelGGL(k_ds_lift_double, g2, b, 0, s, (const uint2 *)tab[0], tab[1], (int)H, (int)W, qc, lift_min);
+      hipLaunchKernelGGL(k_ds_lift_double, g2, b, 0, s, (const uint2 *)tab[1], tab[0], (int)H, (int)W, qc, lift_min);
       src = tab[0];
     }
     const unsigned fin_blocks = (unsigned)std::min<size_t>((q.capacity + 255) / 256, 8192);
-    hipLaunchKernelGGL(k_ds_finish, dim3(fin_blocks), b, 0, s, dem, fdr, w, px, dz, dzf, raw, out, q, (const uint4 *)src,
-                       (const uint4 *)tab[2], n_unresolved, lift_min);
+    hipLaunchKernelGGL(k_ds_finish, dim3(fin_blocks), b, 0, s, dem, fdr, w, px, dz, dzf, raw, out, q, (const uint2 *)src,
+                       (const uint2 *)tab[2], n_unresolved, lift_min);
   }
   return DT_OK;
 }
