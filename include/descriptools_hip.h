@@ -260,11 +260,11 @@ int dt_dev_downslope(dt_ctx *ctx, const float *dem, const uint8_t *fdr, int64_t 
  * difference after 32 further moves are queued and finished with a skip table (64 moves per skip, built on the device
  * when at least 256 walks were queued) -- on real, conditioned terrain, where flats and valley floors make walks
  * thousands of moves long, an order of magnitude faster; same results.  `work`: dt_downslope_lift_workspace(H, W)
- * bytes of device memory (56 bytes per cell), the library's for the duration of the call's kernels. */
+ * bytes of device memory (32 bytes per cell), the library's for the duration of the call's kernels. */
 int64_t dt_downslope_lift_workspace(int64_t H, int64_t W);
 int dt_dev_downslope_lift(dt_ctx *ctx, const float *dem, const uint8_t *fdr, int64_t H, int64_t W, double px,
                           double dz, int raw, float *out, void *work, int64_t work_bytes);
-/* The same in two steps, for callers that may synchronise in between and want the tables' 48 bytes per cell only for
+/* The same in two steps, for callers that may synchronise in between and want the tables' 24 bytes per cell only for
  * rasters that need them: dt_dev_downslope_queue runs the window kernel and queues the long walks (qwork:
  * dt_downslope_queue_workspace bytes, 8 per cell); dt_dev_downslope_queued waits for it and returns their number;
  * dt_dev_downslope_finish finishes them -- with skip tables when twork (dt_downslope_tables_workspace bytes) is given
