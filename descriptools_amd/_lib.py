@@ -91,6 +91,8 @@ _SIGS = {
     "dt_dev_slope_d8_w": (ci, [vp, vp, vp, f64, vp, vp, vp]),
     "dt_dev_slope_twi_w": (ci, [vp, vp, vp, vp, f64, f64, vp, vp, vp, vp]),
     "dt_dev_downslope_w": (ci, [vp, vp, vp, vp, f64, f64, ci, vp, vp]),
+    "dt_downslope_lift_workspace_w": (i64, [vp]),
+    "dt_dev_downslope_lift_w": (ci, [vp, vp, vp, vp, f64, f64, ci, vp, vp, vp, i64]),
     "dt_dev_downslope_walkers_w": (ci, [vp, vp, vp, vp, f64, f64, i64, vp, vp, vp, vp, vp, vp, vp]),
     "dt_dev_flowacc_local_w": (ci, [vp, vp, vp, vp, vp, vp, vp]),
     "dt_dev_flowacc_finish_w": (ci, [vp, vp, vp, vp, vp, i64, vp, vp]),

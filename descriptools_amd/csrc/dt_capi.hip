@@ -803,6 +803,29 @@ extern "C" int dt_dev_downslope_w(dt_ctx *c, const dt_window *win, const float *
   return DT_OK;
 }
 
+// dt_dev_downslope_w with the long-walk workspace: the long walks that stay in the rank's memory (core + halo) are
+// queued and finished with skip tables over that memory; the ones that leave it are marked and counted as ever
+extern "C" int64_t dt_downslope_lift_workspace_w(const dt_window *win) {
+  DtWin w;
+  if (dt_convert_window(win, &w) != DT_OK) return -1;
+  return (int64_t)dt_downslope_lift_bytes_w(w);
+}
+extern "C" int dt_dev_downslope_lift_w(dt_ctx *c, const dt_window *win, const float *dem, const uint8_t *fdr,
+                                       double px, double dz, int raw, float *out, int32_t *n_unresolved_dev,
+                                       void *work, int64_t work_bytes) {
+  DT_CTX(c);
+  DtWin w;
+  DT_TRY(dt_convert_window(win, &w));
+  DT_REQUIRE(dem && fdr && out, "NULL raster");
+  DT_REQUIRE(work != nullptr && work_bytes >= (int64_t)dt_downslope_lift_bytes_w(w),
+             "downslope workspace missing or too small");
+  if (n_unresolved_dev) DT_HIP(hipMemsetAsync(n_unresolved_dev, 0, sizeof(int32_t), c->stream));
+  DT_TRY(dt_launch_downslope(c->stream, w, dem, fdr, px, dz, raw, out, (int *)n_unresolved_dev, work,
+                             (char *)work + dt_downslope_queue_bytes(w.H, w.W), 0));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+
 // walkers of downslope walks that cross rank borders (dt_kernels.hip, k_ds_walkers; tiling.finish_downslope): the ones
 // standing in this rank's memory are advanced until they finish (status 1, value) or must be handed on (status 0)
 extern "C" int dt_dev_downslope_walkers_w(dt_ctx *c, const dt_window *win, const float *dem, const uint8_t *fdr,

@@ -33,6 +33,8 @@ size_t dt_downslope_lift_bytes(int64_t H, int64_t W);
 size_t dt_downslope_queue_bytes(int64_t H, int64_t W);
 size_t dt_downslope_tables_bytes(int64_t H, int64_t W);
 uint32_t dt_downslope_lift_min(int64_t H, int64_t W);
+size_t dt_downslope_tables_bytes_w(const DtWin &w);
+size_t dt_downslope_lift_bytes_w(const DtWin &w);
 int dt_launch_downslope(hipStream_t s, const DtWin &w, const float *dem, const uint8_t *fdr, double px,
                         double dz, int raw, float *out, int *n_unresolved, void *qwork = nullptr,
                         void *twork = nullptr, int phase = 0);

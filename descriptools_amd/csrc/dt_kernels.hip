@@ -518,6 +518,16 @@ struct DsQueue {
   uint32_t capacity;
   __host__ __device__ DsQueue() : entries(nullptr), count(nullptr), capacity(0) {}
 };
+// Cells of the long-walk path are named by their index in the window's MEMORY (core + halo, row stride ld): for a
+// single raster (no halo, ld = W) that is y * W + x
+__device__ __forceinline__ uint32_t ds_mem_index(const DtWin &w, int y, int x) {
+  return (uint32_t)((long long)(y + w.halo) * w.ld + (x + w.halo));
+}
+__device__ __forceinline__ void ds_mem_cell(const DtWin &w, uint32_t e, int &y, int &x) {
+  const uint32_t r = e / (uint32_t)w.ld;
+  y = (int)r - w.halo;
+  x = (int)(e - r * (uint32_t)w.ld) - w.halo;
+}
 // skip-table entry, 8 bytes: y = float bits of the lowest height on the way (-inf for a NaN height); x = where the walk
 // stands after the skip RELATIVE to its start (a skip is at most 64 moves: row and column offsets + 64 in bits 0-7 and
 // 8-15), moves in bits 16-22, the diagonal ones in bits 23-29, bit 30 when the walk cannot go on from there.  (Round 3
@@ -542,7 +552,7 @@ __device__ __forceinline__ void ds_finish_cell(const DtWin &w, const float *__re
                                                const uint8_t *__restrict__ fdr, int y0, int x0, float z0, float drop,
                                                uint32_t loop, uint32_t nd, bool stop_fail, int y, int x, double dcard,
                                                double ddiag, double dz, float dzf, int raw, float *__restrict__ outp,
-                                               int *__restrict__ n_unresolved) {
+                                               uint32_t &n_unres) {
   bool failed = false, slow = false, unresolved = false;
   bool cont = false;  // continue on global memory from the cell the fast walk stopped on
   if (drop < dzf) {
@@ -634,20 +644,24 @@ __device__ __forceinline__ void ds_finish_cell(const DtWin &w, const float *__re
   }
   if (unresolved) {  // the walk left the memory of this rank: a wider halo is needed
     *outp = -50.0f;
-    if (n_unresolved) atomicAdd(n_unresolved, 1);
+    n_unres++;  // counted by the caller, which adds up before it touches the device counter
   } else if (raw && failed) *outp = -50.0f;
   else *outp = res;
 }
 
-// the rest of a walk that found the queue full, from the cell (of a single raster) it stands on
+// the rest of a walk that found the queue full, from the cell it stands on
+template <bool RANKED>
 __device__ __attribute__((noinline)) void ds_finish_overflow(const DtWin &w, const float *__restrict__ dem,
                                                              const uint8_t *__restrict__ fdr, int y0, int x0, float z0,
                                                              uint32_t loop, uint32_t nd, uint32_t pos, double px,
                                                              double dz, float dzf, int raw, float *__restrict__ out,
                                                              int *__restrict__ n_unresolved) {
-  const int y = (int)(pos / (uint32_t)w.W), x = (int)(pos - (uint32_t)y * (uint32_t)w.W);
-  ds_finish_cell<false>(w, dem, fdr, y0, x0, z0, z0 - dem[(long long)y * w.ld + x], loop, nd, false, y, x, px,
-                        px * sqrt(2.0), dz, dzf, raw, out + (long long)y0 * w.ld + x0, n_unresolved);
+  int y, x;
+  ds_mem_cell(w, pos, y, x);
+  uint32_t unres = 0u;
+  ds_finish_cell<RANKED>(w, dem, fdr, y0, x0, z0, z0 - dem[(long long)y * w.ld + x], loop, nd, false, y, x, px,
+                        px * sqrt(2.0), dz, dzf, raw, out + (long long)y0 * w.ld + x0, unres);
+  if (unres && n_unresolved) atomicAdd(n_unresolved, (int)unres);
 }
 
 // Windowed version: a 1024-thread workgroup stages a 112 x 112 window (64 x 64 core + 24-cell
@@ -691,7 +705,8 @@ __device__ __forceinline__ void ds_win_body(const float *__restrict__ dem,
   // address register)
   __shared__ __attribute__((aligned(16))) unsigned char smem[DW_LD * DW_WIN * 6];
   __shared__ uint16_t s_lut[256];
-  __shared__ uint32_t s_queued[2];  // QUEUE: walks this workgroup hands over, and where its block of the queue starts
+  // QUEUE: walks this workgroup hands over, and where its block of the queue starts; RANKED: [2] = its unresolved walks
+  __shared__ uint32_t s_queued[3];
   float *s_z = reinterpret_cast<float *>(smem);
   uint16_t *s_w = reinterpret_cast<uint16_t *>(smem + DW_LD * DW_WIN * 4);
   // LDS byte address of smem (0 when it is the kernel's only LDS object, but do not rely on it)
@@ -757,7 +772,7 @@ __device__ __forceinline__ void ds_win_body(const float *__restrict__ dem,
     }
     s_lut[code] = (uint16_t)mw;
   }
-  if (QUEUE && threadIdx.x == 0) s_queued[0] = 0u;
+  if ((QUEUE || RANKED) && threadIdx.x == 0) s_queued[0] = s_queued[2] = 0u;
   __syncthreads();
   if (interior) {
 #pragma unroll
@@ -834,6 +849,7 @@ __device__ __forceinline__ void ds_win_body(const float *__restrict__ dem,
   const double dcard = px, ddiag = px * sqrt(2.0);
   const uint32_t neg2lds0 = 0u - 2u * lds0 + lds0;  // z address = 2 * (q2 - lds0) + lds0 = (q2 << 1) + neg2lds0
   // QUEUE: a thread's walks to hand over (bit j of pend: its j-th cell), where each stands and moves | diagonal ones << 16
+  uint32_t unres = 0u;  // walks that left this rank's memory
   uint32_t pend = 0u, pq0 = 0u, pq1 = 0u, pq2 = 0u, pq3 = 0u, pl0 = 0u, pl1 = 0u, pl2 = 0u, pl3 = 0u;
   static_assert((DW_CORE * DW_CORE) / 1024 == 4, "four cells per thread");
   for (int j = 0; j < (DW_CORE * DW_CORE) / 1024; j++) {
@@ -903,10 +919,10 @@ __device__ __forceinline__ void ds_win_body(const float *__restrict__ dem,
     const uint32_t pos = (q2 - lds0) >> 1;
     const int ys = wy0 + (int)(pos / DW_LD), xs = wx0 + (int)(pos % DW_LD);
     const bool stop_fail = (mw & (MW_BADCODE | MW_EDGE)) != 0u;
-    if (QUEUE && drop < dzf && !stop_fail && dt_readable(w, ys, xs)) {
+    if (QUEUE && drop < dzf && !stop_fail && (RANKED ? dt_has_code(w, ys, xs) : dt_readable(w, ys, xs))) {
       // A LONG walk (a flat, a valley floor: real conditioned terrain has walks of thousands of moves, each a
       // dependent global load in ds_finish_cell): left for k_ds_finish, which crosses it in skips of 64 moves
-      const uint32_t pq = (uint32_t)((long long)ys * w.W + xs), pl = loop | (nd << 16);
+      const uint32_t pq = ds_mem_index(w, ys, xs), pl = loop | (nd << 16);
       if (j == 0) { pq0 = pq; pl0 = pl; }
       else if (j == 1) { pq1 = pq; pl1 = pl; }
       else if (j == 2) { pq2 = pq; pl2 = pl; }
@@ -915,7 +931,16 @@ __device__ __forceinline__ void ds_win_body(const float *__restrict__ dem,
       continue;
     }
     ds_finish_cell<RANKED>(w, dem, fdr, y0, x0, z0, drop, loop, nd, stop_fail, ys, xs, dcard, ddiag, dz, dzf, raw,
-                           out + o, n_unresolved);
+                           out + o, unres);
+  }
+  if (RANKED) {
+    // on real terrain every border of a rank has such walks by the ten thousand: counted per workgroup (LDS), ONE
+    // device atomic each -- one per cell queues up on the one address like the queue's reservations did
+    if (unres) atomicAdd(&s_queued[2], unres);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_queued[2] && n_unresolved) atomicAdd(n_unresolved, (int)s_queued[2]);
+  } else if (unres && n_unresolved) {
+    atomicAdd(n_unresolved, (int)unres);  // (a single raster has no memory to run out of)
   }
   if (QUEUE) {
     // ONE global atomic per workgroup reserves its block of the queue (one per wave and pass -- 3 M of them on one
@@ -936,11 +961,12 @@ __device__ __forceinline__ void ds_win_body(const float *__restrict__ dem,
       const int cy = c / DW_CORE, cx = c - cy * DW_CORE;
       const int y0 = tyi * DW_CORE + cy, x0 = txi * DW_CORE + cx;
       if (slot < queue.capacity) {
-        queue.entries[slot] = make_uint4((uint32_t)((long long)y0 * w.W + x0), pq, pl & 0xFFFFu, pl >> 16);
+        queue.entries[slot] = make_uint4(ds_mem_index(w, y0, x0), pq, pl & 0xFFFFu, pl >> 16);
       } else {
         // a full queue (more than half the raster's cells): the walk is made here after all
         const float z0 = s_z[(cy + DW_M) * DW_LD + cx + DW_M];
-        ds_finish_overflow(w, dem, fdr, y0, x0, z0, pl & 0xFFFFu, pl >> 16, pq, px, dz, dzf, raw, out, n_unresolved);
+        ds_finish_overflow<RANKED>(w, dem, fdr, y0, x0, z0, pl & 0xFFFFu, pl >> 16, pq, px, dz, dzf, raw, out,
+                                   n_unresolved);
       }
       slot++;
     }
@@ -970,32 +996,44 @@ __global__ __launch_bounds__(1024, 8) void k_downslope_win_q(const float *__rest
   ds_win_body<24, true, false>(dem, fdr, w, px, dz, dzf, raw, out, tiles_x, ntiles, n_unresolved, queue);
 }
 
+// ... of a rank's window: the long walks that stay in the rank's memory; the ones that leave it are counted as ever
+__global__ __launch_bounds__(1024, 8) void k_downslope_win_rq(const float *__restrict__ dem,
+                                                          const uint8_t *__restrict__ fdr, DtWin w, double px,
+                                                          double dz, float dzf, int raw, float *__restrict__ out,
+                                                          int tiles_x, int ntiles, int *__restrict__ n_unresolved,
+                                                          DsQueue queue) {
+  ds_win_body<24, true, true>(dem, fdr, w, px, dz, dzf, raw, out, tiles_x, ntiles, n_unresolved, queue);
+}
+
 // ---- skip table ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float ds_lift_z(float z) { return z != z ? -__builtin_inff() : z; }  // a NaN height ends a walk
-// the 8-move table straight from the rasters (single raster: w is the full window): a lane walks its cell's eight
-// moves itself -- neighbouring cells, cache hits -- instead of three rounds of doubling over one-move entries (each
-// round moves 48 bytes per cell)
+// the 8-move table straight from the rasters, for every cell of the window's memory (core + halo; a single raster: the
+// raster): a lane walks its cell's eight moves itself -- neighbouring cells, cache hits -- instead of three rounds of
+// doubling over one-move entries.  A skip ends (stop flag) where the move-by-move code would have to decide something:
+// a cell without a code in memory (non-D8, or the last ring of a rank's halo), a move off the raster or out of the
+// rank's memory, nodata ahead.
+template <bool RANKED>
 __global__ __launch_bounds__(256) void k_ds_lift_init(const float *__restrict__ dem, const uint8_t *__restrict__ fdr,
                                                      DtWin w, uint2 *__restrict__ T, const uint32_t *__restrict__ qcount, uint32_t lift_min) {
   if (*qcount < lift_min) return;
-  const int x0 = (int)(blockIdx.x * 256u + threadIdx.x);
-  if (x0 >= w.W) return;
-  for (int y0 = (int)blockIdx.y; y0 < w.H; y0 += (int)gridDim.y) {  // a row per workgroup row: no division per cell
-    const long long i = (long long)y0 * w.W + x0;
+  const int x0 = (int)(blockIdx.x * 256u + threadIdx.x) - w.halo;
+  if (x0 >= w.W + w.halo) return;
+  auto has_code = [&](int yy, int xx) { return RANKED ? dt_has_code(w, yy, xx) : dt_readable(w, yy, xx); };
+  for (int y0 = (int)blockIdx.y - w.halo; y0 < w.H + w.halo; y0 += (int)gridDim.y) {  // a row per workgroup row: no division per cell
     int y = y0, x = x0;
     float minz = __builtin_inff();
     uint32_t len = 0, nd = 0, stop = 0;
-    uint32_t code = fdr[i];
+    uint32_t code = has_code(y, x) ? (uint32_t)fdr[(long long)y * w.ld + x] : 0u;
 #pragma unroll 1
     for (int k = 0; k < 8; k++) {
       if (!dt_d8_valid(code)) { stop = DS_LIFT_STOP; break; }
       int dy, dx;
       dt_d8_delta(code, dy, dx);
       const int ny = y + dy, nx = x + dx;
-      if (!(ny >= 0 && ny < w.H && nx >= 0 && nx < w.W)) { stop = DS_LIFT_STOP; break; }
-      const long long on = (long long)ny * w.W + nx;
+      if (!dt_readable(w, ny, nx)) { stop = DS_LIFT_STOP; break; }
+      const long long on = (long long)ny * w.ld + nx;
       const float zt = dem[on];
-      code = fdr[on];
+      code = has_code(ny, nx) ? (uint32_t)fdr[on] : 0u;
       if (zt == DT_NODATA) { stop = DS_LIFT_STOP; break; }
       y = ny;
       x = nx;
@@ -1003,20 +1041,21 @@ __global__ __launch_bounds__(256) void k_ds_lift_init(const float *__restrict__ 
       nd += (dy != 0 && dx != 0) ? 1u : 0u;
       minz = fminf(minz, ds_lift_z(zt));
     }
-    T[i] = make_uint2(ds_lift_pack(y - y0, x - x0, len, nd) | stop, __float_as_uint(minz));
+    T[ds_mem_index(w, y0, x0)] = make_uint2(ds_lift_pack(y - y0, x - x0, len, nd) | stop, __float_as_uint(minz));
   }
 }
-// skips of 2 L moves from skips of L
-__global__ __launch_bounds__(256) void k_ds_lift_double(const uint2 *__restrict__ A, uint2 *__restrict__ B, int H, int W,
-                                                       const uint32_t *__restrict__ qcount, uint32_t lift_min) {
+// skips of 2 L moves from skips of L; rows x cols cells of row stride ld
+__global__ __launch_bounds__(256) void k_ds_lift_double(const uint2 *__restrict__ A, uint2 *__restrict__ B, int rows,
+                                                       int cols, int ld, const uint32_t *__restrict__ qcount,
+                                                       uint32_t lift_min) {
   if (*qcount < lift_min) return;
   const int x = (int)(blockIdx.x * 256u + threadIdx.x);
-  if (x >= W) return;
-  for (int y = (int)blockIdx.y; y < H; y += (int)gridDim.y) {
-    const long long i = (long long)y * W + x;
+  if (x >= cols) return;
+  for (int y = (int)blockIdx.y; y < rows; y += (int)gridDim.y) {
+    const long long i = (long long)y * ld + x;
     uint2 a = A[i];
     if (!(a.x & DS_LIFT_STOP)) {
-      const uint2 b = A[(long long)(y + ds_lift_dy(a.x)) * W + (x + ds_lift_dx(a.x))];
+      const uint2 b = A[(long long)(y + ds_lift_dy(a.x)) * ld + (x + ds_lift_dx(a.x))];
       // the four fields add without carries (offsets within +-64 of the start, <= 64 moves): one addition, less the
       // second entry's two biases; the stop bit is the second entry's
       a.x += b.x - DS_LIFT_BIAS2;
@@ -1026,6 +1065,7 @@ __global__ __launch_bounds__(256) void k_ds_lift_double(const uint2 *__restrict_
   }
 }
 // the queued walks: skips while no cell of a skip can end the walk, then the moves that remain, one by one
+template <bool RANKED>
 __global__ __launch_bounds__(256) void k_ds_finish(const float *__restrict__ dem, const uint8_t *__restrict__ fdr, DtWin w,
                                                   double px, double dz, float dzf, int raw, float *__restrict__ out,
                                                   DsQueue queue, const uint2 *__restrict__ T,
@@ -1034,12 +1074,14 @@ __global__ __launch_bounds__(256) void k_ds_finish(const float *__restrict__ dem
   const uint32_t total = min(*queue.count, queue.capacity);
   const bool lifted = T != nullptr && *queue.count >= lift_min;
   const double dcard = px, ddiag = px * sqrt(2.0);
+  uint32_t unres = 0u;
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
     const uint4 e = queue.entries[i];
-    const int y0 = (int)(e.x / (uint32_t)w.W), x0 = (int)(e.x - (uint32_t)y0 * (uint32_t)w.W);
-    const float z0 = dem[e.x];
+    int y0, x0, y, x;
+    ds_mem_cell(w, e.x, y0, x0);
+    ds_mem_cell(w, e.y, y, x);
+    const float z0 = dem[(long long)y0 * w.ld + x0];
     uint32_t loop = e.z, nd = e.w;
-    int y = (int)(e.y / (uint32_t)w.W), x = (int)(e.y - (uint32_t)y * (uint32_t)w.W);
     if (lifted) {
       // skips of 64 moves, then of 8 (the table of the third doubling round is kept): < 16 moves are left for the
       // move-by-move code
@@ -1047,7 +1089,7 @@ __global__ __launch_bounds__(256) void k_ds_finish(const float *__restrict__ dem
       for (int level = 0; level < 2; level++) {
         const uint2 *__restrict__ tab = level ? T8 : T;
         for (;;) {
-          const uint2 t = tab[(long long)y * w.W + x];
+          const uint2 t = tab[ds_mem_index(w, y, x)];
           const uint32_t len = ds_lift_len(t.x);
           // every cell of the skip leaves the drop below dz (the lowest one does), and the cap is beyond it
           if (len == 0u || !(z0 - __uint_as_float(t.y) < dzf) || loop + len > 4999u) break;
@@ -1058,10 +1100,13 @@ __global__ __launch_bounds__(256) void k_ds_finish(const float *__restrict__ dem
         }
       }
     }
-    const float drop = z0 - dem[(long long)y * w.W + x];
-    ds_finish_cell<false>(w, dem, fdr, y0, x0, z0, drop, loop, nd, false, y, x, dcard, ddiag, dz, dzf, raw, out + e.x,
-                          n_unresolved);
+    const float drop = z0 - dem[(long long)y * w.ld + x];
+    ds_finish_cell<RANKED>(w, dem, fdr, y0, x0, z0, drop, loop, nd, false, y, x, dcard, ddiag, dz, dzf, raw,
+                           out + (long long)y0 * w.ld + x0, unres);
   }
+  // (a rank's walks that leave its memory: one atomic per wave)
+  for (int o = 32; o; o >>= 1) unres += (uint32_t)__shfl_xor((int)unres, o);
+  if ((threadIdx.x & 63u) == 0u && unres && n_unresolved) atomicAdd(n_unresolved, (int)unres);
 }
 
 // ---- walks across rank borders ---------------------------------------------------------------------------------------
@@ -1133,8 +1178,14 @@ size_t dt_downslope_lift_bytes(int64_t H, int64_t W) {
   return dt_downslope_queue_bytes(H, W) + dt_downslope_tables_bytes(H, W);
 }
 uint32_t dt_downslope_lift_min(int64_t H, int64_t W) { return (uint32_t)std::max<int64_t>(DS_LIFT_MIN, H * W / 128); }
-// qwork / twork (optional; single rasters only -- a rank window's walks leave its memory): long walks are queued and
-// finished with skip tables (see DsQueue).  phase 0: everything; 1: the window kernel with the queue only; 2: the
+// ... of a window: the queue holds core cells, the tables cover the window's memory (core + halo, row stride ld)
+static size_t ds_mem_cells(const DtWin &w) { return (size_t)(w.H + 2 * (int64_t)w.halo) * (size_t)w.ld; }
+size_t dt_downslope_tables_bytes_w(const DtWin &w) { return 3 * dt_align256(ds_mem_cells(w) * 8); }
+size_t dt_downslope_lift_bytes_w(const DtWin &w) {
+  return dt_downslope_queue_bytes(w.H, w.W) + dt_downslope_tables_bytes_w(w);
+}
+// qwork / twork (optional): long walks are queued and finished with skip tables (see DsQueue); in a rank's window the
+// ones that stay in the rank's memory -- the others are counted in n_unresolved as without the workspace.  phase 0: everything; 1: the window kernel with the queue only; 2: the
 // tables (when twork is given; built only if enough walks were queued) and the queued walks -- so that a caller who may
 // synchronise can look at the queue's counter (the first word of qwork) after phase 1 and allocate tables only when a
 // raster needs them.
@@ -1150,20 +1201,20 @@ int dt_launch_downslope(hipStream_t s, const DtWin &w, const float *dem, const u
   if ((double)dzf < dz) dzf = nextafterf(dzf, INFINITY);
   DsQueue q;
   uint2 *tab[3] = {nullptr, nullptr, nullptr};  // two ping-pong tables and the 8-move table that is kept
-  const bool single = w.halo == 0 && w.gy0 == 0 && w.gx0 == 0 && w.Hg == w.H && w.Wg == w.W && w.ld == w.W;
+  const bool ranked = !(w.halo == 0 && w.gy0 == 0 && w.gx0 == 0 && w.Hg == w.H && w.Wg == w.W);
   // margin of the LDS window around the 64 x 64 core: walks that reach the window's ring carry on in global memory
   const int m = dt_debug_get(DT_DBG_DS_MARGIN);
-  if (qwork && single && n < 0x7FFFFFFFll && m != 16 && m != 20) {  // (the A/B margins run without the queue)
+  if (qwork && ds_mem_cells(w) < 0x7FFFFFFFull && m != 16 && m != 20) {  // (the A/B margins run without the queue)
     q.count = (uint32_t *)qwork;
     q.entries = (uint4 *)((char *)qwork + 256);
     q.capacity = (uint32_t)ds_queue_capacity(H, W);
     if (twork) {
       tab[0] = (uint2 *)twork;
-      tab[1] = (uint2 *)((char *)tab[0] + dt_align256((size_t)n * 8));
-      tab[2] = (uint2 *)((char *)tab[1] + dt_align256((size_t)n * 8));
+      tab[1] = (uint2 *)((char *)tab[0] + dt_align256(ds_mem_cells(w) * 8));
+      tab[2] = (uint2 *)((char *)tab[1] + dt_align256(ds_mem_cells(w) * 8));
     }
   }
-  DT_REQUIRE(phase == 0 || q.entries, "the phases of the long-walk form need a single raster and its queue workspace");
+  DT_REQUIRE(phase == 0 || q.entries, "the phases of the long-walk form need the queue workspace (and a window of < 2^31 cells)");
   if (phase != 2) {
     if (q.entries) DT_HIP(hipMemsetAsync(q.count, 0, sizeof(uint32_t), s));
     if (m == 16)
@@ -1172,7 +1223,10 @@ int dt_launch_downslope(hipStream_t s, const DtWin &w, const float *dem, const u
     else if (m == 20)
       hipLaunchKernelGGL(k_downslope_win<20>, dim3((unsigned)ntiles), dim3(1024), 0, s, dem, fdr, w, px, dz, dzf, raw,
                          out, tiles_x, (int)ntiles, n_unresolved);
-    else if (!(w.halo == 0 && w.gy0 == 0 && w.gx0 == 0 && w.Hg == w.H && w.Wg == w.W))
+    else if (ranked && q.entries)
+      hipLaunchKernelGGL(k_downslope_win_rq, dim3((unsigned)ntiles), dim3(1024), 0, s, dem, fdr, w, px, dz, dzf, raw,
+                         out, tiles_x, (int)ntiles, n_unresolved, q);
+    else if (ranked)
       hipLaunchKernelGGL(k_downslope_win_r, dim3((unsigned)ntiles), dim3(1024), 0, s, dem, fdr, w, px, dz, dzf, raw,
                          out, tiles_x, (int)ntiles, n_unresolved);
     else if (q.entries)
@@ -1189,17 +1243,23 @@ int dt_launch_downslope(hipStream_t s, const DtWin &w, const float *dem, const u
     if (tab[0]) {
       // every kernel of the tables returns at once when fewer than lift_min walks were queued
       // 8 moves per skip (tab[2], kept) -> 16 -> 32 -> 64
-      const dim3 g2((unsigned)((W + 255) / 256), (unsigned)std::min<int64_t>(H, 65535));
+      const int rows = (int)(H + 2 * w.halo), cols = (int)(W + 2 * w.halo);
+      const dim3 g2((unsigned)((cols + 255) / 256), (unsigned)std::min(rows, 65535));
       const uint32_t *qc = (const uint32_t *)q.count;
-      hipLaunchKernelGGL(k_ds_lift_init, g2, b, 0, s, dem, fdr, w, tab[2], qc, lift_min);
-      hipLaunchKernelGGL(k_ds_lift_double, g2, b, 0, s, (const uint2 *)tab[2], tab[0], (int)H, (int)W, qc, lift_min);
-      hipLaunchKernelGGL(k_ds_lift_double, g2, b, 0, s, (const uint2 *)tab[0], tab[1], (int)H, (int)W, qc, lift_min);
-      hipLaunchKernelGGL(k_ds_lift_double, g2, b, 0, s, (const uint2 *)tab[1], tab[0], (int)H, (int)W, qc, lift_min);
+      if (ranked) hipLaunchKernelGGL(k_ds_lift_init<true>, g2, b, 0, s, dem, fdr, w, tab[2], qc, lift_min);
+      else hipLaunchKernelGGL(k_ds_lift_init<false>, g2, b, 0, s, dem, fdr, w, tab[2], qc, lift_min);
+      hipLaunchKernelGGL(k_ds_lift_double, g2, b, 0, s, (const uint2 *)tab[2], tab[0], rows, cols, w.ld, qc, lift_min);
+      hipLaunchKernelGGL(k_ds_lift_double, g2, b, 0, s, (const uint2 *)tab[0], tab[1], rows, cols, w.ld, qc, lift_min);
+      hipLaunchKernelGGL(k_ds_lift_double, g2, b, 0, s, (const uint2 *)tab[1], tab[0], rows, cols, w.ld, qc, lift_min);
       src = tab[0];
     }
     const unsigned fin_blocks = (unsigned)std::min<size_t>((q.capacity + 255) / 256, 8192);
-    hipLaunchKernelGGL(k_ds_finish, dim3(fin_blocks), b, 0, s, dem, fdr, w, px, dz, dzf, raw, out, q, (const uint2 *)src,
-                       (const uint2 *)tab[2], n_unresolved, lift_min);
+    if (ranked)
+      hipLaunchKernelGGL(k_ds_finish<true>, dim3(fin_blocks), b, 0, s, dem, fdr, w, px, dz, dzf, raw, out, q,
+                         (const uint2 *)src, (const uint2 *)tab[2], n_unresolved, lift_min);
+    else
+      hipLaunchKernelGGL(k_ds_finish<false>, dim3(fin_blocks), b, 0, s, dem, fdr, w, px, dz, dzf, raw, out, q,
+                         (const uint2 *)src, (const uint2 *)tab[2], n_unresolved, lift_min);
   }
   return DT_OK;
 }

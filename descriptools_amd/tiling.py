@@ -261,17 +261,22 @@ class RankTile:
     """Extended rasters ((H + 2*HALO) x (W + 2*HALO)) of one rank and the windowed library calls."""
 
     def __init__(self, layout, rank, device=0, stream=None, px=10.0, n_top=0.1, n_gfi=0.4, b=0.1, dz=5.0,
-                 river_threshold=None, halo=HALO, idx64=None, acc64=None, rasters=None, tune_placement=True):
+                 river_threshold=None, halo=HALO, idx64=None, acc64=None, rasters=None, tune_placement=True,
+                 long_walks=False):
         """acc64: flow accumulation (and the river accumulation payload) as int64 rasters, the reference's dtype --
         the default for a global raster of more than 2^31 cells, where a basin can exceed 32 bits; int32 rasters
         otherwise (exact: an accumulation is at most cells - 1; half the bytes).  rasters: names of the rasters to allocate (default: all).
         tune_placement: hand the 4-byte rasters to their roles by measured write-conflict class (placement.py; only
-        rasters of >= 64 MiB are measured)."""
+        rasters of >= 64 MiB are measured).
+        long_walks: downslope with the long-walk workspace (dt_dev_downslope_lift_w: 8 bytes per core cell + 24 per
+        cell of core + halo, allocated at the first downslope call) -- for real terrain, where flats and valley floors
+        make walks thousands of moves long; same results."""
         import torch
         from . import _lib
         from .device import Context
         self.torch, self._lib, self.L = torch, _lib, _lib.lib()
         self.layout, self.rank, self.halo = layout, rank, halo
+        self.long_walks, self._lift_work = bool(long_walks), None
         self.H, self.W = layout.shape(rank)
         self.gy0, self.gx0 = layout.origin(rank)
         self.He, self.We = self.H + 2 * halo, self.W + 2 * halo
@@ -551,7 +556,7 @@ class RankTile:
         self.side_ctx.sync()
         self.ctx.sync()
         self.t, self._keep, self._keep2, self._keep_rows, self._keep_rows2 = {}, None, None, None, None
-        self.fa_row = self.fh_row = self._ext = self._res = self._fa_v = self._fh_v = None
+        self.fa_row = self.fh_row = self._ext = self._res = self._fa_v = self._fh_v = self._lift_work = None
         self.side_ctx.close()
         self.ctx.close()
 
@@ -617,6 +622,16 @@ class RankTile:
         if side:
             self.ctx.fork(self.side_ctx)
             ctx = self.side_ctx
+        if self.long_walks:
+            if self._lift_work is None:
+                nb = int(self.L.dt_downslope_lift_workspace_w(C.byref(self.win)))
+                with self.on_stream():
+                    self._lift_work = self.torch.empty(nb, dtype=self.torch.uint8, device=self.dev)
+                self.ctx.sync()  # (the side stream may be the one that uses it)
+            self._chk(self.L.dt_dev_downslope_lift_w(ctx.h, C.byref(self.win), self.p("dem"), self.p("fdr"), self.px,
+                                                     self.dz, 0, self.p("down"), self.n_unres.data_ptr(),
+                                                     self._lift_work.data_ptr(), self._lift_work.numel()))
+            return
         self._chk(self.L.dt_dev_downslope_w(ctx.h, C.byref(self.win), self.p("dem"), self.p("fdr"), self.px,
                                             self.dz, 0, self.p("down"), self.n_unres.data_ptr()))
 

@@ -302,6 +302,15 @@ int dt_dev_slope_twi_w(dt_ctx *ctx, const dt_window *win, const float *dem, cons
 /* n_unresolved_dev (device int32, may be NULL): walks that left this rank's halo (marked -50) */
 int dt_dev_downslope_w(dt_ctx *ctx, const dt_window *win, const float *dem, const uint8_t *fdr, double px,
                        double elevation_difference, int raw, float *out, int32_t *n_unresolved_dev);
+/* The same with the long-walk workspace (dt_dev_downslope_lift, for a rank): `work` = dt_downslope_lift_workspace_w(win)
+ * bytes (8 per core cell for the queue, 24 per cell of the rank's memory -- core + halo -- for the skip tables).  On
+ * real terrain (flats, valley floors) the walks of thousands of moves that stay in the rank's memory are finished in
+ * skips of 64 moves instead of one dependent load per move (four ranks of the Example tiled 4 x 4: 69 -> see DESIGN.md
+ * ms); the ones that leave it are marked and counted exactly as by dt_dev_downslope_w.  Same results bit for bit. */
+int64_t dt_downslope_lift_workspace_w(const dt_window *win);
+int dt_dev_downslope_lift_w(dt_ctx *ctx, const dt_window *win, const float *dem, const uint8_t *fdr, double px,
+                            double elevation_difference, int raw, float *out, int32_t *n_unresolved_dev, void *work,
+                            int64_t work_bytes);
 /* Walks that leave a rank's memory (dt_dev_downslope_w marks them -50 and counts them) travel on as WALKERS: global
  * position (gy, gx), moves made, the path length as the reference's sequential float64 sum, the start cell's height.
  * The walkers with status 0 that stand in this rank's memory are advanced until they finish (status 1: value = the

@@ -35,7 +35,8 @@ def main():
         dist.init_process_group("gloo")
     layout = tiling.Layout.uniform(world, a.h, a.w)
     thr = (layout.Hg * layout.Wg) // 512
-    tile = tiling.RankTile(layout, rank, device=0, px=10.0, river_threshold=thr)
+    # (the plane terrain runs downslope with the long-walk workspace: the queue and the tables in real processes)
+    tile = tiling.RankTile(layout, rank, device=0, px=10.0, river_threshold=thr, long_walks=(a.terrain == "plane"))
     if a.terrain == "plane":
         # a 1 per mille plane: every downslope walk is thousands of moves long and crosses the rank borders
         h = tiling.HALO

@@ -351,12 +351,15 @@ def test_two_phase_state_is_guarded():
     t.ctx.sync()
 
 
+@pytest.mark.parametrize("long_walks", [False, True])
 @pytest.mark.parametrize("heights,widths", [([256, 256], [384, 384]), ([512], [192, 320, 256])])
-def test_downslope_walks_across_rank_borders(heights, widths):
+def test_downslope_walks_across_rank_borders(heights, widths, long_walks):
     """terrain whose walks run for thousands of moves (a 1 per mille plane, a flat, nodata): on every rank border the
     window kernel marks the cells whose walk leaves the rank's memory; tiling.finish_downslope sends them on as
     walkers from rank to rank (LocalComm: one thread per logical rank) -- the result equals the oracle's walk on the
-    whole raster, cell for cell"""
+    whole raster, cell for cell.  long_walks: the ranks run dt_dev_downslope_lift_w (queue + skip tables over core +
+    halo; on this plane more walks are long than the queue holds, so the walks a full queue leaves to the window kernel
+    are covered too)"""
     import threading
     import torch
     import oracle
@@ -375,7 +378,8 @@ def test_downslope_walks_across_rank_borders(heights, widths):
     pad[h:h + Hg, h:h + Wg] = dem
     tiles = []
     for r in range(layout.size):
-        tl = tiling.RankTile(layout, r, device=0, px=1.0, dz=5.0, river_threshold=Hg * Wg // 64)
+        tl = tiling.RankTile(layout, r, device=0, px=1.0, dz=5.0, river_threshold=Hg * Wg // 64,
+                             long_walks=long_walks)
         y0, x0 = layout.origin(r)
         tl.set_dem_ext(pad[y0:y0 + tl.He, x0:x0 + tl.We])
         tiles.append(tl)
@@ -405,4 +409,43 @@ def test_downslope_walks_across_rank_borders(heights, widths):
         assert tl.unresolved_downslope() == 0
         assert np.array_equal(got, ref, equal_nan=True), (tl.rank, int((got != ref).sum()))
         tl.free()
+    torch.cuda.empty_cache()
+
+
+def test_ranks_on_real_terrain_with_the_long_walk_workspace():
+    """the bundled Example with its GIS D8 raster (flats, valley floors: walks of thousands of moves), cropped to
+    multiples of 64 and split 2 x 2 through the middle of the data: with and without RankTile(long_walks=True) every
+    rank marks the same cells as leaving its memory, and the cells it resolves itself equal the untiled raster's"""
+    import torch
+    from conftest import load_example
+    from descriptools_amd import tiling, downslope
+    ex = load_example()
+    dem = np.ascontiguousarray(np.asarray(ex[0], np.float32)[:2176, :1472])
+    fdr = np.ascontiguousarray(np.asarray(ex[1], np.uint8)[:2176, :1472])
+    want = downslope.downsloper(dem, fdr, 12.5, 5.0)
+    layout = tiling.Layout([1088, 1088], [704, 768])
+    h = tiling.HALO
+    dem_p, fdr_p = np.pad(dem, h, constant_values=-100.0), np.pad(fdr, h, constant_values=0)
+    left = {}
+    for long_walks in (False, True):
+        for r in range(layout.size):
+            tl = tiling.RankTile(layout, r, device=0, px=12.5, dz=5.0, rasters=("dem", "fdr", "down"),
+                                 tune_placement=False, long_walks=long_walks)
+            y0, x0 = layout.origin(r)
+            tl.set_dem_ext(dem_p[y0:y0 + tl.He, x0:x0 + tl.We])
+            with tl.on_stream():
+                tl.t["fdr"].copy_(torch.as_tensor(np.ascontiguousarray(fdr_p[y0:y0 + tl.He, x0:x0 + tl.We])))
+            tl.ctx.sync()
+            tl.downslope()
+            un = tl.unresolved_downslope()
+            got = tl.host("down")
+            own = got != -50
+            assert int((~own).sum()) == un
+            ref = want[y0:y0 + tl.H, x0:x0 + tl.W]
+            assert np.array_equal(got[own].view(np.int32), ref[own].view(np.int32)), (long_walks, r)
+            left.setdefault(r, []).append((un, np.flatnonzero(~own)))
+            tl.free()
+    assert sum(v[0][0] for v in left.values()) > 1000, "the split is meant to cut through long walks"
+    for r, (a, b) in left.items():
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]), r
     torch.cuda.empty_cache()
