@@ -1,7 +1,7 @@
 """Downslope on REAL terrain IN RANKS (one GPU plays every rank in turn): the bundled Example with its GIS D8 raster
 tiled 4 x 4, cropped to multiples of 64 and split 2 x 2.  Per rank: the window kernel's time and the walks that left
 the rank's memory (the ones tiling.finish_downslope carries on as walkers).
-   python tools/ds_ranks_real.py [plain] [check]     plain: without the long-walk workspace; check: against the untiled raster"""
+   python tools/ds_ranks_real.py [plain] [check] [finish]     finish: then tiling.finish_downslope; plain: without the long-walk workspace; check: against the untiled raster"""
 import os
 import sys
 import time
@@ -27,6 +27,7 @@ if "check" in sys.argv:  # the untiled raster, to compare the cells the ranks re
     ref = ds_mod.downsloper(dem, fdr, 12.5, 5.0)
 long_walks = "plain" not in sys.argv
 total = 0.0
+tiles = []
 for r in range(layout.size):
     tile = tiling.RankTile(layout, r, px=12.5, dz=5.0, rasters=("dem", "fdr", "down"), tune_placement=False,
                            long_walks=long_walks)
@@ -52,5 +53,27 @@ for r in range(layout.size):
         assert int((~own).sum()) == un and np.array_equal(got[own].view(np.int32), want[own].view(np.int32)), "rank %d" % r
     print("rank %d (%d x %d at %d, %d): downslope %.2f ms, %d walks leave the rank's memory (%.2f %% of its cells)"
           % (r, tile.H, tile.W, gy0, gx0, min(ts) * 1e3, un, 100.0 * un / (tile.H * tile.W)), flush=True)
-    tile.free()
+    if "finish" in sys.argv:
+        tiles.append(tile)
+    else:
+        tile.free()
+if tiles:  # the walks that left their rank travel on as walkers (one thread plays each rank)
+    import threading
+    comms = tiling.LocalComm.create(layout.size)
+    done = [None] * layout.size
+
+    def work(r):
+        done[r] = tiling.finish_downslope(tiles[r], comms[r])
+    t0 = time.perf_counter()
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(layout.size)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    print("finish_downslope: %d walkers in %.1f ms (host arrays, all-gathers between threads)" % (done[0], (time.perf_counter() - t0) * 1e3))
+    if ref is not None:
+        for tile in tiles:
+            gy0, gx0 = layout.origin(tile.rank)
+            assert np.array_equal(tile.host("down").view(np.int32), ref[gy0:gy0 + tile.H, gx0:gx0 + tile.W].view(np.int32))
+        print("every rank's raster equals the untiled one")
 print("all four ranks%s: %.2f ms" % ("" if long_walks else " (without the long-walk workspace)", total * 1e3))
