@@ -978,57 +978,65 @@ def finish_downslope(tile, comm, max_iters=200):
     flats and along valley floors).  Every rank calls this after its step.  The marked cells are walked again as
     WALKERS that travel from rank to rank -- global position, moves made, the path length as the reference
     accumulates it (a sequential float64 sum, carried in the state, so the result is the reference's own arithmetic
-    whatever the route), the start cell's height: each iteration every rank advances the walkers standing in its
-    core (dt_dev_downslope_walkers_w) until they finish or reach the end of its halo, the updates are all-gathered
-    (`comm`: DistComm / LocalComm, small host arrays), and the owner of a finished walker's start cell writes the
-    value.  Returns the number of cells resolved (over all ranks); 0 without a single exchange when no rank had any."""
+    whatever the route), the start cell's height.  A rank keeps, on the device, only the walkers that stand in its
+    core: each iteration it advances them (dt_dev_downslope_walkers_w) until they finish or reach the end of its
+    memory -- either way they leave its list --, the movers are all-gathered (`comm`: DistComm / LocalComm; rows of
+    8 float64, only the walkers that moved), a finished walker's value is written by the owner of its start cell and
+    a walker on its way joins the list of the rank that owns the cell it stands on.  Returns the number of cells
+    resolved (over all ranks); 0 without a single exchange when no rank had any."""
     tc, L, layout = tile.torch, tile.L, tile.layout
     n_local = tile.unresolved_downslope()
     total = int(sum(int(np.asarray(v).reshape(-1)[0]) for v in comm.all_gather(np.asarray([n_local], np.int64))))
     if total == 0:
         return 0
+    i32, f64 = tc.int32, tc.float64
     with tile.on_stream():
         core = tile.core("down")
         ys, xs = (core == -50.0).nonzero(as_tuple=True)
-        z0 = tile.core("dem")[ys, xs].float()
-    tile.ctx.sync()
-    mine = np.zeros((len(ys), 3), np.float64)
-    mine[:, 0], mine[:, 1], mine[:, 2] = ys.cpu().numpy() + tile.gy0, xs.cpu().numpy() + tile.gx0, z0.cpu().numpy()
-    rows = np.concatenate([np.asarray(r, np.float64).reshape(-1, 3) for r in comm.all_gather(mine)], axis=0)
-    n = len(rows)
-    sy, sx = rows[:, 0].astype(np.int32), rows[:, 1].astype(np.int32)     # start cells: the same list on every rank
-    gy, gx = sy.copy(), sx.copy()                                          # where each walker stands
-    moves, dist = np.zeros(n, np.int32), np.zeros(n, np.float64)
-    zs = rows[:, 2].astype(np.float32)
-    value, status = np.zeros(n, np.float32), np.zeros(n, np.int32)
-    dev = lambda a: tc.as_tensor(a, device=tile.dev)
+        sgy, sgx = (ys + tile.gy0).to(i32), (xs + tile.gx0).to(i32)       # start cells (global)
+        gy, gx = sgy.clone(), sgx.clone()                                 # where each walker stands
+        moves, dist = tc.zeros(len(ys), dtype=i32, device=tile.dev), tc.zeros(len(ys), dtype=f64, device=tile.dev)
+        z0 = tile.core("dem")[ys, xs].float().contiguous()
     for _ in range(max_iters):
-        sel = np.nonzero((status == 0) & (layout.owner(gy.astype(np.int64), gx.astype(np.int64)) == tile.rank))[0]
-        upd = np.zeros((0, 7), np.float64)
-        if len(sel):
+        n = int(gy.numel())
+        rows = np.zeros((0, 8), np.float64)
+        if n:
             with tile.on_stream():
-                d = [dev(np.ascontiguousarray(a[sel])) for a in (gy, gx, moves, dist, zs, value, status)]
+                value = tc.zeros(n, dtype=tc.float32, device=tile.dev)
+                status = tc.zeros(n, dtype=i32, device=tile.dev)
                 tile._chk(L.dt_dev_downslope_walkers_w(tile.ctx.h, C.byref(tile.win), tile.p("dem"), tile.p("fdr"),
-                                                       tile.px, tile.dz, len(sel), *[x.data_ptr() for x in d]))
+                                                       tile.px, tile.dz, n, gy.data_ptr(), gx.data_ptr(),
+                                                       moves.data_ptr(), dist.data_ptr(), z0.data_ptr(),
+                                                       value.data_ptr(), status.data_ptr()))
+                fin = status != 0
+                # int32 / float32 values are exact in float64: one array for the exchange
+                rows_t = tc.stack([fin.to(f64), sgy.to(f64), sgx.to(f64), gy.to(f64), gx.to(f64), moves.to(f64), dist,
+                                   tc.where(fin, value, z0).to(f64)], dim=1)
             tile.ctx.sync()
-            h = [x.cpu().numpy() for x in d]
-            upd = np.stack([sel.astype(np.float64), h[0], h[1], h[2], h[3], h[5], h[6]], axis=1).astype(np.float64)
-        for u in comm.all_gather(upd):
-            u = np.asarray(u, np.float64).reshape(-1, 7)
-            if len(u):
-                k = u[:, 0].astype(np.int64)
-                gy[k], gx[k], moves[k], dist[k] = u[:, 1].astype(np.int32), u[:, 2].astype(np.int32), u[:, 3].astype(np.int32), u[:, 4]
-                value[k], status[k] = u[:, 5].astype(np.float32), u[:, 6].astype(np.int32)
-        if (status != 0).all():
+            rows = rows_t.cpu().numpy()
+        got = [np.asarray(r, np.float64).reshape(-1, 8) for r in comm.all_gather(rows)]
+        rows = np.concatenate(got, axis=0) if got else rows
+        fin = rows[:, 0] != 0
+        home = rows[fin]
+        home = home[layout.owner(home[:, 1].astype(np.int64), home[:, 2].astype(np.int64)) == tile.rank]
+        on = rows[~fin]
+        active = len(on)                                                   # the same number on every rank
+        on = on[layout.owner(on[:, 3].astype(np.int64), on[:, 4].astype(np.int64)) == tile.rank]
+        dev = lambda a, dt: tc.as_tensor(np.ascontiguousarray(a), device=tile.dev).to(dt)
+        with tile.on_stream():
+            if len(home):
+                tile.core("down")[dev(home[:, 1], tc.int64) - tile.gy0, dev(home[:, 2], tc.int64) - tile.gx0] = \
+                    dev(home[:, 7], tc.float32)
+            sgy, sgx, gy, gx = dev(on[:, 1], i32), dev(on[:, 2], i32), dev(on[:, 3], i32), dev(on[:, 4], i32)
+            moves, dist, z0 = dev(on[:, 5], i32), dev(on[:, 6], f64), dev(on[:, 7], tc.float32)
+        tile.ctx.sync()
+        if active == 0:
             break
     else:
         raise RuntimeError("finish_downslope: walkers still on their way after %d exchanges" % max_iters)
-    own = np.nonzero(layout.owner(sy.astype(np.int64), sx.astype(np.int64)) == tile.rank)[0]
-    if len(own):
-        with tile.on_stream():
-            tile.core("down")[dev(sy[own].astype(np.int64) - tile.gy0), dev(sx[own].astype(np.int64) - tile.gx0)] = dev(value[own])
-            tile.n_unres.zero_()
-        tile.ctx.sync()
+    with tile.on_stream():
+        tile.n_unres.zero_()
+    tile.ctx.sync()
     return total
 
 
