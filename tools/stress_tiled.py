@@ -27,7 +27,8 @@ for k in range(cases):
     pad[h:h + Hg, h:h + Wg] = dem
     tiles = []
     for r in range(layout.size):
-        t = tiling.RankTile(layout, r, device=0, px=px, river_threshold=thr)
+        # every other case with the long-walk workspace (queue + skip tables over core + halo)
+        t = tiling.RankTile(layout, r, device=0, px=px, river_threshold=thr, long_walks=(k % 2 == 1))
         y0, x0 = layout.origin(r)
         t.set_dem_ext(pad[y0:y0 + t.He, x0:x0 + t.We])
         tiles.append(t)
