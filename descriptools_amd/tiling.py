@@ -997,6 +997,11 @@ def finish_downslope(tile, comm, max_iters=200):
         gy, gx = sgy.clone(), sgx.clone()                                 # where each walker stands
         moves, dist = tc.zeros(len(ys), dtype=i32, device=tile.dev), tc.zeros(len(ys), dtype=f64, device=tile.dev)
         z0 = tile.core("dem")[ys, xs].float().contiguous()
+        ys_t, xs_t = tc.as_tensor(layout.ys, device=tile.dev).double(), tc.as_tensor(layout.xs, device=tile.dev).double()
+
+    def owner(y, x):  # Layout.owner on the device
+        return ((tc.bucketize(y.contiguous(), ys_t, right=True) - 1) * layout.tx +
+                (tc.bucketize(x.contiguous(), xs_t, right=True) - 1))
     for _ in range(max_iters):
         n = int(gy.numel())
         rows = np.zeros((0, 8), np.float64)
@@ -1016,19 +1021,17 @@ def finish_downslope(tile, comm, max_iters=200):
             rows = rows_t.cpu().numpy()
         got = [np.asarray(r, np.float64).reshape(-1, 8) for r in comm.all_gather(rows)]
         rows = np.concatenate(got, axis=0) if got else rows
-        fin = rows[:, 0] != 0
-        home = rows[fin]
-        home = home[layout.owner(home[:, 1].astype(np.int64), home[:, 2].astype(np.int64)) == tile.rank]
-        on = rows[~fin]
-        active = len(on)                                                   # the same number on every rank
-        on = on[layout.owner(on[:, 3].astype(np.int64), on[:, 4].astype(np.int64)) == tile.rank]
-        dev = lambda a, dt: tc.as_tensor(np.ascontiguousarray(a), device=tile.dev).to(dt)
+        # sorted out on the device: the finished walkers whose start cell is mine, the others that stand in my core
         with tile.on_stream():
-            if len(home):
-                tile.core("down")[dev(home[:, 1], tc.int64) - tile.gy0, dev(home[:, 2], tc.int64) - tile.gx0] = \
-                    dev(home[:, 7], tc.float32)
-            sgy, sgx, gy, gx = dev(on[:, 1], i32), dev(on[:, 2], i32), dev(on[:, 3], i32), dev(on[:, 4], i32)
-            moves, dist, z0 = dev(on[:, 5], i32), dev(on[:, 6], f64), dev(on[:, 7], tc.float32)
+            t = tc.as_tensor(rows, device=tile.dev)
+            fin = t[:, 0] != 0
+            home = t[fin & (owner(t[:, 1], t[:, 2]) == tile.rank)]
+            on = t[~fin & (owner(t[:, 3], t[:, 4]) == tile.rank)]
+            if home.shape[0]:
+                tile.core("down")[home[:, 1].long() - tile.gy0, home[:, 2].long() - tile.gx0] = home[:, 7].float()
+            sgy, sgx, gy, gx = (on[:, k].to(i32).contiguous() for k in (1, 2, 3, 4))
+            moves, dist, z0 = on[:, 5].to(i32).contiguous(), on[:, 6].contiguous(), on[:, 7].float().contiguous()
+            active = int((~fin).sum().item())                              # the same number on every rank
         tile.ctx.sync()
         if active == 0:
             break

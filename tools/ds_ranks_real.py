@@ -68,17 +68,25 @@ if tiles:  # the walks that left their rank travel on as walkers (one thread pla
     wr = torch.stack([(wv != 0).to(torch.float64), wy.to(torch.int32).to(torch.float64), torch.where(wv != 0, wv, wv).to(torch.float64)], dim=1).cpu()
     wz[1:9, 1:9][wy, wx] = torch.as_tensor(np.zeros(64), device="cuda").to(torch.float32)
     torch.zeros(4, dtype=torch.int32, device="cuda").zero_()
+    wb = torch.bucketize(wr.cuda()[:, 1].contiguous(), torch.as_tensor([0.0, 4.0, 8.0], device="cuda").double(), right=True)
+    wr.cuda()[(wb == 1) & ~(wb == 2)][:, 1].long(); int((wb == 1).sum().item())
     torch.cuda.synchronize()
 
     def work(r):
         done[r] = tiling.finish_downslope(tiles[r], comms[r])
-    t0 = time.perf_counter()
-    threads = [threading.Thread(target=work, args=(r,)) for r in range(layout.size)]
-    for th in threads:
-        th.start()
-    for th in threads:
-        th.join()
-    print("finish_downslope: %d walkers in %.1f ms (host arrays, all-gathers between threads)" % (done[0], (time.perf_counter() - t0) * 1e3))
+    for rnd in ("first call (torch's allocator asks the driver for every block on each rank's stream)", "second call"):
+        t0 = time.perf_counter()
+        threads = [threading.Thread(target=work, args=(r,)) for r in range(layout.size)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        print("finish_downslope, %s: %d walkers in %.1f ms (four threads play the ranks; all-gathers of host rows between them)"
+              % (rnd, done[0], (time.perf_counter() - t0) * 1e3), flush=True)
+        if rnd != "second call":
+            for tile in tiles:  # the same step again
+                tile.downslope()
+                tile.ctx.sync()
     if ref is not None:
         for tile in tiles:
             gy0, gx0 = layout.origin(tile.rank)
