@@ -1066,7 +1066,7 @@ __global__ __launch_bounds__(256) void k_ds_lift_double(const uint2 *__restrict_
 }
 // the queued walks: skips while no cell of a skip can end the walk, then the moves that remain, one by one
 template <bool RANKED>
-__global__ __launch_bounds__(256) void k_ds_finish(const float *__restrict__ dem, const uint8_t *__restrict__ fdr, DtWin w,
+__global__ __launch_bounds__(256, 8) void k_ds_finish(const float *__restrict__ dem, const uint8_t *__restrict__ fdr, DtWin w,
                                                   double px, double dz, float dzf, int raw, float *__restrict__ out,
                                                   DsQueue queue, const uint2 *__restrict__ T,
                                                   const uint2 *__restrict__ T8, int *__restrict__ n_unresolved,
