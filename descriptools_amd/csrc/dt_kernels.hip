@@ -505,13 +505,13 @@ __global__ __launch_bounds__(256) void k_downslope(const float *__restrict__ dem
 // are queued as soon as they leave the window and finished by k_ds_finish with a SKIP TABLE: for every cell, where the
 // walk stands 64 moves on (or where it cannot go on), how many of those moves are diagonal, and the lowest height on
 // the way -- the 8-move table by walking, three rounds of pointer doubling from there, only when the queue holds at least DS_LIFT_MIN walks and one
-// cell in 128 (fewer are walked out move by move by k_ds_finish: the table costs a pass over the raster).  A skip is
+// cell in 256 (fewer are walked out move by move by k_ds_finish: the table costs a pass over the raster).  A skip is
 // taken when no cell of it can end the walk: the lowest height still leaves the drop below dz (the float32
 // subtraction is monotone in the height, so the test on the minimum is exact), no move of it fails, and the 5000-move
 // cap is not reached within it; skips of 8 moves (the table of the third round, kept) follow, and the moves that
 // remain (< 8 + 8) are made one by one by the code above, so every
 // exit of the reference's walk keeps its exact meaning.
-#define DS_LIFT_MIN 256u /* and at least one cell in 128: the table costs ~170 bytes of traffic per CELL of the raster */
+#define DS_LIFT_MIN 256u /* and at least one cell in 256 (one in 128 while the entries had 16 bytes): the table costs ~170 bytes of traffic per CELL of the raster */
 struct DsQueue {
   uint4 *entries;     // {start cell, cell the walk stands on (both y * W + x), moves made, diagonal moves}
   uint32_t *count;    // walks queued (may exceed capacity: the excess stayed in the main kernel)
@@ -1177,7 +1177,7 @@ size_t dt_downslope_tables_bytes(int64_t H, int64_t W) { return 3 * dt_align256(
 size_t dt_downslope_lift_bytes(int64_t H, int64_t W) {
   return dt_downslope_queue_bytes(H, W) + dt_downslope_tables_bytes(H, W);
 }
-uint32_t dt_downslope_lift_min(int64_t H, int64_t W) { return (uint32_t)std::max<int64_t>(DS_LIFT_MIN, H * W / 128); }
+uint32_t dt_downslope_lift_min(int64_t H, int64_t W) { return (uint32_t)std::max<int64_t>(DS_LIFT_MIN, H * W / 256); }
 // ... of a window: the queue holds core cells, the tables cover the window's memory (core + halo, row stride ld)
 static size_t ds_mem_cells(const DtWin &w) { return (size_t)(w.H + 2 * (int64_t)w.halo) * (size_t)w.ld; }
 size_t dt_downslope_tables_bytes_w(const DtWin &w) { return 3 * dt_align256(ds_mem_cells(w) * 8); }
