@@ -351,6 +351,10 @@ __global__ __launch_bounds__(256, 6) void k_stencil(const float *__restrict__ de
 // wave-uniform LDS address), instead of two bank-conflicting ds_read_b32.
 // ===========================================================================================
 #define SD_MID 16u /* flag |low 29 mantissa bits - 2^28| <= SD_MID */
+// The fix-up kernels read the tile marks 256 at a time; SD_FIX_SPLIT workgroups share the marked tiles of one such
+// chunk.  (With one workgroup per chunk a raster whose tiles are ALL marked -- slopes beyond 250 %, TI / MTI near 0 on
+// many cells: 15 % of the cells of a rough synthetic DEM with 40 m pits at 10 m pixels -- ran on one workgroup per CU.)
+#define SD_FIX_SPLIT 8
 
 // value of `v` in the previous / next lane of the wave; lane 0 / lane 63 keep `edge`
 __device__ __forceinline__ float sd_from_prev_lane(float edge, float v) {
@@ -566,13 +570,13 @@ __global__ __launch_bounds__(256) void k_slope_twi_fix(const float *__restrict__
   const float pinf = __builtin_inff();
   // 256 tile marks per step, one per lane: an unmarked raster costs ceil(ntiles / 256) independent byte loads
   __shared__ uint8_t s_mark[256];
-  for (int chunk = blockIdx.x; chunk * 256 < ntiles; chunk += gridDim.x) {
+  for (int chunk = blockIdx.x / SD_FIX_SPLIT; chunk * 256 < ntiles; chunk += gridDim.x / SD_FIX_SPLIT) {
     const int mine = chunk * 256 + (int)threadIdx.x;
     const uint8_t m = mine < ntiles ? tile_mark[mine] : (uint8_t)0;
     __syncthreads();  // the previous chunk's readers are done with s_mark
     s_mark[threadIdx.x] = m;
     if (!__syncthreads_or(m)) continue;
-    for (int i = 0; i < 256; i++) {
+    for (int i = blockIdx.x % SD_FIX_SPLIT; i < 256; i += SD_FIX_SPLIT) {
       if (!s_mark[i]) continue;  // block-uniform
       const int tile = chunk * 256 + i;
       const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
@@ -732,13 +736,13 @@ __global__ __launch_bounds__(256) void k_d8_fix(const float *__restrict__ dem, D
   const double dcard = px, ddiag = px * sqrt(2.0);
   const double inv_card = 1.0 / dcard, inv_diag = 1.0 / ddiag;
   const float pinf = __builtin_inff();
-  for (int chunk = blockIdx.x; chunk * 256 < ntiles; chunk += gridDim.x) {
+  for (int chunk = blockIdx.x / SD_FIX_SPLIT; chunk * 256 < ntiles; chunk += gridDim.x / SD_FIX_SPLIT) {
     const int mine = chunk * 256 + (int)threadIdx.x;
     const uint8_t m = mine < ntiles ? tile_mark[mine] : (uint8_t)0;
     __syncthreads();
     s_mark[threadIdx.x] = m;
     if (!__syncthreads_or(m)) continue;
-    for (int i = 0; i < 256; i++) {
+    for (int i = blockIdx.x % SD_FIX_SPLIT; i < 256; i += SD_FIX_SPLIT) {
       if (!s_mark[i]) continue;  // block-uniform
       const int tile = chunk * 256 + i;
       const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
@@ -823,7 +827,7 @@ static int launch_slope_twi(hipStream_t s, const DtWin &w, const float *dem, dou
   else if (wr) DT_HOT(false, true, 1);
   else DT_HOT(false, false, 1);
 #undef DT_HOT
-  unsigned fix_blocks = (unsigned)((ntiles + 255) / 256 < 1024 ? (ntiles + 255) / 256 : 1024);
+  unsigned fix_blocks = SD_FIX_SPLIT * (unsigned)((ntiles + 255) / 256 < 1024 ? (ntiles + 255) / 256 : 1024);
   hipLaunchKernelGGL((k_slope_twi_fix<AccT, WX>), dim3(fix_blocks), b, 0, s, dem, w, px, slope, slope_rad, acc, n_top,
                      lnpx2, ti, mti, tiles_x, tiles_y, vec_ok, mark, lmask, g_tab);
   return DT_OK;
@@ -872,7 +876,7 @@ int dt_launch_stencil(hipStream_t s, const DtWin &w, const float *dem, double px
     uint8_t *mark = (uint8_t *)aux;
     uint16_t *lmask = (uint16_t *)((char *)aux + dt_align256((size_t)ntiles));
     hipLaunchKernelGGL(k_d8<false>, g, b, 0, s, dem, w, fdr, tiles_x, tiles_y, vec_ok, mark, lmask);
-    unsigned fix_blocks = (unsigned)((ntiles + 255) / 256 < 1024 ? (ntiles + 255) / 256 : 1024);
+    unsigned fix_blocks = SD_FIX_SPLIT * (unsigned)((ntiles + 255) / 256 < 1024 ? (ntiles + 255) / 256 : 1024);
     hipLaunchKernelGGL(k_d8_fix, dim3(fix_blocks), b, 0, s, dem, w, px, fdr, tiles_x, tiles_y, vec_ok, mark, lmask);
   } else if (wf) DT_GO(false, true, false);
   else if (wr) DT_GO(false, false, true);
