@@ -11,23 +11,24 @@
 #   placement_*                               tools/placement_pmc.sh / placement_probe.py: the write-conflict classes
 set -euo pipefail
 : ${GRAFT_REPO_ROOT:?}
-TAG=${1:-r3_final}
-ROUND=${2:-r3}
+TAG=${1:-r4_final}
+ROUND=${2:-r4}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+. tools/pmc_pass.sh   # every counter pass goes through pmc_pass: one TCC byte counter per pass, program after --
 OUT=gpurun_out/$TAG
 mkdir -p $OUT profiles/$ROUND
 # placement tuning off in the counter runs: its ~250 probe launches would only pad the traces (which block serves
 # which raster does not change what a kernel moves)
 B="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-verify --no-e2e --no-overlap --no-placement"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $B > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $B > $OUT/pmc_write.log 2>&1
+pmc_pass $OUT/pmc_fetch FETCH_SIZE -- $B
+pmc_pass $OUT/pmc_write WRITE_SIZE -- $B
 cp $(find $OUT/pmc_fetch -name "*counter_collection.csv" | head -1) $OUT/pmc_fetch_counter_collection.csv
 cp $(find $OUT/pmc_write -name "*counter_collection.csv" | head -1) $OUT/pmc_write_counter_collection.csv
 python3 tools/pmc_traffic.py $OUT/pmc_fetch_counter_collection.csv $OUT/pmc_write_counter_collection.csv $OUT/pmc_traffic.json > $OUT/pmc_traffic.log
 cp $OUT/pmc_traffic.json profiles/$ROUND/pmc_traffic.json
 echo "pmc done"
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/sq_a -- $B > $OUT/sq_a.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS --output-format csv -d $OUT/sq_b -- $B > $OUT/sq_b.log 2>&1
+pmc_pass $OUT/sq_a SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT -- $B
+pmc_pass $OUT/sq_b SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS -- $B
 echo "sq done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-e2e --no-overlap --no-placement > $OUT/trace.log 2>&1
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/bench16384_kernel_stats.csv
