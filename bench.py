@@ -84,12 +84,45 @@ def per_op_table(events, ops, cells, size, steps):
     return per_op, roof
 
 
+def default_workload(gpus, size, global_dem):
+    """(size, global_dem) after the defaults: --gpus 8 with neither given is BASELINE.json configs[4] -- the
+    north_star's "65536^2 DEM tiled over 8 MI355X" (2 x 4 rank tiles of 32768 x 16384; int64 accumulation and river
+    index, since the raster has 2^32 cells); everything else is the weak-scaling series of 16384^2 tiles per GPU
+    (N = 1: configs[2], the 16384^2 DEM the metric is quoted on; N = 4: configs[3], 32768^2 as 2 x 2)."""
+    if global_dem is None and size is None and gpus == 8:
+        global_dem = "65536x65536"
+    return (16384 if size is None else size), global_dem
+
+
+def tiled_layout(world, size, global_dem):
+    """the rank grid of an N > 1 run: (tiling.Layout, description).  global_dem "HxW": that raster cut into the most
+    nearly square ty x tx grid of equal rank tiles; otherwise one size x size tile per rank."""
+    from descriptools_amd import tiling
+    if global_dem:
+        Hg, Wg = (int(v) for v in global_dem.lower().split("x"))
+        grid = tiling.Layout.uniform(world, 64, 64)
+        if Hg % (64 * grid.ty) or Wg % (64 * grid.tx):
+            sys.exit("bench.py: --global %s does not cut into %d x %d rank tiles on the 64-cell grid"
+                     % (global_dem, grid.ty, grid.tx))
+        layout = tiling.Layout.uniform(world, Hg // grid.ty, Wg // grid.tx)
+        series = "global raster %dx%d%s" % (Hg, Wg, " = BASELINE.json configs[4]" if (Hg, Wg, world) == (65536, 65536, 8)
+                                            else " (--global)")
+        return layout, series
+    return (tiling.Layout.uniform(world, size, size),
+            "weak-scaling series: one %dx%d tile per GPU (--size)" % (size, size))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--size", type=int, default=16384, help="tile edge per GPU")
+    ap.add_argument("--size", type=int, default=None, help="tile edge per GPU: every rank owns one SIZE x SIZE tile (the "
+                    "weak-scaling series; default 16384 -- except --gpus 8, whose default is BASELINE.json configs[4]: "
+                    "see --global)")
+    ap.add_argument("--global", dest="global_dem", default=None, metavar="HxW", help="N > 1: the GLOBAL raster, cut into "
+                    "the most nearly square ty x tx grid of equal rank tiles.  Default for --gpus 8 (when --size is not "
+                    "given): 65536x65536 = BASELINE.json configs[4], 2 x 4 rank tiles of 32768 x 16384")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=3584, help="edge of the CPU baseline's DEM (a bounded sample: ~20 s "
@@ -113,6 +146,7 @@ def main():
                                                         "with several ranks sharing one GPU)")
     args = ap.parse_args()
     args.overlap = not args.no_overlap
+    args.size, args.global_dem = default_workload(args.gpus, args.size, args.global_dem)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(relaunch_under_torchrun(args))
@@ -384,10 +418,10 @@ def main_tiled(args, torch, dist, world, rank, local_rank, dev):
     headline = tiling.run_rank (overlapped unless --no-overlap), then a serial loop on rank 0's stream for per_op /
     roofline, cross-checks of the rasters, cpu_baseline on rank 0."""
     from descriptools_amd import chain, tiling
-    S = args.size
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
-    layout = tiling.Layout.uniform(world, S, S)
+    layout, series = tiled_layout(world, args.size, args.global_dem)
+    TH_, TW_ = layout.shape(rank)
     tile = tiling.RankTile(layout, rank, device=local_rank, stream=stream.cuda_stream, px=10.0,
                            river_threshold=(layout.Hg * layout.Wg) // 512, tune_placement=not args.no_placement)
     tile.synth_dem(args.seed)
@@ -448,11 +482,11 @@ def main_tiled(args, torch, dist, world, rank, local_rank, dev):
     dt_serial = time.perf_counter() - t1
     if use_dist:
         dt_serial = allreduce([dt_serial], dist.ReduceOp.MAX)[0]
-    per_op, roof = per_op_table(ev, op_defs, S * S, -1, args.steps)  # rank 0's own stream and tile
+    per_op, roof = per_op_table(ev, op_defs, TH_ * TW_, -1, args.steps)  # rank 0's own stream and tile
     roof["note"] += "; N > 1: rank 0's tile, the exchange stages (0 bytes) are the all-gathers' launch and wait"
 
     verified = None if args.no_verify else verify_tiled(torch, tile, layout, allreduce)
-    cells = S * S * world
+    cells = layout.Hg * layout.Wg
     sched = ("downslope as a second branch on its own stream" if args.overlap else "one stream per rank (--no-overlap)")
     out = {
         "metric": "Mcells/s full descriptor chain", "value": round(cells * args.steps / dt / 1e6, 1),
@@ -461,8 +495,10 @@ def main_tiled(args, torch, dist, world, rank, local_rank, dev):
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%dx%d synthetic tilted-integer-fBm DEM per GPU, full chain (d8, flowacc, river mask, "
                                "flowhand/HAND with fused GFI + ln(hl/H), fused slope+TI+MTI, downslope), "
-                               "device-resident" % (S, S),
-                   "global_dem": "%dx%d" % (layout.Hg, layout.Wg), "px": 10.0,
+                               "device-resident" % (TH_, TW_),
+                   "global_dem": "%dx%d" % (layout.Hg, layout.Wg), "series": series,
+                   "rank_tile": "%dx%d" % (TH_, TW_), "px": 10.0,
+                   "river_index_dtype": "int64" if tile.idx_dtype == torch.int64 else "int32",
                    "river_threshold_cells": tile.river_threshold,
                    "accumulation_dtype": "int64" if tile.acc64 else "int32",
                    "placement": tile.placement,

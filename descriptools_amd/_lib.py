@@ -183,9 +183,16 @@ def lib():
     return L
 
 
+DT_ENOMEM = -3
+
+
 def check(rc):
+    """raise for a non-zero return code of the C ABI: MemoryError for DT_ENOMEM (a full device is something a caller
+    may want to handle: placement.assign does), RuntimeError for everything else"""
     if rc != 0:
         msg = lib().dt_last_error().decode("utf-8", "replace")
+        if rc == DT_ENOMEM:
+            raise MemoryError("descriptools_hip error %d: %s" % (rc, msg))
         raise RuntimeError("descriptools_hip error %d: %s" % (rc, msg))
 
 

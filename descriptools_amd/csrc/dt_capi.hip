@@ -328,7 +328,16 @@ extern "C" int dt_dev_malloc(dt_ctx *c, int64_t bytes, void **out) {
     (void)hipGetLastError();
     *out = nullptr;
     dt_host_trim();  // the host tier's cached device blocks are the only memory this library holds on to
-    DT_HIP(hipMalloc(out, n));
+    const hipError_t e = hipMalloc(out, n);
+    if (e != hipSuccess) {
+      // the runtime keeps the last error until it is read: left in place, the hipGetLastError() behind the next
+      // kernel launch of ANY entry point would report this out-of-memory (placement.assign uses a full device as
+      // control flow)
+      (void)hipGetLastError();
+      *out = nullptr;
+      dt_set_error("hipMalloc(%zu bytes) failed: %s", n, hipGetErrorString(e));
+      return e == hipErrorOutOfMemory ? DT_ENOMEM : DT_EHIP;
+    }
   }
   return DT_OK;
 }

@@ -732,32 +732,62 @@ def halo_plan(layout, rank):
     return plan
 
 
-def exchange_halo(ext, layout, rank, halo=HALO, group=None):
-    """Point-to-point halo exchange of an extended raster `ext` ((H + 2*halo) x (W + 2*halo) torch
-    tensor, CPU for gloo / GPU for RCCL) with the <= 8 neighbouring ranks: each rank sends the border
-    strips of its core and receives its halo.  xGMI is point-to-point, the strips are KBs: eight small
-    sends per rank, no collective.  Halo cells outside the global raster are left untouched."""
+def exchange_halos(exts, layout, proc_of=None, halo=HALO, group=None):
+    """Point-to-point halo exchange of extended rasters ((H + 2*halo) x (W + 2*halo) torch tensors, CPU for gloo /
+    GPU for RCCL) with the <= 8 neighbouring ranks: each rank sends the border strips of its core and receives its
+    halo.  xGMI is point-to-point, the strips are KBs: eight small sends per rank, no collective.  Halo cells outside
+    the global raster are left untouched.
+
+    exts: {logical rank: its extended raster} -- the logical ranks that live in THIS process (one, for one process per
+    GPU); proc_of[r]: the process (group rank) holding logical rank r (default: r itself).  A neighbour that lives in
+    the same process is still served by an isend / irecv pair to oneself (torch allows it; RCCL turns it into a copy):
+    that is how a 1-GPU box exercises this very code path over RCCL (tests/test_gpu_run_rank.py).  RCCL matches the
+    sends and receives between two processes by ORDER (tags are a gloo notion), so both lists are posted in the order
+    of the key (sending logical rank, direction of the send).  gloo has no connection to oneself: there a neighbour
+    in the same process is served by a plain copy of the same strips."""
     import torch
     import torch.distributed as dist
-    H, W = layout.shape(rank)
     h = halo
+    me = dist.get_rank(group)
+    self_p2p = dist.get_backend(group) != "gloo"
     assert all(hh >= h for hh in layout.heights) and all(ww >= h for ww in layout.widths), \
         "rank tiles must be at least `halo` cells in both directions"
-    rows, cols = _halo_slices(H, W, h)
-    ops, recvs = [], []
-    for k, dy, dx, peer in halo_plan(layout, rank):
-        sbuf = ext[rows(dy, True), cols(dx, True)].contiguous()
-        rbuf = torch.empty_like(ext[rows(dy, False), cols(dx, False)]).contiguous()
-        # the peer sends towards us in the opposite direction: its tag is 7 - k
-        ops.append(dist.P2POp(dist.isend, sbuf, peer, group=group, tag=k))
-        ops.append(dist.P2POp(dist.irecv, rbuf, peer, group=group, tag=7 - k))
-        recvs.append((dy, dx, rbuf))
+    if proc_of is None:
+        proc_of = list(range(layout.size))
+    sends, recvs, local = [], [], []
+    for r in sorted(exts):
+        ext = exts[r]
+        H, W = layout.shape(r)
+        assert tuple(ext.shape) == (H + 2 * h, W + 2 * h), (r, tuple(ext.shape), (H, W))
+        rows, cols = _halo_slices(H, W, h)
+        for k, dy, dx, peer in halo_plan(layout, r):
+            if not self_p2p and int(proc_of[peer]) == me and peer in exts:
+                pH, pW = layout.shape(peer)
+                prow, pcol = _halo_slices(pH, pW, h)
+                local.append((r, dy, dx, exts[peer][prow(-dy, True), pcol(-dx, True)].clone()))
+                continue
+            sbuf = ext[rows(dy, True), cols(dx, True)].contiguous()
+            rbuf = torch.empty_like(ext[rows(dy, False), cols(dx, False)]).contiguous()
+            # the peer sends towards us in the opposite direction: its key is (peer, 7 - k)
+            sends.append(((r, k), dist.P2POp(dist.isend, sbuf, int(proc_of[peer]), group=group, tag=r * 8 + k)))
+            recvs.append(((peer, 7 - k), dist.P2POp(dist.irecv, rbuf, int(proc_of[peer]), group=group,
+                                                    tag=peer * 8 + 7 - k), r, dy, dx, rbuf))
+    sends.sort(key=lambda e: e[0])
+    recvs.sort(key=lambda e: e[0])
+    ops = [e[1] for e in sends] + [e[1] for e in recvs]
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
-    for dy, dx, rbuf in recvs:
-        ext[rows(dy, False), cols(dx, False)] = rbuf
-    return ext
+    for r, dy, dx, rbuf in [e[2:] for e in recvs] + local:
+        H, W = layout.shape(r)
+        rows, cols = _halo_slices(H, W, h)
+        exts[r][rows(dy, False), cols(dx, False)] = rbuf
+    return exts
+
+
+def exchange_halo(ext, layout, rank, halo=HALO, group=None):
+    """exchange_halos for one process per rank: `ext` is rank `rank`'s extended raster"""
+    return exchange_halos({rank: ext}, layout, None, halo, group)[rank]
 
 
 def exchange_halo_local(exts, layout, halo=HALO):
@@ -825,6 +855,39 @@ class Exchange:
             self._done = None
 
 
+class LocalExchange:
+    """Exchange for N LOGICAL ranks living in one process (one device), driven in lock-step by run_ranks_local: a
+    gather concatenates the ranks' rows, exactly what the all-gather delivers.  Same interface as Exchange, so the
+    product's schedule (rank_ops, the stages bench.py times) runs unchanged on a 1-GPU box."""
+
+    def __init__(self, tiles):
+        self.tiles = tiles
+        self.fa_all = self.fh_all = None  # (Exchange's receive buffers: a gather here returns a fresh concatenation)
+
+    def gather(self, row, out):
+        tc = self.tiles[0].torch
+        which = "fa_row" if any(row is t.fa_row for t in self.tiles) else "fh_row"
+        for t in self.tiles:
+            t.ctx.sync()
+        out = tc.cat([getattr(t, which) for t in self.tiles])
+        tc.cuda.synchronize()
+        return out
+
+    def wait(self):
+        pass
+
+
+def run_ranks_local(tiles, layout, d8=True):
+    """rank_ops() of every logical rank, stage by stage in lock-step (every rank's rows exist before anybody gathers)"""
+    ex = LocalExchange(tiles)
+    ops = [rank_ops(t, layout, ex, d8=d8) for t in tiles]
+    for i in range(len(RANK_OPS)):
+        for o in ops:
+            o[i][1]()
+    for t in tiles:
+        t.ctx.sync()
+
+
 # one rank's step as named stages in launch order: (name, algorithmic bytes per cell -- chain.OPS' definitions; 0 for
 # the exchanges --, what it covers)
 RANK_OPS = (
@@ -833,11 +896,13 @@ RANK_OPS = (
 )
 
 
-def rank_ops(tile, layout, exchange):
+def rank_ops(tile, layout, exchange, d8=True):
     """The serial schedule of one rank's step as [(name, call)] in launch order -- what run_rank(overlap=False)
     executes and bench.py times stage by stage.  The two all-gathers are the only communication; the independent
     kernels (downslope; slope+TI+MTI) are queued between each gather's launch and the wait on it, so they overlap
-    the transfer.  Nothing synchronises with the host."""
+    the transfer.  Nothing synchronises with the host.  d8=False: the tile already holds its D8 codes, core and halo
+    (condition_rank / condition_ranks: the conditioned codes; or a D8 raster from a GIS tool, Example/example.py:36) --
+    the "d8" stage is then a no-op instead of overwriting them with the plain steepest descent."""
     st = {}
 
     def fa_local():
@@ -858,19 +923,22 @@ def rank_ops(tile, layout, exchange):
         exchange.wait()
         tile.fh_solve_finish(st["fh"], fuse_gfi=True, want_a_river=False)
 
-    calls = (tile.d8, fa_local, fa_gather, tile.downslope, fa_finish_fh_local, fh_gather, tile.slope_twi, fh_finish)
+    calls = (tile.d8 if d8 else (lambda: None), fa_local, fa_gather, tile.downslope, fa_finish_fh_local, fh_gather,
+             tile.slope_twi, fh_finish)
     return [(name, fn) for (name, _), fn in zip(RANK_OPS, calls)]
 
 
-def run_rank(tile, layout, exchange, overlap=True):
+def run_rank(tile, layout, exchange, overlap=True, d8=True):
     """One step of one rank.  overlap=True (the default, as chain.Chain's): downslope runs as a second compute
     branch on its own stream from the D8 kernel to the end of the step, beside the flow kernels as well as the
-    exchanges; overlap=False: the serial schedule of rank_ops().  Nothing in the step synchronises with the host."""
+    exchanges; overlap=False: the serial schedule of rank_ops().  Nothing in the step synchronises with the host.
+    d8=False: start from the D8 codes the tile holds (see rank_ops)."""
     if not overlap:
-        for _, fn in rank_ops(tile, layout, exchange):
+        for _, fn in rank_ops(tile, layout, exchange, d8=d8):
             fn()
         return
-    tile.d8()
+    if d8:
+        tile.d8()
     tile.downslope(side=True)
     tile.fa_local(sync=False)
     tile.fill_ring_codes()

@@ -23,6 +23,9 @@ def main():
     ap.add_argument("--overlap", type=int, default=0)
     ap.add_argument("--force-world", type=int, default=0)
     ap.add_argument("--terrain", default="synth", choices=["synth", "plane"])
+    ap.add_argument("--logical", type=int, default=0, help="this ONE process plays that many logical ranks: their DEM "
+                    "halos are exchanged with isend / irecv pairs to itself over the process group (RCCL: the "
+                    "point-to-point path of the 8-GPU run on a 1-GPU box), then the ranks step in lock-step")
     a = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -33,6 +36,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
     else:
         dist.init_process_group("gloo")
+    if a.logical:
+        return logical_ranks(a, torch, dist, tiling)
     layout = tiling.Layout.uniform(world, a.h, a.w)
     thr = (layout.Hg * layout.Wg) // 512
     # (the plane terrain runs downslope with the long-walk workspace: the queue and the tables in real processes)
@@ -65,6 +70,38 @@ def main():
     names = ["dem", "fdr", "fac", "river", "fdist", "idx", "hand", "slope", "ti", "mti", "gfi", "lnhlh", "down"]
     np.savez(os.path.join(a.out, "rank%d.npz" % rank), origin=np.array(layout.origin(rank)),
              **{n: tile.host(n) for n in names})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def logical_ranks(a, torch, dist, tiling):
+    import oracle  # test infrastructure: the same generator on the host
+    layout = tiling.Layout.uniform(a.logical, a.h, a.w)
+    thr = (layout.Hg * layout.Wg) // 512
+    h = tiling.HALO
+    on_gpu = a.backend == "nccl"
+    tiles, exts = [], {}
+    for r in range(layout.size):
+        t = tiling.RankTile(layout, r, device=0, px=10.0, river_threshold=thr)
+        y0, x0 = layout.origin(r)
+        core = oracle.synth_dem(a.seed, layout.Hg, layout.Wg, y0, x0, t.H, t.W, a.nodata)
+        ext = torch.full((t.He, t.We), float("nan"), device="cuda" if on_gpu else "cpu")
+        ext[h:h + t.H, h:h + t.W] = torch.as_tensor(core).to(ext.device)
+        tiles.append(t)
+        exts[r] = ext
+    torch.cuda.synchronize()
+    tiling.exchange_halos(exts, layout, [0] * layout.size)  # every neighbour is this process: isend / irecv to itself
+    torch.cuda.synchronize()
+    for t in tiles:
+        t.set_dem_ext(exts[t.rank].cpu().numpy())
+    for _ in range(2):
+        tiling.run_ranks_local(tiles, layout)  # rank_ops(): the serial schedule bench.py times, stage by stage
+    names = ["dem", "fdr", "fac", "river", "fdist", "idx", "hand", "slope", "ti", "mti", "gfi", "lnhlh", "down"]
+    for t in tiles:
+        t.check_status()
+        assert t.unresolved_downslope() == 0
+        np.savez(os.path.join(a.out, "rank%d.npz" % t.rank), origin=np.array(layout.origin(t.rank)),
+                 **{n: t.host(n) for n in names})
     dist.barrier()
     dist.destroy_process_group()
 

@@ -2,7 +2,9 @@
 (~65 GB) and the same DEM as 2 x 2 logical ranks of 16384^2 with the product's rank-level solves on the GPU
 (tiling.simulate_dev; ~60 GB more), raster for raster identical; the size-independent properties of the chain; the
 20000-move cap biting on real terrain (paths of > 20000 moves exist at this size) and resolved identically by the
-tile hierarchy, by the rank hierarchy and by the independent global kernels (dt_set_flow_impl(1))."""
+tile hierarchy, by the rank hierarchy and by the independent global kernels (dt_set_flow_impl(1)); and the same DEM as
+1 x 2 logical ranks of 32768 x 16384 -- the rank-tile shape of configs[4] (65536^2 over 8 GPUs), with that
+configuration's int64 accumulation / river index -- through tiling.rank_ops."""
 import numpy as np
 import pytest
 
@@ -106,6 +108,34 @@ def test_config4_32768_tiled_2x2_equals_untiled():
         want = torch.where(li >= 0, gy * n + gx, li)
         assert gi.dtype == torch.int32  # 2^30 cells: the 32-bit global index
         assert torch.equal(gi.long(), want), (tl.rank, "idx")
+        tl.free()
+    del tiles
+    gc.collect()
+    torch.cuda.empty_cache()
+    # (5) BASELINE.json configs[4]'s RANK-TILE SHAPE -- 32768 x 16384 with its 64-cell halo, int64 accumulation and int64
+    # global river index as a rank of the 65536^2 raster has them -- through tiling.rank_ops (the schedule bench.py
+    # times at N = 8): 1 x 2 logical ranks of that shape are this very DEM
+    layout = tiling.Layout([n], [half, half])
+    assert layout.shape(0) == (32768, 16384)
+    tiles = []
+    for r in range(2):
+        tl = tiling.RankTile(layout, r, device=0, px=px, river_threshold=thr, acc64=True, idx64=True,
+                             tune_placement=False)
+        tl.synth_dem(1)
+        tiles.append(tl)
+    tiling.run_ranks_local(tiles, layout)
+    for tl in tiles:
+        tl.check_status()
+        assert tl.unresolved_downslope() == 0
+        y0, x0 = layout.origin(tl.rank)
+        for name in ("fdr", "river", "fdist", "hand", "slope", "ti", "mti", "gfi", "lnhlh", "down"):
+            a, b = tl.core(name), t[name][y0:y0 + tl.H, x0:x0 + tl.W]
+            assert torch.equal(a, b), ("32768x16384 rank", tl.rank, name, int((a != b).sum()))
+        assert tl.core("fac").dtype == torch.int64 and tl.core("idx").dtype == torch.int64
+        for name in ("fac", "idx"):
+            for yb in range(0, tl.H, 8192):  # (in row blocks: the int64 comparison of 2^29 cells at once needs no 8 GB)
+                a, b = tl.core(name)[yb:yb + 8192], t[name][y0 + yb:y0 + yb + 8192, x0:x0 + tl.W]
+                assert torch.equal(a, b.long()), ("32768x16384 rank", tl.rank, name)
         tl.free()
     del tiles, t, keep, dem
     gc.collect()

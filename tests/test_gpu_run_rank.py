@@ -26,7 +26,7 @@ def _free_port():
     return p
 
 
-def _launch(tmp_path, world, h, w, **kw):
+def _launch(tmp_path, world, h, w, nparts=None, **kw):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "tests", "_rank_child.py"), "--out", str(tmp_path), "--h", str(h), "--w", str(w)]
@@ -35,7 +35,7 @@ def _launch(tmp_path, world, h, w, **kw):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
-    return [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    return [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(nparts or world)]
 
 
 def _check(parts, Hg, Wg, seed, nodata, dem=None):
@@ -84,6 +84,18 @@ def test_run_rank_rccl_single_rank(tmp_path):
     8-GPU run, minus the peers"""
     parts = _launch(tmp_path, 1, 320, 448, seed=3, nodata=2, backend="nccl", force_world=2)
     _check(parts, 320, 448, 3, 2)
+
+
+def test_exchange_halo_over_rccl_to_itself_then_rank_ops(tmp_path):
+    """tiling.exchange_halos on DEVICE tensors over RCCL: one process, 2 x 3 logical ranks with nodata, every send /
+    receive pair of the 8-GPU run's point-to-point halo exchange posted to the process itself (torch allows isend to
+    oneself; RCCL matches by posting order -- the order exchange_halos establishes); then the ranks run rank_ops(),
+    the serial schedule bench.py times, in lock-step: every raster equals the untiled chain's"""
+    parts = _launch(tmp_path, 1, 192, 128, nparts=6, seed=4, nodata=2, backend="nccl", logical=6)
+    from descriptools_amd import tiling
+    layout = tiling.Layout.uniform(6, 192, 128)
+    assert (layout.ty, layout.tx) == (2, 3)
+    _check(parts, layout.Hg, layout.Wg, 4, 2)
 
 
 def test_exchange_halo_on_device_tensors():

@@ -120,3 +120,27 @@ def test_a_representative_that_conflicts_with_everybody_is_replaced(monkeypatch)
     for g in groups:
         if len(g) > 1:
             assert len({info["classes"][r] for r in g}) >= 2, (g, info)
+
+
+def test_bench_gpus8_defaults_to_config5():
+    """`bench.py --gpus 8` (what the driver's SCALE run launches) measures BASELINE.json configs[4]: the 65536^2 raster
+    as 2 x 4 rank tiles of 32768 x 16384; an explicit --size keeps the weak-scaling series; N = 4 is configs[3]"""
+    import importlib
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    bench = importlib.import_module("bench")
+    size, glob = bench.default_workload(8, None, None)
+    layout, series = bench.tiled_layout(8, size, glob)
+    assert (layout.ty, layout.tx) == (2, 4) and layout.shape(0) == (32768, 16384)
+    assert (layout.Hg, layout.Wg) == (65536, 65536) and "configs[4]" in series
+    assert layout.Hg * layout.Wg > 2 ** 31  # -> int64 accumulation and river index (RankTile defaults)
+    size, glob = bench.default_workload(8, 16384, None)
+    layout, series = bench.tiled_layout(8, size, glob)
+    assert layout.shape(0) == (16384, 16384) and (layout.Hg, layout.Wg) == (32768, 65536) and "weak" in series
+    size, glob = bench.default_workload(4, None, None)
+    layout, _ = bench.tiled_layout(4, size, glob)
+    assert (layout.Hg, layout.Wg) == (32768, 32768) and layout.shape(3) == (16384, 16384)
+    assert bench.default_workload(1, None, None) == (16384, None)
+    layout, _ = bench.tiled_layout(2, 0, "1024x2048")
+    assert (layout.ty, layout.tx) == (1, 2) and layout.shape(1) == (1024, 1024)

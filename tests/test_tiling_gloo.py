@@ -202,6 +202,59 @@ def _halo_worker(rank, port, q):
         dist.destroy_process_group()
 
 
+def _halo_multi_worker(rank, port, q):
+    """two processes, three logical ranks each (2 x 3 layout, interleaved ownership): neighbours in the other process
+    over gloo send / recv, neighbours in the same process by copy -- tiling.exchange_halos"""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from descriptools_amd import tiling
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE="2")
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    try:
+        layout = tiling.Layout([128, 70], [64, 128, 65])
+        proc_of = [0, 1, 0, 1, 0, 1]
+        h = 64
+        rng = np.random.default_rng(11)
+        glob = rng.random((layout.Hg, layout.Wg)).astype(np.float32)
+        exts = {}
+        for r in range(layout.size):
+            if proc_of[r] != rank:
+                continue
+            y0, x0 = layout.origin(r)
+            H, W = layout.shape(r)
+            e = torch.full((H + 2 * h, W + 2 * h), -7.0)
+            e[h:h + H, h:h + W] = torch.as_tensor(glob[y0:y0 + H, x0:x0 + W])
+            exts[r] = e
+        tiling.exchange_halos(exts, layout, proc_of, h)
+        pad = np.full((layout.Hg + 2 * h, layout.Wg + 2 * h), -7.0, np.float32)
+        pad[h:h + layout.Hg, h:h + layout.Wg] = glob
+        ok = True
+        for r, e in exts.items():
+            y0, x0 = layout.origin(r)
+            H, W = layout.shape(r)
+            ok &= bool(np.array_equal(e.numpy(), pad[y0:y0 + H + 2 * h, x0:x0 + W + 2 * h]))
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_world2_gloo_halo_exchange_three_logical_ranks_per_process():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_halo_multi_worker, args=(r, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), sorted(res)
+
+
 @pytest.mark.timeout(300)
 def test_world4_gloo_halo_exchange():
     import torch.multiprocessing as mp
