@@ -129,6 +129,11 @@ def main():
                     "on one thread)")
     ap.add_argument("--no-verify", action="store_true", help="skip the cross-check of the timed step's rasters")
     ap.add_argument("--no-placement", action="store_true", help="rasters in allocation order (no placement tuning)")
+    ap.add_argument("--placement", default="search", choices=["off", "own", "search"], help="which block of device memory "
+                    "serves which raster (descriptools_amd/placement.py): search (default here; an opt-in set-up option "
+                    "of a long-lived chain: bounded transient allocations until blocks of several write-conflict classes "
+                    "are found, seconds reported in config.placement.setup_s), own (the library's default: only the "
+                    "blocks the chain allocates anyway), off")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end_to_end block (host-tier API, PCIe included)")
     ap.add_argument("--e2e-size", type=int, default=16384, help="edge of the host DEM of the end_to_end block")
     ap.add_argument("--graph", action="store_true", help="N = 1: the headline loop replays the step as one HIP graph "
@@ -147,6 +152,7 @@ def main():
     args = ap.parse_args()
     args.overlap = not args.no_overlap
     args.size, args.global_dem = default_workload(args.gpus, args.size, args.global_dem)
+    args.tune = False if (args.no_placement or args.placement == "off") else (True if args.placement == "own" else "search")
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(relaunch_under_torchrun(args))
@@ -212,7 +218,7 @@ def main():
     # rasters one kernel writes together must not all lie in one class of the device's memory
     ch = chain.Chain(H, W, ctx=ctx, px=10.0, river_threshold=(H * W) // 512, alloc=alloc_ptr, release=release_ptr,
                      side_ctx=ctx2 if args.overlap else None, overlap=args.overlap, want_slope_rad=False,
-                     tune_placement=not args.no_placement)
+                     tune_placement=args.tune)
     torch.cuda.empty_cache()  # the candidates the chain did not keep go back to the device
     if (ch.placement or {}).get("spacer_GiB"):
         # the runtime defers the release of what the search allocated: the next allocation of >= 2 GiB would wait for it
@@ -423,7 +429,7 @@ def main_tiled(args, torch, dist, world, rank, local_rank, dev):
     layout, series = tiled_layout(world, args.size, args.global_dem)
     TH_, TW_ = layout.shape(rank)
     tile = tiling.RankTile(layout, rank, device=local_rank, stream=stream.cuda_stream, px=10.0,
-                           river_threshold=(layout.Hg * layout.Wg) // 512, tune_placement=not args.no_placement)
+                           river_threshold=(layout.Hg * layout.Wg) // 512, tune_placement=args.tune)
     tile.synth_dem(args.seed)
 
     use_dist = world > 1 or args.force_dist

@@ -58,6 +58,11 @@ _SIGS = {
     "dt_gfi": (ci, [c_f32p, c_i64p, c_i64p, i64, f64, f64, f64, c_f32p]),
     "dt_lnhlh": (ci, [c_f32p, c_i64p, i64, f64, f64, f64, c_f32p]),
     "dt_downslope": (ci, [c_f32p, c_u8p, i64, i64, f64, f64, ci, c_f32p]),
+    # heights in float64 (a DEM / HAND that float32 cannot hold)
+    "dt_slope_f64": (ci, [c_f64p, i64, i64, f64, c_f32p]),
+    "dt_hand_f64": (ci, [c_f64p, c_i64p, i64, c_f64p]),
+    "dt_downslope_f64": (ci, [c_f64p, c_u8p, i64, i64, f64, f64, ci, c_f32p]),
+    "dt_gfi_f64h": (ci, [c_f64p, c_i64p, c_i64p, i64, f64, f64, f64, ci, c_f32p]),
     "dt_confusion_multi": (ci, [c_f64p, c_i8p, i64, f64, c_f64p, ci, ci, c_i64p]),
     "dt_synth_dem": (ci, [u32, i64, i64, i64, i64, i64, i64, ci, c_f32p]),
     # device tier
@@ -93,7 +98,9 @@ _SIGS = {
     "dt_dev_downslope_w": (ci, [vp, vp, vp, vp, f64, f64, ci, vp, vp]),
     "dt_downslope_lift_workspace_w": (i64, [vp]),
     "dt_dev_downslope_lift_w": (ci, [vp, vp, vp, vp, f64, f64, ci, vp, vp, vp, i64]),
-    "dt_dev_downslope_walkers_w": (ci, [vp, vp, vp, vp, f64, f64, i64, vp, vp, vp, vp, vp, vp, vp]),
+    "dt_dev_downslope_emit_w": (ci, [vp, vp, vp, vp, f64, f64, ci, vp, vp, vp, i64, vp, i64]),
+    "dt_dev_downslope_walk_w": (ci, [vp, vp, vp, vp, f64, f64, i64, vp, vp, i64]),
+    "dt_dev_downslope_walk_seed_w": (ci, [vp, vp, vp, i64, vp, vp, vp]),
     "dt_dev_flowacc_local_w": (ci, [vp, vp, vp, vp, vp, vp, vp]),
     "dt_dev_flowacc_finish_w": (ci, [vp, vp, vp, vp, vp, i64, vp, vp]),
     "dt_dev_flowhand_local_w": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
@@ -102,6 +109,8 @@ _SIGS = {
     "dt_dev_minmax_scale_f32": (ci, [vp, vp, i64, C.c_float, C.c_float, C.c_float, vp]),
     "dt_dev_membench_copy": (ci, [vp, vp, vp, i64, ci]),
     "dt_dev_membench_mix": (ci, [vp, vp, vp, vp, vp, vp, i64, ci, ci, ci]),
+    "dt_dev_membench_mix_timed": (ci, [vp, vp, vp, vp, vp, vp, i64, ci, ci, ci, ci, c_f64p]),
+    "dt_dev_mem_info": (ci, [vp, c_i64p, c_i64p]),
     "dt_dev_minmax_scale_f32_f64": (ci, [vp, vp, i64, f64, f64, f64, vp]),
     "dt_dev_classify": (ci, [vp, vp, vp, i64, f64, f64, ci, ci, vp, vp, vp]),
     "dt_minmax_scale": (ci, [vp, ci, i64, f64, f64, f64, vp]),
@@ -208,30 +217,63 @@ def as_c(a, dtype):
 _EXACT_IN_F32 = (np.float32, np.float16, np.int8, np.uint8, np.int16, np.uint16, np.bool_)
 
 
-def dem_f32(dem, what="DEM"):
-    """DEM / HAND at the boundary: float32 on the device.
-
-    The reference takes height differences in the DEM's OWN dtype (slope.py:244-258 under Numba typing,
-    flowhand.py:436-438 `dem - dem[indices]`, downslope.py:468); the kernels take them in float32.  That is the same
-    arithmetic exactly when every height is a float32 value: int8 / int16 / float16 / float32 rasters always, wider
-    dtypes (float64, int32, int64) when their values happen to be representable -- a float64 array holding float32
-    values, integer heights below 2^24.  Anything else would silently lose the sub-float32 differences the reference
-    keeps, so it is refused with a ValueError (set DT_ALLOW_DEM_ROUNDING=1 to round to float32 knowingly)."""
-    a = np.asarray(dem)
-    d32 = np.ascontiguousarray(a, dtype=np.float32)
-    if a.dtype.type in _EXACT_IN_F32 or os.environ.get("DT_ALLOW_DEM_ROUNDING") == "1":
-        return d32
+def _first_inexact(a, d32):
+    """flat index of the first element of `a` that float32 cannot hold (d32 = a as float32), or -1; blockwise: no
+    second full-size temporary"""
     flat, f32 = a.reshape(-1), d32.reshape(-1)
-    step = 1 << 24  # blockwise: no second full-size temporary
+    step = 1 << 24
     for i in range(0, flat.size, step):
         blk = flat[i:i + step]
         back = f32[i:i + step].astype(a.dtype)
         same = (back == blk) | ((back != back) & (blk != blk)) if a.dtype.kind == "f" else (back == blk)
         if not same.all():
-            k = i + int(np.argmin(same))
-            raise ValueError(
-                "%s of dtype %s is not exactly representable in float32 (first at flat index %d: %r -> %r): the "
-                "reference computes height differences in the raster's own dtype, this library in float32.  Pass "
-                "float32-exact heights (or set DT_ALLOW_DEM_ROUNDING=1 to accept the rounding)"
-                % (what, a.dtype, k, flat[k].item(), f32[k].item()))
+            return i + int(np.argmin(same))
+    return -1
+
+
+def heights(raster, what="DEM"):
+    """A DEM / HAND at the boundary -> (array, wide).
+
+    The reference takes height differences in the raster's OWN dtype (slope.py:244-258 under Numba typing,
+    flowhand.py:436-438 `dem - dem[indices]`, downslope.py:468).  The tuned kernels take them in float32 -- the same
+    arithmetic exactly when every height is a float32 value: int8 / int16 / float16 / float32 rasters always, wider
+    dtypes (float64, int32, int64) when their values happen to be representable (a float64 array holding float32
+    values, integer heights below 2^24).  Those come back as (float32 array, False).  Anything else -- a genuinely
+    float64 DEM, integer heights beyond 2^24 -- comes back as (float64 array, True) and the caller uses the float64
+    entry points (dt_slope_f64, dt_hand_f64, dt_downslope_f64, dt_gfi_f64h: csrc/dt_wide.hip), which evaluate the
+    reference's expressions on the heights as they are.  Integer heights beyond 2^53 have no exact float64 either:
+    ValueError.  DT_ALLOW_DEM_ROUNDING=1 rounds everything to float32 knowingly (the fast kernels)."""
+    a = np.asarray(raster)
+    d32 = np.ascontiguousarray(a, dtype=np.float32)
+    if a.dtype.type in _EXACT_IN_F32 or os.environ.get("DT_ALLOW_DEM_ROUNDING") == "1":
+        return d32, False
+    if _first_inexact(a, d32) < 0:
+        return d32, False
+    d64 = np.ascontiguousarray(a, dtype=np.float64)
+    if a.dtype.kind in "iu" and a.dtype.itemsize == 8:
+        back = d64.astype(a.dtype)
+        if not (back == a).all():
+            k = int(np.argmin((back == a).reshape(-1)))
+            raise ValueError("%s of dtype %s holds %r (flat index %d), which float64 cannot represent: the reference "
+                             "would take differences of such heights in int64" % (what, a.dtype, a.reshape(-1)[k].item(), k))
+    return d64, True
+
+
+def dem_f32(dem, what="DEM"):
+    """DEM / HAND for an entry point that exists in float32 only (the resident chain, the net-new D8 / conditioning):
+    the float32 array when every height is a float32 value (see heights()), ValueError otherwise -- the drop-in
+    descriptor functions (sloper, flow_hand_index, hand_calculator, downsloper, gfi_calculator, ln_hl_H_calculator)
+    accept such a raster and compute in float64; set DT_ALLOW_DEM_ROUNDING=1 to round to float32 knowingly."""
+    a = np.asarray(dem)
+    d32 = np.ascontiguousarray(a, dtype=np.float32)
+    if a.dtype.type in _EXACT_IN_F32 or os.environ.get("DT_ALLOW_DEM_ROUNDING") == "1":
+        return d32
+    k = _first_inexact(a, d32)
+    if k >= 0:
+        raise ValueError(
+            "%s of dtype %s is not exactly representable in float32 (first at flat index %d: %r -> %r): the "
+            "reference computes height differences in the raster's own dtype, this entry point in float32.  Use the "
+            "drop-in descriptor functions (they take such a raster in float64), pass float32-exact heights, or set "
+            "DT_ALLOW_DEM_ROUNDING=1 to accept the rounding"
+            % (what, a.dtype, k, a.reshape(-1)[k].item(), d32.reshape(-1)[k].item()))
     return d32

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libdescriptools_hip.so")
-SOURCES = ["dt_kernels.hip", "dt_stencil.hip", "dt_tiles.hip", "dt_hydro.hip", "dt_capi.hip"]
+SOURCES = ["dt_kernels.hip", "dt_stencil.hip", "dt_tiles.hip", "dt_hydro.hip", "dt_wide.hip", "dt_capi.hip"]
 HEADERS = ["dt_common.h", "dt_kernels.h", "dt_math.h", "dt_math_coeffs.h", os.path.join("..", "..", "include", "descriptools_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function"]

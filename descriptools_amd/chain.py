@@ -47,6 +47,10 @@ class Chain:
     def __init__(self, H, W, ctx=None, px=10.0, n_top=0.1, n_gfi=0.4, b=0.1, dz=5.0,
                  river_threshold=None, alloc=None, want_slope_rad=True, side_ctx=None, overlap=True,
                  condition=False, condition_rounds=64, tune_placement=True, release=None, long_walks=False):
+        # tune_placement: True (default) -- hand the blocks this chain allocates anyway to their roles by measured
+        # write-conflict class (placement.py; ~100 probe launches, nothing else allocated); "search" -- also look for
+        # blocks of other classes when those are all alike (bounded, transient allocations of tens of GiB: a set-up
+        # option of a long-lived chain, what bench.py uses); False -- rasters in allocation order.
         """overlap (the default): downslope and the slope + TI + MTI stencil run as a second branch on their own stream
         (side_ctx, created on demand) beside the flow-accumulation / HAND kernels: ~3 % faster end to end at 16384^2.  overlap=False: one stream, kernels back to back (what per-kernel timings need:
         ops(serial=True) gives that order on a chain built either way).
@@ -79,11 +83,12 @@ class Chain:
         self._graphs = []
         for name, dt in OUTPUTS + ((("filled", F32),) if self.condition else ()):
             self.buf[name] = alloc((H, W), dt) if alloc else self.ctx.empty((H, W), dt)
+        assert tune_placement in (False, True, "search")
         self.placement = {"tuned": False, "why": "tune_placement=False"}
         if tune_placement:
-            self._tune_placement()
+            self._tune_placement(search=tune_placement == "search")
 
-    def _tune_placement(self):
+    def _tune_placement(self, search=False):
         """hand the 4-byte rasters to their roles so that no group of rasters written by one kernel lies in a single
         conflict class of the device's memory (placement.py; measured with ~100 timed launches of a write-only kernel
         at set-up, skipped for rasters below 64 MiB).  With the chain's own allocator, or an `alloc` that comes with
@@ -106,7 +111,7 @@ class Chain:
                 b.free()
             elif self._release is not None:
                 self._release(q)
-        can_grow = self._alloc is None or self._release is not None
+        can_grow = search and (self._alloc is None or self._release is not None)
 
         def spacer_alloc(nbytes):
             rows = max(int(nbytes) // (self.W * 4), 1)
@@ -123,14 +128,14 @@ class Chain:
         roles, info = placement.assign(self.ctx, self.N * 4, list(objs), [list(g) for g in WRITE_GROUPS],
                                        extra_alloc if can_grow else None, extra_release if can_grow else None,
                                        spacer_alloc=spacer_alloc if can_grow else None,
-                                       spacer_release=spacer_release if can_grow else None)
+                                       spacer_release=spacer_release if can_grow else None, search=search)
         self.placement = info
         if info.get("spacer_GiB"):
             # the runtime defers the release of the spacers: take the wait here, where it was caused
             for gib in (2, 16):
                 try:
                     self.ctx.empty((gib << 30,), np.uint8).free()
-                except (MemoryError, RuntimeError):
+                except MemoryError:
                     break
         if roles is None:
             return
@@ -171,7 +176,7 @@ class Chain:
             tb = int(L.dt_downslope_tables_workspace(self.H, self.W))
             try:
                 tables = c.empty((tb,), np.uint8)
-            except (MemoryError, RuntimeError):
+            except MemoryError:  # (DT_ENOMEM: the walks are then made move by move)
                 tables, tb = None, 0
         check(L.dt_dev_downslope_finish(c.h, self._lift_dem, self.p("fdr"), self.H, self.W, self.px, self.dz, 0,
                                         self.p("down"), self._lift_q.ptr, self._lift_q_bytes,

@@ -750,6 +750,38 @@ extern "C" int dt_dev_membench_mix(dt_ctx *c, const float *r0, const float *r1, 
   return DT_OK;
 }
 
+extern "C" int dt_dev_membench_mix_timed(dt_ctx *c, const float *r0, const float *r1, float *w0, float *w1, float *w2,
+                                         int64_t N, int n_reads, int n_writes, int nontemporal, int reps, double *ms) {
+  DT_CTX(c);
+  DT_REQUIRE(ms && reps >= 1, "bad arguments");
+  DT_TRY(dt_dev_membench_mix(c, r0, r1, w0, w1, w2, N, n_reads, n_writes, nontemporal));
+  hipEvent_t e0, e1;
+  DT_HIP(hipEventCreate(&e0));
+  DT_HIP(hipEventCreate(&e1));
+  int rc = DT_OK;
+  float t = 0.0f;
+  if (hipEventRecord(e0, c->stream) != hipSuccess) rc = DT_EHIP;
+  for (int r = 0; r < reps && rc == DT_OK; r++)
+    rc = dt_dev_membench_mix(c, r0, r1, w0, w1, w2, N, n_reads, n_writes, nontemporal);
+  if (rc == DT_OK && (hipEventRecord(e1, c->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+                      hipEventElapsedTime(&t, e0, e1) != hipSuccess)) {
+    dt_set_error("event timing failed: %s", hipGetErrorString(hipGetLastError()));
+    rc = DT_EHIP;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *ms = (double)t / reps;
+  return rc;
+}
+extern "C" int dt_dev_mem_info(dt_ctx *c, int64_t *free_bytes, int64_t *total_bytes) {
+  DT_CTX(c);
+  size_t f = 0, t = 0;
+  DT_HIP(hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = (int64_t)f;
+  if (total_bytes) *total_bytes = (int64_t)t;
+  return DT_OK;
+}
+
 extern "C" int dt_dev_i32_to_i64(dt_ctx *c, const int32_t *src, int64_t N, int64_t *dst) {
   DT_CTX(c);
   DT_TRY(dt_launch_i32_to_i64(c->stream, src, N, dst));
@@ -835,17 +867,51 @@ extern "C" int dt_dev_downslope_lift_w(dt_ctx *c, const dt_window *win, const fl
   return DT_OK;
 }
 
-// walkers of downslope walks that cross rank borders (dt_kernels.hip, k_ds_walkers; tiling.finish_downslope): the ones
-// standing in this rank's memory are advanced until they finish (status 1, value) or must be handed on (status 0)
-extern "C" int dt_dev_downslope_walkers_w(dt_ctx *c, const dt_window *win, const float *dem, const uint8_t *fdr,
-                                          double px, double dz, int64_t n, int32_t *gy, int32_t *gx, int32_t *moves,
-                                          double *dist, const float *z0, float *value, int32_t *status) {
+// dt_dev_downslope_w / _lift_w (work = NULL / the long-walk workspace) that also EMITS the walks leaving the rank's
+// memory as walker records: walkers = [count u32, pad to 256 bytes | 48-byte records], see DsWalkOut in dt_kernels.hip.
+// More walks than records fit: the count says so, the cells are marked -50 all the same.
+extern "C" int dt_dev_downslope_emit_w(dt_ctx *c, const dt_window *win, const float *dem, const uint8_t *fdr,
+                                       double px, double dz, int raw, float *out, int32_t *n_unresolved_dev,
+                                       void *work, int64_t work_bytes, void *walkers, int64_t walkers_bytes) {
+  DT_CTX(c);
+  DtWin w;
+  DT_TRY(dt_convert_window(win, &w));
+  DT_REQUIRE(dem && fdr && out, "NULL raster");
+  DT_REQUIRE(work == nullptr || work_bytes >= (int64_t)dt_downslope_lift_bytes_w(w), "downslope workspace too small");
+  DT_REQUIRE(walkers != nullptr && walkers_bytes >= 256 + 48, "walker buffer missing or too small");
+  if (n_unresolved_dev) DT_HIP(hipMemsetAsync(n_unresolved_dev, 0, sizeof(int32_t), c->stream));
+  DT_TRY(dt_launch_downslope(c->stream, w, dem, fdr, px, dz, raw, out, (int *)n_unresolved_dev, work,
+                             work ? (char *)work + dt_downslope_queue_bytes(w.H, w.W) : nullptr, 0, walkers,
+                             (size_t)walkers_bytes));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+
+// The walkers standing in this rank's memory advanced in place (k_ds_walk): rec = n records of 48 bytes; work
+// (optional) = the rank's long-walk workspace as the downslope call of this step left it (its skip tables carry
+// counting walkers across the rank 64 moves at a time).
+extern "C" int dt_dev_downslope_walk_w(dt_ctx *c, const dt_window *win, const float *dem, const uint8_t *fdr, double px,
+                                       double dz, int64_t n, void *rec, void *work, int64_t work_bytes) {
   DT_CTX(c);
   DtWin w;
   DT_TRY(dt_convert_window(win, &w));
   DT_REQUIRE(n >= 0, "negative count");
-  DT_REQUIRE(n == 0 || (dem && fdr && gy && gx && moves && dist && z0 && value && status), "NULL pointer");
-  DT_TRY(dt_launch_ds_walkers(c->stream, w, dem, fdr, px, dz, n, gy, gx, moves, dist, z0, value, status));
+  DT_REQUIRE(n == 0 || (dem && fdr && rec), "NULL pointer");
+  DT_REQUIRE(work == nullptr || work_bytes >= (int64_t)dt_downslope_lift_bytes_w(w), "downslope workspace too small");
+  DT_TRY(dt_launch_ds_walk(c->stream, w, dem, fdr, px, dz, n, rec, work));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+// records of walkers at their start cells (core coordinates ys / xs of n cells), no move made: for cells that are
+// marked -50 without a record (emission buffer too small, or a tile without one)
+extern "C" int dt_dev_downslope_walk_seed_w(dt_ctx *c, const dt_window *win, const float *dem, int64_t n,
+                                            const int32_t *ys, const int32_t *xs, void *rec) {
+  DT_CTX(c);
+  DtWin w;
+  DT_TRY(dt_convert_window(win, &w));
+  DT_REQUIRE(n >= 0, "negative count");
+  DT_REQUIRE(n == 0 || (dem && ys && xs && rec), "NULL pointer");
+  DT_TRY(dt_launch_ds_walk_seed(c->stream, w, dem, n, ys, xs, rec));
   DT_HIP(hipGetLastError());
   return DT_OK;
 }
@@ -1508,6 +1574,89 @@ extern "C" int dt_hand_f32(const float *dem, const int64_t *idx, int64_t N, floa
   DT_TRY(dt_launch_hand_i64(c->stream, d_d.as<float>(), d_i.as<int64_t>(), N, d_h.as<float>()));
   DT_HIP(hipGetLastError());
   D2H(hand, d_h, n * 4, c);
+  return dt_ctx_sync(c);
+}
+
+// ---- heights in float64 (dt_wide.hip): see include/descriptools_hip.h --------------------------------------------
+extern "C" int dt_slope_f64(const double *dem, int64_t H, int64_t W, double px, float *slope) {
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  dt_ctx *c;
+  DT_TRY(host_ctx(&c));
+  DT_TRY(dt_check_hw(H, W));
+  const size_t n = (size_t)H * W;
+  if (n == 0) return DT_OK;
+  DT_REQUIRE(dem && slope, "NULL raster");
+  DevBuf d_d, d_s;
+  DT_TRY(d_d.alloc(n * 8));
+  DT_TRY(d_s.alloc(n * 4));
+  H2D(d_d, dem, n * 8, c);
+  DT_TRY(dt_launch_slope_f64(c->stream, d_d.as<double>(), H, W, px, d_s.as<float>()));
+  DT_HIP(hipGetLastError());
+  D2H(slope, d_s, n * 4, c);
+  return dt_ctx_sync(c);
+}
+extern "C" int dt_hand_f64(const double *dem, const int64_t *idx, int64_t N, double *hand) {
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  dt_ctx *c;
+  DT_TRY(host_ctx(&c));
+  DT_REQUIRE(N >= 0, "negative size");
+  if (N == 0) return DT_OK;
+  DT_REQUIRE(dem && idx && hand, "NULL raster");
+  const size_t n = (size_t)N;
+  DevBuf d_d, d_i, d_h;
+  DT_TRY(d_d.alloc(n * 8));
+  DT_TRY(d_i.alloc(n * 8));
+  DT_TRY(d_h.alloc(n * 8));
+  H2D(d_d, dem, n * 8, c);
+  H2D(d_i, idx, n * 8, c);
+  DT_TRY(dt_launch_hand_f64(c->stream, d_d.as<double>(), d_i.as<int64_t>(), N, d_h.as<double>()));
+  DT_HIP(hipGetLastError());
+  D2H(hand, d_h, n * 8, c);
+  return dt_ctx_sync(c);
+}
+extern "C" int dt_downslope_f64(const double *dem, const uint8_t *fdr, int64_t H, int64_t W, double px, double dz,
+                                int raw, float *out) {
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  dt_ctx *c;
+  DT_TRY(host_ctx(&c));
+  DT_TRY(dt_check_hw(H, W));
+  const size_t n = (size_t)H * W;
+  if (n == 0) return DT_OK;
+  DT_REQUIRE(dem && fdr && out, "NULL raster");
+  DevBuf d_d, d_f, d_o;
+  DT_TRY(d_d.alloc(n * 8));
+  DT_TRY(d_f.alloc(n));
+  DT_TRY(d_o.alloc(n * 4));
+  H2D(d_d, dem, n * 8, c);
+  H2D(d_f, fdr, n, c);
+  DT_TRY(dt_launch_downslope_f64(c->stream, d_d.as<double>(), d_f.as<uint8_t>(), H, W, px, dz, raw, d_o.as<float>()));
+  DT_HIP(hipGetLastError());
+  D2H(out, d_o, n * 4, c);
+  return dt_ctx_sync(c);
+}
+extern "C" int dt_gfi_f64h(const double *hand, const int64_t *fac, const int64_t *idx, int64_t N, double n_gfi,
+                           double b, double size, int own_area, float *out) {
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  dt_ctx *c;
+  DT_TRY(host_ctx(&c));
+  DT_REQUIRE(N >= 0, "negative size");
+  if (N == 0) return DT_OK;
+  DT_REQUIRE(hand && fac && out && (own_area || idx), "NULL raster");
+  const size_t n = (size_t)N;
+  DevBuf d_h, d_f, d_i, d_o;
+  DT_TRY(d_h.alloc(n * 8));
+  DT_TRY(d_f.alloc(n * 8));
+  DT_TRY(d_o.alloc(n * 4));
+  H2D(d_h, hand, n * 8, c);
+  H2D(d_f, fac, n * 8, c);
+  if (!own_area) {
+    DT_TRY(d_i.alloc(n * 8));
+    H2D(d_i, idx, n * 8, c);
+  }
+  DT_TRY(dt_launch_gfi_f64h(c->stream, d_h.as<double>(), d_f.as<int64_t>(), own_area ? nullptr : d_i.as<int64_t>(), N,
+                            n_gfi, b, size, own_area, d_o.as<float>()));
+  DT_HIP(hipGetLastError());
+  D2H(out, d_o, n * 4, c);
   return dt_ctx_sync(c);
 }
 

@@ -26,9 +26,6 @@ int dt_launch_gfi_i64(hipStream_t s, const float *hand, const int64_t *area, int
                       double b, double size, float *out, int own_cell);
 int dt_launch_river_acc_i64(hipStream_t s, const int64_t *fac, const int64_t *idx, int64_t n,
                             int64_t *out);
-int dt_launch_ds_walkers(hipStream_t s, const DtWin &w, const float *dem, const uint8_t *fdr, double px, double dz,
-                         int64_t n, int32_t *gy, int32_t *gx, int32_t *moves, double *dist, const float *z0, float *value,
-                         int32_t *status);
 size_t dt_downslope_lift_bytes(int64_t H, int64_t W);
 size_t dt_downslope_queue_bytes(int64_t H, int64_t W);
 size_t dt_downslope_tables_bytes(int64_t H, int64_t W);
@@ -37,10 +34,21 @@ size_t dt_downslope_tables_bytes_w(const DtWin &w);
 size_t dt_downslope_lift_bytes_w(const DtWin &w);
 int dt_launch_downslope(hipStream_t s, const DtWin &w, const float *dem, const uint8_t *fdr, double px,
                         double dz, int raw, float *out, int *n_unresolved, void *qwork = nullptr,
-                        void *twork = nullptr, int phase = 0);
+                        void *twork = nullptr, int phase = 0, void *walkers = nullptr, size_t walkers_bytes = 0);
+int dt_launch_ds_walk(hipStream_t s, const DtWin &w, const float *dem, const uint8_t *fdr, double px, double dz,
+                      int64_t n, void *rec, void *work);
+int dt_launch_ds_walk_seed(hipStream_t s, const DtWin &w, const float *dem, int64_t n, const int32_t *ys,
+                           const int32_t *xs, void *rec);
 int dt_launch_downslope_v1(hipStream_t s, const float *dem, const uint8_t *fdr, int64_t H, int64_t W,
                            double px, double dz, int raw, float *out);
 int dt_launch_hand_i64(hipStream_t s, const float *dem, const int64_t *idx, int64_t n, float *hand);
+// dt_wide.hip: heights in float64
+int dt_launch_slope_f64(hipStream_t s, const double *dem, int64_t H, int64_t W, double px, float *slope);
+int dt_launch_hand_f64(hipStream_t s, const double *dem, const int64_t *idx, int64_t n, double *hand);
+int dt_launch_downslope_f64(hipStream_t s, const double *dem, const uint8_t *fdr, int64_t H, int64_t W, double px,
+                            double dz, int raw, float *out);
+int dt_launch_gfi_f64h(hipStream_t s, const double *hand, const int64_t *fac, const int64_t *idx, int64_t n,
+                       double expo, double b, double size, int own_area, float *out);
 int dt_launch_confusion(hipStream_t s, const double *desc, const int8_t *flood, int64_t n,
                         double nodata, const double *th_host, int nth, int under,
                         unsigned long long *counts4);

@@ -542,6 +542,63 @@ __device__ __forceinline__ int ds_lift_dx(uint32_t e) { return (int)((e >> 8) & 
 __device__ __forceinline__ uint32_t ds_lift_len(uint32_t e) { return (e >> 16) & 0x7Fu; }
 __device__ __forceinline__ uint32_t ds_lift_nd(uint32_t e) { return (e >> 23) & 0x7Fu; }
 
+// ---- walkers: downslope walks that leave a rank's memory ------------------------------------------------------------
+// A walk that reaches the end of its rank's memory (core + halo) belongs to another rank from there on.  Where it
+// leaves, the kernel EMITS its state as a walker record (round 4; until then the cell was only marked -50 and
+// descriptools_amd/tiling.finish_downslope started every such walk again at its start cell, move by move):
+//   r0 = {start cell (global row, column), cell the walk stands on (global row, column)}
+//   r1 = {moves made, diagonal moves, float bits of the start cell's height, flags}
+//   r2 = {the reference's sequential float64 path length (DSW_SEQ walkers only), float bits of the result (DSW_DONE)}
+// A walker normally only COUNTS its moves (the count form of the path length with its rounding-safety test gives the
+// reference's float32 quotient, ds_quotient below); the ~1e-7 of the walks whose quotient is not provably
+// order-independent start again as DSW_SEQ walkers, which carry the reference's own sequential sum from rank to rank.
+// tiling.finish_downslope sends the records on as device buffers (all-to-all); k_ds_walk advances them.
+#define DSW_SEQ 1u
+#define DSW_DONE 2u
+#define DSW_WORDS 12 /* 32-bit words per record */
+struct DsWalkOut {
+  uint32_t *count;  // records emitted (may exceed capacity: the excess cells are only marked -50, as before)
+  uint4 *rec;       // 3 x uint4 per record
+  uint32_t capacity;
+  __host__ __device__ DsWalkOut() : count(nullptr), rec(nullptr), capacity(0) {}
+};
+// called by the lanes whose walk leaves the rank (divergent code): ONE atomic per wave reserves their records
+__device__ __forceinline__ void ds_emit_walker(const DsWalkOut &wo, const DtWin &w, int y0, int x0, int y, int x,
+                                               uint32_t moves, uint32_t nd, float z0, uint32_t flags, double dist) {
+  const unsigned long long m = __ballot(1);
+  const uint32_t lane = __lane_id();
+  const int leader = __ffsll((long long)m) - 1;
+  uint32_t base = 0u;
+  if ((int)lane == leader) base = atomicAdd(wo.count, (uint32_t)__popcll(m));
+  base = (uint32_t)__shfl((int)base, leader);
+  const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+  if (slot < wo.capacity) {
+    uint4 *r = wo.rec + 3ull * slot;
+    const unsigned long long db = (unsigned long long)__double_as_longlong(dist);
+    r[0] = make_uint4((uint32_t)(y0 + w.gy0), (uint32_t)(x0 + w.gx0), (uint32_t)(y + w.gy0), (uint32_t)(x + w.gx0));
+    r[1] = make_uint4(moves, nd, __float_as_uint(z0), flags);
+    r[2] = make_uint4((uint32_t)db, (uint32_t)(db >> 32), 0u, 0u);
+  }
+}
+
+// float32(drop / path length) from the COUNTS of the walk, or `safe` = false when the reference's sequential float64
+// sum could round differently: see ds_finish_cell
+__device__ __forceinline__ float ds_quotient(float drop, uint32_t loop, uint32_t nd, double dcard, double ddiag,
+                                             bool &safe) {
+  const double dist = dcard * (double)(loop - nd) + ddiag * (double)nd;
+  double rc = __builtin_amdgcn_rcp(dist);
+  rc = fma(fma(-dist, rc, 1.0), rc, rc);
+  rc = fma(fma(-dist, rc, 1.0), rc, rc);
+  const double q = (double)drop * rc;
+  const uint64_t qb = (uint64_t)__double_as_longlong(q);
+  const uint32_t qlo = (uint32_t)qb, qe = (uint32_t)(qb >> 52) & 0x7FFu;
+  const uint32_t de = (uint32_t)((uint64_t)__double_as_longlong(dist) >> 52) & 0x7FFu;
+  const uint32_t m = loop + 24u;
+  const bool near_mid = ((qlo & 0x1FFFFFFFu) - (0x10000000u - m)) <= 2u * m;
+  safe = !(near_mid || (qe - 897u) > 253u || (de - 523u) > 1000u);
+  return (float)q;
+}
+
 // What one cell's fast walk in the LDS window hands over, turned into the stored value.  drop: z0 - z(cell the walk stands on) (+inf: it stepped onto nodata); loop / nd: moves
 // made / diagonal ones; stop_fail: the walk stopped on a cell that cannot be left (non-D8 code, move off the raster);
 // (y, x): rank coordinates of the cell it stands on.
@@ -552,8 +609,10 @@ __device__ __forceinline__ void ds_finish_cell(const DtWin &w, const float *__re
                                                const uint8_t *__restrict__ fdr, int y0, int x0, float z0, float drop,
                                                uint32_t loop, uint32_t nd, bool stop_fail, int y, int x, double dcard,
                                                double ddiag, double dz, float dzf, int raw, float *__restrict__ outp,
-                                               uint32_t &n_unres) {
+                                               uint32_t &n_unres, const DsWalkOut &wo) {
   bool failed = false, slow = false, unresolved = false;
+  uint32_t wflags = 0u;  // of the walker this walk becomes if it leaves the rank
+  double wdist = 0.0;
   bool cont = false;  // continue on global memory from the cell the fast walk stopped on
   if (drop < dzf) {
     // stopped on a move word: a move off the raster stops the walk (downslope.py:209-228); a non-D8
@@ -601,19 +660,10 @@ __device__ __forceinline__ void ds_finish_cell(const DtWin &w, const float *__re
     // midpoint 2^28 (and q is a normal float32, dist far from the ends of the double range).  One IEEE
     // float64 division, two products and three conversions per cell gave way to 4 FMAs and integer tests:
     // this kernel is bound by VALU issue and float64 runs at half rate.
-    const double dist = dcard * (double)(loop - nd) + ddiag * (double)nd;
-    double rc = __builtin_amdgcn_rcp(dist);
-    rc = fma(fma(-dist, rc, 1.0), rc, rc);
-    rc = fma(fma(-dist, rc, 1.0), rc, rc);
-    const double q = (double)drop * rc;
-    res = (float)q;
-    const uint64_t qb = (uint64_t)__double_as_longlong(q);
-    const uint32_t qlo = (uint32_t)qb, qe = (uint32_t)(qb >> 52) & 0x7FFu;
-    const uint32_t de = (uint32_t)((uint64_t)__double_as_longlong(dist) >> 52) & 0x7FFu;
-    const uint32_t m = loop + 24u;
-    const bool near_mid = ((qlo & 0x1FFFFFFFu) - (0x10000000u - m)) <= 2u * m;
+    bool safe;
+    res = ds_quotient(drop, loop, nd, dcard, ddiag, safe);
     // 2^-126 <= |q| < 2^128 (biased exponent 897..1150); 2^-500 <= |dist| < 2^501
-    if (near_mid || (qe - 897u) > 253u || (de - 523u) > 1000u) slow = true;
+    if (!safe) slow = true;
   }
   if (slow) {  // the reference's own walk with its sequential float64 sum, from the start, on global memory
     y = y0;
@@ -623,6 +673,7 @@ __device__ __forceinline__ void ds_finish_cell(const DtWin &w, const float *__re
     failed = false;
     unresolved = false;
     uint32_t moves = 0;
+    nd = 0u;
     while ((double)drop < dz) {
       if (!(RANKED ? dt_has_code(w, y, x) : dt_readable(w, y, x))) { unresolved = true; break; }  // the end of this rank's memory
       uint32_t code = fdr[(long long)y * w.ld + x];
@@ -641,10 +692,14 @@ __device__ __forceinline__ void ds_finish_cell(const DtWin &w, const float *__re
       if (++moves == 5000u) { failed = true; break; }
     }
     res = dist == 0.0 ? 0.0f : (float)((double)drop / dist);
+    loop = moves;
+    wflags = DSW_SEQ;
+    wdist = dist;
   }
-  if (unresolved) {  // the walk left the memory of this rank: a wider halo is needed
+  if (unresolved) {  // the walk left the memory of this rank: it goes on as a walker (tiling.finish_downslope)
     *outp = -50.0f;
     n_unres++;  // counted by the caller, which adds up before it touches the device counter
+    if (RANKED && wo.rec) ds_emit_walker(wo, w, y0, x0, y, x, loop, nd, z0, wflags, wdist);
   } else if (raw && failed) *outp = -50.0f;
   else *outp = res;
 }
@@ -655,12 +710,12 @@ __device__ __attribute__((noinline)) void ds_finish_overflow(const DtWin &w, con
                                                              const uint8_t *__restrict__ fdr, int y0, int x0, float z0,
                                                              uint32_t loop, uint32_t nd, uint32_t pos, double px,
                                                              double dz, float dzf, int raw, float *__restrict__ out,
-                                                             int *__restrict__ n_unresolved) {
+                                                             int *__restrict__ n_unresolved, DsWalkOut wo) {
   int y, x;
   ds_mem_cell(w, pos, y, x);
   uint32_t unres = 0u;
   ds_finish_cell<RANKED>(w, dem, fdr, y0, x0, z0, z0 - dem[(long long)y * w.ld + x], loop, nd, false, y, x, px,
-                        px * sqrt(2.0), dz, dzf, raw, out + (long long)y0 * w.ld + x0, unres);
+                        px * sqrt(2.0), dz, dzf, raw, out + (long long)y0 * w.ld + x0, unres, wo);
   if (unres && n_unresolved) atomicAdd(n_unresolved, (int)unres);
 }
 
@@ -699,7 +754,7 @@ __device__ __forceinline__ void ds_win_body(const float *__restrict__ dem,
                                                        const uint8_t *__restrict__ fdr, DtWin w,
                                                        double px, double dz, float dzf, int raw,
                                                        float *__restrict__ out, int tiles_x, int ntiles,
-                                                       int *__restrict__ n_unresolved, DsQueue queue) {
+                                                       int *__restrict__ n_unresolved, DsQueue queue, DsWalkOut wo) {
   constexpr int DW_WIN = DW_CORE + 2 * DW_M, DW_LD = DW_WIN + 4;
   // one LDS block: heights at byte 0, move words at byte DW_LD*DW_WIN*4 (the walk reads both from one
   // address register)
@@ -931,7 +986,7 @@ __device__ __forceinline__ void ds_win_body(const float *__restrict__ dem,
       continue;
     }
     ds_finish_cell<RANKED>(w, dem, fdr, y0, x0, z0, drop, loop, nd, stop_fail, ys, xs, dcard, ddiag, dz, dzf, raw,
-                           out + o, unres);
+                           out + o, unres, wo);
   }
   if (RANKED) {
     // on real terrain every border of a rank has such walks by the ten thousand: counted per workgroup (LDS), ONE
@@ -966,7 +1021,7 @@ __device__ __forceinline__ void ds_win_body(const float *__restrict__ dem,
         // a full queue (more than half the raster's cells): the walk is made here after all
         const float z0 = s_z[(cy + DW_M) * DW_LD + cx + DW_M];
         ds_finish_overflow<RANKED>(w, dem, fdr, y0, x0, z0, pl & 0xFFFFu, pl >> 16, pq, px, dz, dzf, raw, out,
-                                   n_unresolved);
+                                   n_unresolved, wo);
       }
       slot++;
     }
@@ -978,14 +1033,16 @@ __global__ __launch_bounds__(1024, 8) void k_downslope_win(const float *__restri
                                                        const uint8_t *__restrict__ fdr, DtWin w, double px, double dz,
                                                        float dzf, int raw, float *__restrict__ out, int tiles_x,
                                                        int ntiles, int *__restrict__ n_unresolved) {
-  ds_win_body<DW_M, false, false>(dem, fdr, w, px, dz, dzf, raw, out, tiles_x, ntiles, n_unresolved, DsQueue());
+  ds_win_body<DW_M, false, false>(dem, fdr, w, px, dz, dzf, raw, out, tiles_x, ntiles, n_unresolved, DsQueue(),
+                                  DsWalkOut());
 }
 // a rank's window (core + halo inside a larger raster): see ds_finish_cell
 __global__ __launch_bounds__(1024, 8) void k_downslope_win_r(const float *__restrict__ dem,
                                                          const uint8_t *__restrict__ fdr, DtWin w, double px,
                                                          double dz, float dzf, int raw, float *__restrict__ out,
-                                                         int tiles_x, int ntiles, int *__restrict__ n_unresolved) {
-  ds_win_body<24, false, true>(dem, fdr, w, px, dz, dzf, raw, out, tiles_x, ntiles, n_unresolved, DsQueue());
+                                                         int tiles_x, int ntiles, int *__restrict__ n_unresolved,
+                                                         DsWalkOut wo) {
+  ds_win_body<24, false, true>(dem, fdr, w, px, dz, dzf, raw, out, tiles_x, ntiles, n_unresolved, DsQueue(), wo);
 }
 // the same with the hand-over of long walks to the queue (a kernel of its own: the plain one keeps its registers)
 __global__ __launch_bounds__(1024, 8) void k_downslope_win_q(const float *__restrict__ dem,
@@ -993,7 +1050,7 @@ __global__ __launch_bounds__(1024, 8) void k_downslope_win_q(const float *__rest
                                                          double dz, float dzf, int raw, float *__restrict__ out,
                                                          int tiles_x, int ntiles, int *__restrict__ n_unresolved,
                                                          DsQueue queue) {
-  ds_win_body<24, true, false>(dem, fdr, w, px, dz, dzf, raw, out, tiles_x, ntiles, n_unresolved, queue);
+  ds_win_body<24, true, false>(dem, fdr, w, px, dz, dzf, raw, out, tiles_x, ntiles, n_unresolved, queue, DsWalkOut());
 }
 
 // ... of a rank's window: the long walks that stay in the rank's memory; the ones that leave it are counted as ever
@@ -1001,8 +1058,8 @@ __global__ __launch_bounds__(1024, 8) void k_downslope_win_rq(const float *__res
                                                           const uint8_t *__restrict__ fdr, DtWin w, double px,
                                                           double dz, float dzf, int raw, float *__restrict__ out,
                                                           int tiles_x, int ntiles, int *__restrict__ n_unresolved,
-                                                          DsQueue queue) {
-  ds_win_body<24, true, true>(dem, fdr, w, px, dz, dzf, raw, out, tiles_x, ntiles, n_unresolved, queue);
+                                                          DsQueue queue, DsWalkOut wo) {
+  ds_win_body<24, true, true>(dem, fdr, w, px, dz, dzf, raw, out, tiles_x, ntiles, n_unresolved, queue, wo);
 }
 
 // ---- skip table ------------------------------------------------------------------------------------------------
@@ -1070,7 +1127,7 @@ __global__ __launch_bounds__(256, 8) void k_ds_finish(const float *__restrict__ 
                                                   double px, double dz, float dzf, int raw, float *__restrict__ out,
                                                   DsQueue queue, const uint2 *__restrict__ T,
                                                   const uint2 *__restrict__ T8, int *__restrict__ n_unresolved,
-                                                  uint32_t lift_min) {
+                                                  uint32_t lift_min, DsWalkOut wo) {
   const uint32_t total = min(*queue.count, queue.capacity);
   const bool lifted = T != nullptr && *queue.count >= lift_min;
   const double dcard = px, ddiag = px * sqrt(2.0);
@@ -1102,73 +1159,165 @@ __global__ __launch_bounds__(256, 8) void k_ds_finish(const float *__restrict__ 
     }
     const float drop = z0 - dem[(long long)y * w.ld + x];
     ds_finish_cell<RANKED>(w, dem, fdr, y0, x0, z0, drop, loop, nd, false, y, x, dcard, ddiag, dz, dzf, raw,
-                           out + (long long)y0 * w.ld + x0, unres);
+                           out + (long long)y0 * w.ld + x0, unres, wo);
   }
   // (a rank's walks that leave its memory: one atomic per wave)
   for (int o = 32; o; o >>= 1) unres += (uint32_t)__shfl_xor((int)unres, o);
   if ((threadIdx.x & 63u) == 0u && unres && n_unresolved) atomicAdd(n_unresolved, (int)unres);
 }
 
-// ---- walks across rank borders ---------------------------------------------------------------------------------------
-// A walk that leaves a rank's memory (core + halo) is marked -50 and counted by the window kernel; on real terrain,
-// where walks run for thousands of moves, that happens along every border.  descriptools_amd/tiling.py
-// (finish_downslope) re-walks such cells as WALKERS that travel from rank to rank: global position, moves made, the
-// path length as the reference accumulates it (a sequential float64 sum: the state carries the sum itself, so the
-// result is the reference's own arithmetic whatever the route), the start cell's height.  This kernel advances the
-// walkers that stand in this rank's memory until they finish (status 1: value = downslope), or must be handed on
-// (status 0: position / moves / sum updated).
-__global__ __launch_bounds__(256) void k_ds_walkers(const float *__restrict__ dem, const uint8_t *__restrict__ fdr,
-                                                   DtWin w, double px, double dz, int64_t n, int32_t *__restrict__ gy,
-                                                   int32_t *__restrict__ gx, int32_t *__restrict__ moves,
-                                                   double *__restrict__ dist, const float *__restrict__ z0s,
-                                                   float *__restrict__ value, int32_t *__restrict__ status) {
+// ---- walks across rank borders: walker records, see DsWalkOut -------------------------------------------------------
+// Walker records (see DsWalkOut) standing in this rank's memory, advanced in place until they finish (DSW_DONE, result
+// in r2.z) or reach the end of the rank's memory again.  Counting walkers cross the rank in skips of 64 and 8 moves when
+// the rank's skip tables exist (T / T8 of the long-walk workspace, built when *qcount >= lift_min), then move by move
+// with the exact exits of the reference's walk (ds_finish_cell's continuation loop); a finished counting walker whose
+// quotient is not provably the reference's turns into a DSW_SEQ walker at its start cell (the caller sends it to the
+// owner of that cell), and DSW_SEQ walkers make the reference's own moves with its sequential float64 sum.
+__global__ __launch_bounds__(256) void k_ds_walk(const float *__restrict__ dem, const uint8_t *__restrict__ fdr, DtWin w,
+                                                double px, double dz, float dzf, int64_t n, uint4 *__restrict__ rec,
+                                                const uint2 *__restrict__ T, const uint2 *__restrict__ T8,
+                                                const uint32_t *__restrict__ qcount, uint32_t lift_min) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  if (status[i] != 0) return;
-  int y = gy[i] - w.gy0, x = gx[i] - w.gx0;
+  uint4 r0 = rec[3 * i], r1 = rec[3 * i + 1];
+  if (r1.w & DSW_DONE) return;
+  int y = (int)r0.z - w.gy0, x = (int)r0.w - w.gx0;
   if (!dt_has_code(w, y, x)) return;  // not mine: somebody else's walker
   const double dcard = px, ddiag = px * sqrt(2.0);
-  const float z0 = z0s[i];
-  int m = moves[i];
-  double d = dist[i];
-  float drop = m > 0 ? z0 - dem[(long long)y * w.ld + x] : 0.0f;
+  const float z0 = __uint_as_float(r1.z);
+  uint32_t loop = r1.x, nd = r1.y;
   bool done = false;
+  float value = 0.0f;
+  if (!(r1.w & DSW_SEQ)) {
+    if (T != nullptr && qcount != nullptr && *qcount >= lift_min) {
+#pragma unroll
+      for (int level = 0; level < 2; level++) {
+        const uint2 *__restrict__ tab = level ? T8 : T;
+        for (;;) {
+          const uint2 t = tab[ds_mem_index(w, y, x)];
+          const uint32_t len = ds_lift_len(t.x);
+          if (len == 0u || !(z0 - __uint_as_float(t.y) < dzf) || loop + len > 4999u) break;
+          y += ds_lift_dy(t.x);
+          x += ds_lift_dx(t.x);
+          loop += len;
+          nd += ds_lift_nd(t.x);
+        }
+      }
+    }
+    float drop = loop > 0u ? z0 - dem[(long long)y * w.ld + x] : 0.0f;
+    uint32_t code = dt_has_code(w, y, x) ? (uint32_t)fdr[(long long)y * w.ld + x] : 0u;
+    bool handover = false;
+    while ((double)drop < dz) {
+      if (!dt_has_code(w, y, x)) { handover = true; break; }
+      if (!dt_d8_valid(code)) break;                       // failed: the walk so far is the result
+      int dy, dx;
+      dt_d8_delta(code, dy, dx);
+      const int ny = y + dy, nx = x + dx;
+      if (!dt_in_global(w, ny, nx)) break;                 // downslope.py:209-228
+      if (!dt_readable(w, ny, nx)) { handover = true; break; }
+      const long long on = (long long)ny * w.ld + nx;
+      const float zt = dem[on];
+      code = fdr[on];
+      if (zt == DT_NODATA) break;                          // nodata ahead: stop without moving (:231-281)
+      y = ny;
+      x = nx;
+      nd += (dy != 0 && dx != 0) ? 1u : 0u;
+      drop = z0 - zt;
+      if (++loop == 5000u) break;                          // downslope.py:303-304
+    }
+    if (!handover) {
+      if (loop == 0u) {
+        done = true;  // no move: distance 0 -> 0 (downslope.py:306-309)
+      } else {
+        bool safe;
+        value = ds_quotient(drop, loop, nd, dcard, ddiag, safe);
+        if (safe) {
+          done = true;
+        } else {  // start again with the reference's sequential sum, at the start cell (whoever owns it)
+          r0.z = r0.x;
+          r0.w = r0.y;
+          rec[3 * i] = r0;
+          rec[3 * i + 1] = make_uint4(0u, 0u, r1.z, DSW_SEQ);
+          rec[3 * i + 2] = make_uint4(0u, 0u, 0u, 0u);
+          return;
+        }
+      }
+    }
+    r0.z = (uint32_t)(y + w.gy0);
+    r0.w = (uint32_t)(x + w.gx0);
+    rec[3 * i] = r0;
+    rec[3 * i + 1] = make_uint4(loop, nd, r1.z, done ? DSW_DONE : 0u);
+    if (done) rec[3 * i + 2] = make_uint4(0u, 0u, __float_as_uint(value), 0u);
+    return;
+  }
+  // DSW_SEQ: the reference's own walk, its float64 sum carried in the record
+  const uint4 r2 = rec[3 * i + 2];
+  double d = __longlong_as_double((long long)(((unsigned long long)r2.y << 32) | (unsigned long long)r2.x));
+  float drop = loop > 0u ? z0 - dem[(long long)y * w.ld + x] : 0.0f;
   while ((double)drop < dz) {
-    if (!dt_has_code(w, y, x)) break;  // the end of my memory: (y, x) lies in a neighbour's core -- hand over
-    uint32_t code = fdr[(long long)y * w.ld + x];
-    if (!dt_d8_valid(code)) { done = true; break; }  // failed: the walk so far is the result (non-raw form)
+    if (!dt_has_code(w, y, x)) break;  // the end of my memory: hand over
+    const uint32_t code = fdr[(long long)y * w.ld + x];
+    if (!dt_d8_valid(code)) { done = true; break; }
     int dy, dx;
     dt_d8_delta(code, dy, dx);
     const int ny = y + dy, nx = x + dx;
     if (!dt_in_global(w, ny, nx)) { done = true; break; }
-    if (!dt_readable(w, ny, nx)) break;  // hand over: (y, x) lies in a neighbour's core
+    if (!dt_readable(w, ny, nx)) break;
     const float zt = dem[(long long)ny * w.ld + nx];
     if (zt == DT_NODATA) { done = true; break; }
     y = ny;
     x = nx;
     d += (dy != 0 && dx != 0) ? ddiag : dcard;
     drop = z0 - zt;
-    if (++m == 5000) { done = true; break; }  // downslope.py:303-304
+    if (++loop == 5000u) { done = true; break; }
   }
   if (!((double)drop < dz)) done = true;
-  gy[i] = y + w.gy0;
-  gx[i] = x + w.gx0;
-  moves[i] = m;
-  dist[i] = d;
-  if (done) {
-    value[i] = d == 0.0 ? 0.0f : (float)((double)drop / d);
-    status[i] = 1;
-  }
+  r0.z = (uint32_t)(y + w.gy0);
+  r0.w = (uint32_t)(x + w.gx0);
+  rec[3 * i] = r0;
+  rec[3 * i + 1] = make_uint4(loop, 0u, r1.z, DSW_SEQ | (done ? DSW_DONE : 0u));
+  const unsigned long long db = (unsigned long long)__double_as_longlong(d);
+  value = d == 0.0 ? 0.0f : (float)((double)drop / d);
+  rec[3 * i + 2] = make_uint4((uint32_t)db, (uint32_t)(db >> 32), __float_as_uint(value), 0u);
 }
-int dt_launch_ds_walkers(hipStream_t s, const DtWin &w, const float *dem, const uint8_t *fdr, double px, double dz,
-                         int64_t n, int32_t *gy, int32_t *gx, int32_t *moves, double *dist, const float *z0, float *value,
-                         int32_t *status) {
-  if (n > 0)
-    hipLaunchKernelGGL(k_ds_walkers, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dem, fdr, w, px, dz, n, gy, gx,
-                       moves, dist, z0, value, status);
+// work (optional): the rank's long-walk workspace as dt_dev_downslope_lift_w left it (queue | tables)
+int dt_launch_ds_walk(hipStream_t s, const DtWin &w, const float *dem, const uint8_t *fdr, double px, double dz,
+                      int64_t n, void *rec, void *work) {
+  if (n <= 0) return DT_OK;
+  float dzf = (float)dz;
+  if ((double)dzf < dz) dzf = nextafterf(dzf, INFINITY);
+  const uint2 *T = nullptr, *T8 = nullptr;
+  const uint32_t *qc = nullptr;
+  if (work) {
+    const size_t cells = (size_t)(w.H + 2 * (int64_t)w.halo) * (size_t)w.ld;
+    char *t0 = (char *)work + dt_downslope_queue_bytes(w.H, w.W);
+    qc = (const uint32_t *)work;
+    T = (const uint2 *)t0;
+    T8 = (const uint2 *)(t0 + 2 * dt_align256(cells * 8));
+  }
+  hipLaunchKernelGGL(k_ds_walk, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dem, fdr, w, px, dz, dzf, n, (uint4 *)rec,
+                     T, T8, qc, dt_downslope_lift_min(w.H, w.W));
   return DT_OK;
 }
-
+// start records for cells marked -50 (the fallback when the emission buffer was too small, or a tile without one):
+// walkers at their start cells, no move made
+__global__ __launch_bounds__(256) void k_ds_walk_seed(const float *__restrict__ dem, DtWin w, int64_t n,
+                                                     const int32_t *__restrict__ ys, const int32_t *__restrict__ xs,
+                                                     uint4 *__restrict__ rec) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int y = ys[i], x = xs[i];
+  const uint32_t gy = (uint32_t)(y + w.gy0), gx = (uint32_t)(x + w.gx0);
+  rec[3 * i] = make_uint4(gy, gx, gy, gx);
+  rec[3 * i + 1] = make_uint4(0u, 0u, __float_as_uint(dem[(long long)y * w.ld + x]), 0u);
+  rec[3 * i + 2] = make_uint4(0u, 0u, 0u, 0u);
+}
+int dt_launch_ds_walk_seed(hipStream_t s, const DtWin &w, const float *dem, int64_t n, const int32_t *ys,
+                           const int32_t *xs, void *rec) {
+  if (n > 0)
+    hipLaunchKernelGGL(k_ds_walk_seed, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dem, w, n, ys, xs, (uint4 *)rec);
+  return DT_OK;
+}
 // workspaces of the long-walk acceleration for an H x W raster: the QUEUE (counter | one entry per two cells) and the
 // TABLES (two ping-pong skip tables and the 8-move table that is kept); dt_downslope_lift_bytes = both, back to back
 static size_t ds_queue_capacity(int64_t H, int64_t W) { return (size_t)((H * W + 1) / 2); }
@@ -1190,7 +1339,8 @@ size_t dt_downslope_lift_bytes_w(const DtWin &w) {
 // synchronise can look at the queue's counter (the first word of qwork) after phase 1 and allocate tables only when a
 // raster needs them.
 int dt_launch_downslope(hipStream_t s, const DtWin &w, const float *dem, const uint8_t *fdr, double px,
-                        double dz, int raw, float *out, int *n_unresolved, void *qwork, void *twork, int phase) {
+                        double dz, int raw, float *out, int *n_unresolved, void *qwork, void *twork, int phase,
+                        void *walkers, size_t walkers_bytes) {
   const int64_t H = w.H, W = w.W;
   int64_t n = H * W;
   if (n == 0) return DT_OK;
@@ -1200,6 +1350,15 @@ int dt_launch_downslope(hipStream_t s, const DtWin &w, const float *dem, const u
   float dzf = (float)dz;
   if ((double)dzf < dz) dzf = nextafterf(dzf, INFINITY);
   DsQueue q;
+  // walkers: [count u32, pad to 256 bytes | records of DSW_WORDS words] -- where the walks that leave a rank's memory
+  // are emitted (ranked kernels only)
+  DsWalkOut wo;
+  if (walkers && walkers_bytes >= 256 + DSW_WORDS * 4) {
+    wo.count = (uint32_t *)walkers;
+    wo.rec = (uint4 *)((char *)walkers + 256);
+    wo.capacity = (uint32_t)std::min<size_t>((walkers_bytes - 256) / (DSW_WORDS * 4), 0x7FFFFFFFu);
+    if (phase != 2) DT_HIP(hipMemsetAsync(wo.count, 0, sizeof(uint32_t), s));
+  }
   uint2 *tab[3] = {nullptr, nullptr, nullptr};  // two ping-pong tables and the 8-move table that is kept
   const bool ranked = !(w.halo == 0 && w.gy0 == 0 && w.gx0 == 0 && w.Hg == w.H && w.Wg == w.W);
   // margin of the LDS window around the 64 x 64 core: walks that reach the window's ring carry on in global memory
@@ -1225,10 +1384,10 @@ int dt_launch_downslope(hipStream_t s, const DtWin &w, const float *dem, const u
                          out, tiles_x, (int)ntiles, n_unresolved);
     else if (ranked && q.entries)
       hipLaunchKernelGGL(k_downslope_win_rq, dim3((unsigned)ntiles), dim3(1024), 0, s, dem, fdr, w, px, dz, dzf, raw,
-                         out, tiles_x, (int)ntiles, n_unresolved, q);
+                         out, tiles_x, (int)ntiles, n_unresolved, q, wo);
     else if (ranked)
       hipLaunchKernelGGL(k_downslope_win_r, dim3((unsigned)ntiles), dim3(1024), 0, s, dem, fdr, w, px, dz, dzf, raw,
-                         out, tiles_x, (int)ntiles, n_unresolved);
+                         out, tiles_x, (int)ntiles, n_unresolved, wo);
     else if (q.entries)
       hipLaunchKernelGGL(k_downslope_win_q, dim3((unsigned)ntiles), dim3(1024), 0, s, dem, fdr, w, px, dz, dzf, raw,
                          out, tiles_x, (int)ntiles, n_unresolved, q);
@@ -1256,10 +1415,10 @@ int dt_launch_downslope(hipStream_t s, const DtWin &w, const float *dem, const u
     const unsigned fin_blocks = (unsigned)std::min<size_t>((q.capacity + 255) / 256, 8192);
     if (ranked)
       hipLaunchKernelGGL(k_ds_finish<true>, dim3(fin_blocks), b, 0, s, dem, fdr, w, px, dz, dzf, raw, out, q,
-                         (const uint2 *)src, (const uint2 *)tab[2], n_unresolved, lift_min);
+                         (const uint2 *)src, (const uint2 *)tab[2], n_unresolved, lift_min, wo);
     else
       hipLaunchKernelGGL(k_ds_finish<false>, dim3(fin_blocks), b, 0, s, dem, fdr, w, px, dz, dzf, raw, out, q,
-                         (const uint2 *)src, (const uint2 *)tab[2], n_unresolved, lift_min);
+                         (const uint2 *)src, (const uint2 *)tab[2], n_unresolved, lift_min, DsWalkOut());
   }
   return DT_OK;
 }

@@ -4,17 +4,21 @@ kernel restates both (a walk the kernel completes is identical in the repair).""
 import numpy as np
 
 from . import _lib
-from ._lib import c_f32p, c_u8p, check, dem_f32, ptr
+from ._lib import c_f32p, c_f64p, c_u8p, check, heights, ptr
 from .device import host_empty, widen64
 
 
 def _run(dem, flow_direction, px, elevation_difference, raw):
-    d = dem_f32(dem)
+    d, wide = heights(dem)
     fdr = np.ascontiguousarray(flow_direction, np.uint8)
     H, W = d.shape
     out = host_empty((H, W), np.float32)
-    check(_lib.lib().dt_downslope(ptr(d, c_f32p), ptr(fdr, c_u8p), H, W, float(px),
-                                  float(elevation_difference), raw, ptr(out, c_f32p)))
+    if wide:  # heights that float32 cannot hold: the walk on float64 heights (downslope.py:468 in the DEM's own dtype)
+        check(_lib.lib().dt_downslope_f64(ptr(d, c_f64p), ptr(fdr, c_u8p), H, W, float(px),
+                                          float(elevation_difference), raw, ptr(out, c_f32p)))
+    else:
+        check(_lib.lib().dt_downslope(ptr(d, c_f32p), ptr(fdr, c_u8p), H, W, float(px),
+                                      float(elevation_difference), raw, ptr(out, c_f32p)))
     return out
 
 

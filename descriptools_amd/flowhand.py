@@ -3,7 +3,7 @@ descriptools/flowhand.py (the reference's per-cell pointer chase becomes pointer
 import numpy as np
 
 from . import _lib
-from ._lib import c_f32p, c_i8p, c_i64p, c_u8p, check, dem_f32, ptr
+from ._lib import c_f32p, c_f64p, c_i8p, c_i64p, c_u8p, check, heights, ptr
 from .device import host_empty
 
 
@@ -16,26 +16,38 @@ def flow_hand_index(dem_raster, flow_direction_matrix, river_matrix, px, divisio
                     division_row=0):
     """flowhand.py:242-411 -> (flow_distance float32, indices int64, hand in the DEM's dtype).
     One tile (division_* accepted, ignored: tiled == untiled is the reference's contract)."""
-    dem32 = dem_f32(dem_raster)
+    dem, wide = heights(dem_raster)
     fdr = np.ascontiguousarray(flow_direction_matrix, np.uint8)
     river = np.ascontiguousarray(river_matrix, np.int8)
     H, W = fdr.shape
     fd = host_empty((H, W), np.float32)
     idx = host_empty((H, W), np.int64)
-    hand = host_empty((H, W), np.float32)
-    check(_lib.lib().dt_flowhand(ptr(dem32, c_f32p), ptr(fdr, c_u8p), ptr(river, c_i8p), H, W, float(px),
-                                 ptr(fd, c_f32p), ptr(idx, c_i64p), ptr(hand, c_f32p)))
     ht = _hand_dtype(dem_raster)
+    if wide:
+        # heights that float32 cannot hold: flow distance and river index do not read them; HAND = dem - dem[idx] in
+        # float64 (flowhand.py:436-438 in the DEM's own dtype)
+        check(_lib.lib().dt_flowhand(None, ptr(fdr, c_u8p), ptr(river, c_i8p), H, W, float(px),
+                                     ptr(fd, c_f32p), ptr(idx, c_i64p), None))
+        hand = host_empty((H, W), np.float64)
+        check(_lib.lib().dt_hand_f64(ptr(dem, c_f64p), ptr(idx, c_i64p), dem.size, ptr(hand, c_f64p)))
+        return fd, idx, (hand if ht == np.float64 else hand.astype(ht))
+    hand = host_empty((H, W), np.float32)
+    check(_lib.lib().dt_flowhand(ptr(dem, c_f32p), ptr(fdr, c_u8p), ptr(river, c_i8p), H, W, float(px),
+                                 ptr(fd, c_f32p), ptr(idx, c_i64p), ptr(hand, c_f32p)))
     return fd, idx, (hand if ht == np.float32 else hand.astype(ht))
 
 
 def hand_calculator(dem, indices):
     """flowhand.py:414-442."""
-    dem32 = dem_f32(dem)
+    d, wide = heights(dem)
     idx = np.ascontiguousarray(indices, np.int64)
-    hand = host_empty(dem32.shape, np.float32)
-    check(_lib.lib().dt_hand_f32(ptr(dem32, c_f32p), ptr(idx, c_i64p), dem32.size, ptr(hand, c_f32p)))
     ht = _hand_dtype(dem)
+    if wide:
+        hand = host_empty(d.shape, np.float64)
+        check(_lib.lib().dt_hand_f64(ptr(d, c_f64p), ptr(idx, c_i64p), d.size, ptr(hand, c_f64p)))
+        return hand if ht == np.float64 else hand.astype(ht)
+    hand = host_empty(d.shape, np.float32)
+    check(_lib.lib().dt_hand_f32(ptr(d, c_f32p), ptr(idx, c_i64p), d.size, ptr(hand, c_f32p)))
     return hand if ht == np.float32 else hand.astype(ht)
 
 

@@ -2,7 +2,7 @@
 import numpy as np
 
 from . import _lib
-from ._lib import c_f32p, c_i64p, check, dem_f32, ptr
+from ._lib import c_f32p, c_f64p, c_i64p, check, heights, ptr
 from .device import host_empty, widen64
 
 
@@ -16,9 +16,13 @@ def river_accumulation(flow_accumulation, indices):
 
 
 def _area_index(hand, area, expoent, scale_factor, size, zero_guard):
-    h = dem_f32(hand, "HAND")
+    h, wide = heights(hand, "HAND")
     a = np.ascontiguousarray(area, np.int64)
     out = host_empty(h.shape, np.float32)
+    if wide:  # a HAND that float32 cannot hold (from a float64 DEM): hand + 0.01 on the float64 value, gfi.py:292-294
+        check(_lib.lib().dt_gfi_f64h(ptr(h, c_f64p), ptr(a, c_i64p), None, h.size, float(expoent), float(scale_factor),
+                                     float(size), 1 if zero_guard else 2, ptr(out, c_f32p)))
+        return out
     check(_lib.lib().dt_gfi_area(ptr(h, c_f32p), ptr(a, c_i64p), h.size, float(expoent), float(scale_factor),
                                  float(size), zero_guard, ptr(out, c_f32p)))
     return out
@@ -33,12 +37,16 @@ def geomorphic_flood_index_cpu(hand, river_flow_accumulation, expoent, scale_fac
 def gfi_calculator(hand, flow_accumulation, indices, n_gfi, scale_factor, size, division_column=0,
                    division_row=0):
     """gfi.py:150-207 -> float64 raster holding float32 values."""
-    h = dem_f32(hand, "HAND")
+    h, wide = heights(hand, "HAND")
     fac = np.ascontiguousarray(flow_accumulation, np.int64)
     idx = np.ascontiguousarray(indices, np.int64)
     out = host_empty(h.shape, np.float32)
-    check(_lib.lib().dt_gfi(ptr(h, c_f32p), ptr(fac, c_i64p), ptr(idx, c_i64p), h.size, float(n_gfi),
-                            float(scale_factor), float(size), ptr(out, c_f32p)))
+    if wide:
+        check(_lib.lib().dt_gfi_f64h(ptr(h, c_f64p), ptr(fac, c_i64p), ptr(idx, c_i64p), h.size, float(n_gfi),
+                                     float(scale_factor), float(size), 0, ptr(out, c_f32p)))
+    else:
+        check(_lib.lib().dt_gfi(ptr(h, c_f32p), ptr(fac, c_i64p), ptr(idx, c_i64p), h.size, float(n_gfi),
+                                float(scale_factor), float(size), ptr(out, c_f32p)))
     return widen64(out)
 
 

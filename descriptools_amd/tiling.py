@@ -29,6 +29,8 @@ FA_CYCLE = np.uint64(1 << 63)
 CAP = 20000
 K_RIVER, K_DEAD, K_REXIT = 1, 2, 4
 HALO = 64
+WALKER_WORDS, WALKER_BYTES = 12, 48   # a walker record (include/descriptools_hip.h, dt_dev_downslope_emit_w)
+W_SEQ, W_DONE = 1, 2
 
 _DY = {1: 0, 2: 1, 4: 1, 8: 1, 16: 0, 32: -1, 64: -1, 128: -1}
 _DX = {1: 1, 2: 1, 4: 0, 8: -1, 16: -1, 32: -1, 64: 0, 128: 1}
@@ -262,12 +264,17 @@ class RankTile:
 
     def __init__(self, layout, rank, device=0, stream=None, px=10.0, n_top=0.1, n_gfi=0.4, b=0.1, dz=5.0,
                  river_threshold=None, halo=HALO, idx64=None, acc64=None, rasters=None, tune_placement=True,
-                 long_walks=False):
+                 long_walks=False, emit_walkers=None):
         """acc64: flow accumulation (and the river accumulation payload) as int64 rasters, the reference's dtype --
         the default for a global raster of more than 2^31 cells, where a basin can exceed 32 bits; int32 rasters
         otherwise (exact: an accumulation is at most cells - 1; half the bytes).  rasters: names of the rasters to allocate (default: all).
-        tune_placement: hand the 4-byte rasters to their roles by measured write-conflict class (placement.py; only
-        rasters of >= 64 MiB are measured).
+        tune_placement: True -- hand the 4-byte rasters this tile allocates anyway to their roles by measured
+        write-conflict class (placement.py; only rasters of >= 64 MiB are measured); "search" -- also look for blocks
+        of other classes when those are all alike (bounded transient allocations on THIS rank's device, seconds of
+        set-up: bench.py); False -- allocation order.
+        emit_walkers: downslope emits the walks that leave this rank's memory as walker records on the device (48 bytes
+        each, room for one per 64 core cells; finish_downslope sends them on from where they are) -- default: with
+        long_walks, i.e. on real terrain; without it such walks are found by their -50 marks and start again.
         long_walks: downslope with the long-walk workspace (dt_dev_downslope_lift_w: 8 bytes per core cell + 24 per
         cell of core + halo, allocated at the first downslope call) -- for real terrain, where flats and valley floors
         make walks thousands of moves long; same results."""
@@ -277,6 +284,8 @@ class RankTile:
         self.torch, self._lib, self.L = torch, _lib, _lib.lib()
         self.layout, self.rank, self.halo = layout, rank, halo
         self.long_walks, self._lift_work = bool(long_walks), None
+        self.emit_walkers = bool(long_walks) if emit_walkers is None else bool(emit_walkers)
+        self._walkers = None
         self.H, self.W = layout.shape(rank)
         self.gy0, self.gx0 = layout.origin(rank)
         self.He, self.We = self.H + 2 * halo, self.W + 2 * halo
@@ -322,9 +331,10 @@ class RankTile:
             if rasters is None or name in rasters:
                 t[name] = torch.zeros((self.He, self.We), dtype=dt, device=self.dev)
         self.t = t
+        assert tune_placement in (False, True, "search")
         self.placement = {"tuned": False, "why": "tune_placement=False"}
         if tune_placement:
-            self._tune_placement()
+            self._tune_placement(search=tune_placement == "search")
         self.n_unres = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self.win = _lib.Window(self.H, self.W, self.We, self.gy0, self.gx0, layout.Hg, layout.Wg, halo)
         ys, xs = ring_coords(self.H, self.W)
@@ -351,7 +361,7 @@ class RankTile:
         self._on_ts.__exit__(None, None, None)
         self.ctx.sync()  # the buffers exist and are zero before anybody (any stream) touches them
 
-    def _tune_placement(self):
+    def _tune_placement(self, search=False):
         """placement.assign over this tile's 4-byte rasters (chain.Chain._tune_placement's counterpart): the rasters
         one kernel writes together -- slope / TI / MTI; fdist / idx / hand / GFI / ln(hl/H) -- must not all lie in
         one conflict class of the device's memory; further candidate blocks are tried when the first ones are alike"""
@@ -379,7 +389,7 @@ class RankTile:
             del x
         self.ctx.sync()
         roles, info = placement.assign(self.ctx, self.He * self.We * 4, list(objs), groups, extra_alloc, extra_release,
-                                       spacer_alloc=spacer_alloc, spacer_release=spacer_release)
+                                       spacer_alloc=spacer_alloc, spacer_release=spacer_release, search=search)
         self.placement = info
         if roles is None:
             return
@@ -392,7 +402,7 @@ class RankTile:
         if info.get("spacer_GiB"):  # the runtime defers the release of the spacers: take the wait here (placement.assign)
             try:
                 self.ctx.empty((2 << 30,), np.uint8).free()
-            except (MemoryError, RuntimeError):
+            except MemoryError:
                 pass
 
     def on_stream(self):
@@ -557,6 +567,7 @@ class RankTile:
         self.ctx.sync()
         self.t, self._keep, self._keep2, self._keep_rows, self._keep_rows2 = {}, None, None, None, None
         self.fa_row = self.fh_row = self._ext = self._res = self._fa_v = self._fh_v = self._lift_work = None
+        self._walkers = None
         self.side_ctx.close()
         self.ctx.close()
 
@@ -622,12 +633,25 @@ class RankTile:
         if side:
             self.ctx.fork(self.side_ctx)
             ctx = self.side_ctx
-        if self.long_walks:
-            if self._lift_work is None:
-                nb = int(self.L.dt_downslope_lift_workspace_w(C.byref(self.win)))
+        if self.long_walks and self._lift_work is None:
+            nb = int(self.L.dt_downslope_lift_workspace_w(C.byref(self.win)))
+            with self.on_stream():
+                self._lift_work = self.torch.empty(nb, dtype=self.torch.uint8, device=self.dev)
+            self.ctx.sync()  # (the side stream may be the one that uses it)
+        if self.emit_walkers:
+            if self._walkers is None:
+                cap = max(self.H * self.W // 64, 65536)
                 with self.on_stream():
-                    self._lift_work = self.torch.empty(nb, dtype=self.torch.uint8, device=self.dev)
-                self.ctx.sync()  # (the side stream may be the one that uses it)
+                    self._walkers = self.torch.zeros(256 + WALKER_BYTES * cap, dtype=self.torch.uint8, device=self.dev)
+                self.ctx.sync()
+            work = self._lift_work
+            self._chk(self.L.dt_dev_downslope_emit_w(ctx.h, C.byref(self.win), self.p("dem"), self.p("fdr"), self.px,
+                                                     self.dz, 0, self.p("down"), self.n_unres.data_ptr(),
+                                                     work.data_ptr() if work is not None else None,
+                                                     work.numel() if work is not None else 0,
+                                                     self._walkers.data_ptr(), self._walkers.numel()))
+            return
+        if self.long_walks:
             self._chk(self.L.dt_dev_downslope_lift_w(ctx.h, C.byref(self.win), self.p("dem"), self.p("fdr"), self.px,
                                                      self.dz, 0, self.p("down"), self.n_unres.data_ptr(),
                                                      self._lift_work.data_ptr(), self._lift_work.numel()))
@@ -1001,23 +1025,48 @@ def simulate_dev(tiles, layout, d8=True):
 # evaluation of a tiled descriptor (BASELINE.json configs[4]: "full chain + evaluation.py flood-map classifier")
 # ---------------------------------------------------------------------------------------------------
 class DistComm:
-    """all_gather of small host arrays over torch.distributed (RCCL ranks gather through the CPU: the payloads are
-    3-96 numbers per calibration stage)"""
+    """what a rank exchanges with the others outside its step, over torch.distributed: small host arrays
+    (all_gather: the classifier's extremes and counts, 3-96 numbers per calibration stage) and walker records
+    (exchange_rows: an all-to-all of DEVICE buffers over RCCL; through the CPU on gloo, the rehearsal backend)"""
 
     def __init__(self, group=None):
         import torch.distributed as dist
         self.dist, self.group = dist, group
         self.rank, self.size = dist.get_rank(group), dist.get_world_size(group)
+        self.cpu = dist.get_backend(group) == "gloo"
 
     def all_gather(self, value):
         out = [None] * self.size
         self.dist.all_gather_object(out, np.asarray(value), group=self.group)
         return out
 
+    def all_gather_ints(self, vec):
+        """vec: int64 device tensor [k] -> host numpy [size, k] (one small collective, one synchronisation)"""
+        import torch
+        v = vec.to(torch.int64)
+        if self.cpu:
+            v = v.cpu()
+        out = torch.empty(self.size * v.numel(), dtype=torch.int64, device=v.device)
+        self.dist.all_gather_into_tensor(out, v.contiguous(), group=self.group)
+        return out.cpu().numpy().reshape(self.size, -1)
+
+    def exchange_rows(self, rows, send_counts, recv_counts):
+        """rows: [n, w] int32 device tensor sorted by destination rank; send_counts / recv_counts: rows per peer (host
+        ints).  Returns the rows the peers sent here, a device tensor [sum(recv_counts), w]."""
+        import torch
+        w = rows.shape[1]
+        src = rows.reshape(-1)
+        if self.cpu:
+            src = src.cpu()
+        out = torch.empty(int(sum(recv_counts)) * w, dtype=rows.dtype, device=src.device)
+        self.dist.all_to_all_single(out, src.contiguous(), output_split_sizes=[int(c) * w for c in recv_counts],
+                                    input_split_sizes=[int(c) * w for c in send_counts], group=self.group)
+        return out.to(rows.device).reshape(-1, w)
+
 
 class LocalComm:
     """the same between N logical ranks of ONE process, each running in its own thread (one-GPU rehearsals and
-    tests): gather() is a barrier-synchronised exchange through a shared list"""
+    tests): barrier-synchronised exchanges through shared slots; device tensors are handed over as they are"""
 
     class _Shared:
         def __init__(self, n):
@@ -1032,75 +1081,94 @@ class LocalComm:
         sh = LocalComm._Shared(n)
         return [LocalComm(sh, r) for r in range(n)]
 
-    def all_gather(self, value):
-        self.sh.slots[self.rank] = np.asarray(value).copy()
+    def _swap(self, mine):
+        self.sh.slots[self.rank] = mine
         self.sh.barrier.wait()
         out = list(self.sh.slots)
         self.sh.barrier.wait()  # everybody has read before the next exchange overwrites
         return out
 
+    def all_gather(self, value):
+        return self._swap(np.asarray(value).copy())
+
+    def all_gather_ints(self, vec):
+        return np.stack(self._swap(vec.cpu().numpy().astype(np.int64)))
+
+    def exchange_rows(self, rows, send_counts, recv_counts):
+        import torch
+        offs = np.concatenate([[0], np.cumsum(send_counts)]).astype(np.int64)
+        torch.cuda.current_stream().synchronize()  # the other threads' streams read these rows
+        self.sh.slots[self.rank] = [rows[int(offs[d]):int(offs[d + 1])] for d in range(self.size)]
+        self.sh.barrier.wait()
+        out = torch.cat([self.sh.slots[s][self.rank] for s in range(self.size)])
+        torch.cuda.current_stream().synchronize()  # copied before the senders may let go of their rows
+        self.sh.barrier.wait()
+        return out
+
 
 def finish_downslope(tile, comm, max_iters=200):
-    """Downslope walks that left a rank's memory (dt_dev_downslope_w marks such cells -50 and counts them: none on the
-    synthetic benchmark terrain, thousands along every border on real terrain, whose walks run for kilometres through
-    flats and along valley floors).  Every rank calls this after its step.  The marked cells are walked again as
-    WALKERS that travel from rank to rank -- global position, moves made, the path length as the reference
-    accumulates it (a sequential float64 sum, carried in the state, so the result is the reference's own arithmetic
-    whatever the route), the start cell's height.  A rank keeps, on the device, only the walkers that stand in its
-    core: each iteration it advances them (dt_dev_downslope_walkers_w) until they finish or reach the end of its
-    memory -- either way they leave its list --, the movers are all-gathered (`comm`: DistComm / LocalComm; rows of
-    8 float64, only the walkers that moved), a finished walker's value is written by the owner of its start cell and
-    a walker on its way joins the list of the rank that owns the cell it stands on.  Returns the number of cells
-    resolved (over all ranks); 0 without a single exchange when no rank had any."""
+    """Downslope walks that left a rank's memory (none on the synthetic benchmark terrain, thousands along every border
+    on real terrain, whose walks run for kilometres through flats and along valley floors; the reference's analogue is
+    the CPU repair downslope.py:373-374).  Every rank calls this after its step.  Such a walk travels on as a WALKER
+    record (include/descriptools_hip.h, dt_dev_downslope_emit_w): start cell, the cell it stands on, moves and diagonal
+    moves made, the start height -- emitted by the downslope kernel where the walk left the rank (RankTile(emit_walkers),
+    the default with long_walks), or seeded at the start cell from the -50 marks.  Each iteration a rank advances the
+    walkers standing in its memory (dt_dev_downslope_walk_w: across the rank in skips of 64 moves when it has the
+    long-walk tables), then the records go where they belong in ONE all-to-all of device buffers (comm.exchange_rows:
+    RCCL; DistComm on gloo and LocalComm rehearse it) -- a finished walker to the owner of its start cell, which writes
+    the value, the others to the owner of the cell they stand on -- preceded by one tiny all-gather of the counts, the
+    iteration's only synchronisation with the host.  The result is the reference's float32 whatever the route: counts
+    give it through the rounding-safety test of the count form, and the rare walk that fails the test starts again
+    carrying the reference's own sequential float64 sum.  Returns the number of cells resolved (over all ranks); 0
+    without any exchange of records when no rank had any."""
     tc, L, layout = tile.torch, tile.L, tile.layout
     n_local = tile.unresolved_downslope()
-    total = int(sum(int(np.asarray(v).reshape(-1)[0]) for v in comm.all_gather(np.asarray([n_local], np.int64))))
+    i32 = tc.int32
+    with tile.on_stream():
+        total = int(comm.all_gather_ints(tc.tensor([n_local], dtype=tc.int64, device=tile.dev)).sum())
     if total == 0:
         return 0
-    i32, f64 = tc.int32, tc.float64
     with tile.on_stream():
-        core = tile.core("down")
-        ys, xs = (core == -50.0).nonzero(as_tuple=True)
-        sgy, sgx = (ys + tile.gy0).to(i32), (xs + tile.gx0).to(i32)       # start cells (global)
-        gy, gx = sgy.clone(), sgx.clone()                                 # where each walker stands
-        moves, dist = tc.zeros(len(ys), dtype=i32, device=tile.dev), tc.zeros(len(ys), dtype=f64, device=tile.dev)
-        z0 = tile.core("dem")[ys, xs].float().contiguous()
-        ys_t, xs_t = tc.as_tensor(layout.ys, device=tile.dev).double(), tc.as_tensor(layout.xs, device=tile.dev).double()
+        rec = None
+        if tile._walkers is not None:
+            emitted = int(tile._walkers[:4].view(i32).item())
+            if emitted == n_local and n_local <= (tile._walkers.numel() - 256) // WALKER_BYTES:
+                rec = tile._walkers[256:256 + WALKER_BYTES * n_local].view(i32).reshape(n_local, WALKER_WORDS).clone()
+        if rec is None:  # no records (or more walks than the buffer holds): from the -50 marks, at the start cells
+            ys, xs = (tile.core("down") == -50.0).nonzero(as_tuple=True)
+            ys, xs = ys.to(i32).contiguous(), xs.to(i32).contiguous()
+            rec = tc.empty((int(ys.numel()), WALKER_WORDS), dtype=i32, device=tile.dev)
+            tile._chk(L.dt_dev_downslope_walk_seed_w(tile.ctx.h, C.byref(tile.win), tile.p("dem"), int(ys.numel()),
+                                                     ys.data_ptr(), xs.data_ptr(), rec.data_ptr()))
+        ys_t, xs_t = tc.as_tensor(layout.ys, device=tile.dev).to(i32), tc.as_tensor(layout.xs, device=tile.dev).to(i32)
 
     def owner(y, x):  # Layout.owner on the device
         return ((tc.bucketize(y.contiguous(), ys_t, right=True) - 1) * layout.tx +
                 (tc.bucketize(x.contiguous(), xs_t, right=True) - 1))
+    work = tile._lift_work
     for _ in range(max_iters):
-        n = int(gy.numel())
-        rows = np.zeros((0, 8), np.float64)
-        if n:
-            with tile.on_stream():
-                value = tc.zeros(n, dtype=tc.float32, device=tile.dev)
-                status = tc.zeros(n, dtype=i32, device=tile.dev)
-                tile._chk(L.dt_dev_downslope_walkers_w(tile.ctx.h, C.byref(tile.win), tile.p("dem"), tile.p("fdr"),
-                                                       tile.px, tile.dz, n, gy.data_ptr(), gx.data_ptr(),
-                                                       moves.data_ptr(), dist.data_ptr(), z0.data_ptr(),
-                                                       value.data_ptr(), status.data_ptr()))
-                fin = status != 0
-                # int32 / float32 values are exact in float64: one array for the exchange
-                rows_t = tc.stack([fin.to(f64), sgy.to(f64), sgx.to(f64), gy.to(f64), gx.to(f64), moves.to(f64), dist,
-                                   tc.where(fin, value, z0).to(f64)], dim=1)
-            tile.ctx.sync()
-            rows = rows_t.cpu().numpy()
-        got = [np.asarray(r, np.float64).reshape(-1, 8) for r in comm.all_gather(rows)]
-        rows = np.concatenate(got, axis=0) if got else rows
-        # sorted out on the device: the finished walkers whose start cell is mine, the others that stand in my core
         with tile.on_stream():
-            t = tc.as_tensor(rows, device=tile.dev)
-            fin = t[:, 0] != 0
-            home = t[fin & (owner(t[:, 1], t[:, 2]) == tile.rank)]
-            on = t[~fin & (owner(t[:, 3], t[:, 4]) == tile.rank)]
+            n = int(rec.shape[0])
+            if n:
+                rec = rec.contiguous()
+                tile._chk(L.dt_dev_downslope_walk_w(tile.ctx.h, C.byref(tile.win), tile.p("dem"), tile.p("fdr"), tile.px,
+                                                    tile.dz, n, rec.data_ptr(),
+                                                    work.data_ptr() if work is not None else None,
+                                                    work.numel() if work is not None else 0))
+            done = (rec[:, 7] & W_DONE) != 0
+            dest = tc.where(done, owner(rec[:, 0], rec[:, 1]), owner(rec[:, 2], rec[:, 3]))
+            order = tc.argsort(dest, stable=True)
+            rec = rec[order]
+            meta = tc.cat([tc.bincount(dest, minlength=comm.size)[:comm.size], (~done).sum().reshape(1)])
+            m = comm.all_gather_ints(meta)                      # [size, size + 1] on the host: the one synchronisation
+            active = int(m[:, comm.size].sum())                 # walkers still on their way, over all ranks
+            got = comm.exchange_rows(rec, m[comm.rank, :comm.size], m[:, comm.rank])
+            fin = (got[:, 7] & W_DONE) != 0
+            home = got[fin]                                     # finished, and their start cell is mine
             if home.shape[0]:
-                tile.core("down")[home[:, 1].long() - tile.gy0, home[:, 2].long() - tile.gx0] = home[:, 7].float()
-            sgy, sgx, gy, gx = (on[:, k].to(i32).contiguous() for k in (1, 2, 3, 4))
-            moves, dist, z0 = on[:, 5].to(i32).contiguous(), on[:, 6].contiguous(), on[:, 7].float().contiguous()
-            active = int((~fin).sum().item())                              # the same number on every rank
-        tile.ctx.sync()
+                tile.core("down")[home[:, 0].long() - tile.gy0, home[:, 1].long() - tile.gx0] = \
+                    home[:, 10].contiguous().view(tc.float32)
+            rec = got[~fin]
         if active == 0:
             break
     else:

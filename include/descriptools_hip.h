@@ -169,6 +169,27 @@ int dt_lnhlh(const float *hand, const int64_t *fac, int64_t N, double n_gfi, dou
 int dt_downslope(const float *dem, const uint8_t *fdr, int64_t H, int64_t W, double px,
                  double elevation_difference, int raw, float *out);
 
+/* ---- heights in float64: a DEM (or HAND) that float32 cannot hold --------------------------------------------
+ * The reference takes height differences in the raster's OWN dtype (slope.py:244-258 under Numba typing,
+ * flowhand.py:436-438 `dem - dem[indices]`, downslope.py:468) and adds 0.01 to the HAND it is given in float64
+ * (gfi.py:289-294, :429-440).  The float32 entry points above are that arithmetic exactly when every height is a
+ * float32 value; for the rest -- a genuinely float64 DEM, integer heights beyond 2^24 (exact in float64 up to 2^53)
+ * -- these take the heights as float64 and evaluate the literal expressions (one thread per cell on global memory:
+ * the capability, not the tuned path).  descriptools_amd/_lib.py picks the tier per raster. */
+/* slope.py:152-259 */
+int dt_slope_f64(const double *dem, int64_t H, int64_t W, double px, float *slope);
+/* flowhand.hand_calculator, flowhand.py:414-442 (flow distance / river index do not read heights: dt_flowhand with
+ * dem = hand = NULL) */
+int dt_hand_f64(const double *dem, const int64_t *idx, int64_t N, double *hand);
+/* downslope.py:379-532 + the repair :161-314; raw as in dt_downslope */
+int dt_downslope_f64(const double *dem, const uint8_t *fdr, int64_t H, int64_t W, double px,
+                     double elevation_difference, int raw, float *out);
+/* gfi.py:119-147 + :210-294 (own_area = 0: area of the river cell idx points at, no zero guard; idx required),
+ * gfi.py:349-440 (own_area = 1: the cell's own accumulation, 0 -> 1; idx ignored) and geomorphic_flood_index_cpu on
+ * an explicit per-cell area raster passed as `fac` (own_area = 2: no zero guard), on a float64 HAND */
+int dt_gfi_f64h(const double *hand, const int64_t *fac, const int64_t *idx, int64_t N, double n_gfi,
+                double scale_factor, double size, int own_area, float *out);
+
 /* evaluation.binary_map + avaliacao for `nth` thresholds in one pass (evaluation.py:90-171):
  * counts4[t*4 + v] = #cells with binary(desc, th[t]) + remapped(flood) == v, v = 0..3.
  * Cells equal to `nodata_value` (the caller passes desc[0,0], evaluation.py:111) or NaN
@@ -311,14 +332,25 @@ int64_t dt_downslope_lift_workspace_w(const dt_window *win);
 int dt_dev_downslope_lift_w(dt_ctx *ctx, const dt_window *win, const float *dem, const uint8_t *fdr, double px,
                             double elevation_difference, int raw, float *out, int32_t *n_unresolved_dev, void *work,
                             int64_t work_bytes);
-/* Walks that leave a rank's memory (dt_dev_downslope_w marks them -50 and counts them) travel on as WALKERS: global
- * position (gy, gx), moves made, the path length as the reference's sequential float64 sum, the start cell's height.
- * The walkers with status 0 that stand in this rank's memory are advanced until they finish (status 1: value = the
- * downslope of their start cell) or must be handed to a neighbour (status stays 0, state updated).  All arrays on the
- * device, n entries.  Driver: descriptools_amd/tiling.py, finish_downslope. */
-int dt_dev_downslope_walkers_w(dt_ctx *ctx, const dt_window *win, const float *dem, const uint8_t *fdr, double px,
-                               double dz, int64_t n, int32_t *gy, int32_t *gx, int32_t *moves, double *dist,
-                               const float *z0, float *value, int32_t *status);
+/* Downslope walks that leave a rank's memory (real terrain: walks of thousands of moves along valley floors cross rank
+ * borders).  dt_dev_downslope_emit_w = dt_dev_downslope_w (work NULL) / dt_dev_downslope_lift_w (work = the long-walk
+ * workspace) that additionally EMITS every such walk, where it leaves, as a 48-byte walker record into `walkers`
+ * (bytes 0-3: number of walks emitted, possibly more than fit; records from byte 256):
+ *   words 0-3  start cell (global row, column), cell the walk stands on (global row, column)
+ *   words 4-7  moves made, diagonal moves, float bits of the start height, flags (1 = carries the reference's
+ *              sequential float64 path length instead of counts, 2 = finished)
+ *   words 8-11 that float64 sum (two words), float bits of the result (finished walkers), 0
+ * dt_dev_downslope_walk_w advances, in place, the n records that stand in this rank's memory until they finish or
+ * reach the end of it again (the host sends them on: descriptools_amd/tiling.finish_downslope uses an all-to-all of
+ * device buffers; the reference's analogue is the CPU repair downslope.py:373-374).  dt_dev_downslope_walk_seed_w
+ * writes records of walkers at their start cells (core coordinates) for cells that are marked -50 without one. */
+int dt_dev_downslope_emit_w(dt_ctx *ctx, const dt_window *win, const float *dem, const uint8_t *fdr, double px,
+                            double elevation_difference, int raw, float *out, int32_t *n_unresolved_dev, void *work,
+                            int64_t work_bytes, void *walkers, int64_t walkers_bytes);
+int dt_dev_downslope_walk_w(dt_ctx *ctx, const dt_window *win, const float *dem, const uint8_t *fdr, double px,
+                            double elevation_difference, int64_t n, void *records, void *work, int64_t work_bytes);
+int dt_dev_downslope_walk_seed_w(dt_ctx *ctx, const dt_window *win, const float *dem, int64_t n, const int32_t *ys,
+                                 const int32_t *xs, void *records);
 /* phase 1: in-rank accumulation; per ring cell: A = cells of this rank draining OUT through it (0 unless
  * its D8 step leaves the core), code = that step's D8 code, xr = ring index of the rank exit reached by
  * a path ENTERING at this cell (-1 none, -2 cycle inside the rank).  acc32 is not touched by this phase (the raster
@@ -424,6 +456,12 @@ int dt_dev_membench_copy(dt_ctx *ctx, const float *a, float *b, int64_t N, int b
  * The fused slope + TI + MTI stencil is 2 reads + 3 writes (60 % of its bytes are written). */
 int dt_dev_membench_mix(dt_ctx *ctx, const float *r0, const float *r1, float *w0, float *w1, float *w2, int64_t N,
                         int n_reads, int n_writes, int nontemporal);
+/* `reps` launches of dt_dev_membench_mix bracketed by HIP events on the context's stream (after one untimed launch):
+ * *ms = mean duration of one launch.  Synchronises.  What descriptools_amd/placement.py labels blocks with. */
+int dt_dev_membench_mix_timed(dt_ctx *ctx, const float *r0, const float *r1, float *w0, float *w1, float *w2, int64_t N,
+                              int n_reads, int n_writes, int nontemporal, int reps, double *ms);
+/* free / total bytes of the context's device (hipMemGetInfo) */
+int dt_dev_mem_info(dt_ctx *ctx, int64_t *free_bytes, int64_t *total_bytes);
 
 /* Rank-level solves on the GPU (multi-GPU): `rows_dev` holds one all-gathered byte row per rank
  * (rowbytes apart); field k of rank r starts at rows_dev + r * rowbytes + field_offsets[k] and has Pmax

@@ -156,6 +156,52 @@ def downslope(dem, fdr, px, dz):
     return out
 
 
+def slope_f64(dem, px):
+    """slope (%) of a float64 DEM, differences in float64 (slope.py:244-258 on such a raster)"""
+    dem = np.ascontiguousarray(dem, np.float64)
+    H, W = dem.shape
+    sl = np.empty((H, W), np.float32)
+    lib().dt_oracle_slope_f64(_p(dem, C.c_double), C.c_int64(H), C.c_int64(W), C.c_double(px), _p(sl, C.c_float))
+    return sl
+
+
+def hand_f64(dem, idx):
+    dem = np.ascontiguousarray(dem, np.float64)
+    idx = np.ascontiguousarray(idx, np.int64)
+    hand = np.empty(dem.shape, np.float64)
+    lib().dt_oracle_hand_f64(_p(dem, C.c_double), _p(idx, C.c_int64), C.c_int64(dem.size), _p(hand, C.c_double))
+    return hand
+
+
+def downslope_f64(dem, fdr, px, dz):
+    dem = np.ascontiguousarray(dem, np.float64)
+    fdr = np.ascontiguousarray(fdr, np.uint8)
+    H, W = dem.shape
+    out = np.empty((H, W), np.float32)
+    lib().dt_oracle_downslope_f64(_p(dem, C.c_double), _p(fdr, C.c_uint8), C.c_int64(H), C.c_int64(W),
+                                  C.c_double(px), C.c_double(dz), _p(out, C.c_float))
+    return out
+
+
+def gfi_f64h(hand, fac, idx, n, b, size):
+    hand = np.ascontiguousarray(hand, np.float64)
+    fac = np.ascontiguousarray(fac, np.int64)
+    idx = np.ascontiguousarray(idx, np.int64)
+    out = np.empty(hand.shape, np.float32)
+    lib().dt_oracle_gfi_f64h(_p(hand, C.c_double), _p(fac, C.c_int64), _p(idx, C.c_int64), C.c_int64(hand.size),
+                             C.c_double(n), C.c_double(b), C.c_double(size), _p(out, C.c_float))
+    return out
+
+
+def lnhlh_f64h(hand, fac, n, b, size):
+    hand = np.ascontiguousarray(hand, np.float64)
+    fac = np.ascontiguousarray(fac, np.int64)
+    out = np.empty(hand.shape, np.float32)
+    lib().dt_oracle_lnhlh_f64h(_p(hand, C.c_double), _p(fac, C.c_int64), C.c_int64(hand.size), C.c_double(n),
+                               C.c_double(b), C.c_double(size), _p(out, C.c_float))
+    return out
+
+
 def confusion_multi(desc, flood, th, under=True):
     desc = np.ascontiguousarray(desc, np.float64)
     flood = np.ascontiguousarray(flood, np.int8)

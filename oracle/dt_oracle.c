@@ -595,6 +595,115 @@ int dt_oracle_downslope(const float *dem, const uint8_t *fdr, int64_t H, int64_t
 }
 
 /* ------------------------------------------------------------------------------------
+ * The same descriptors on a DEM that float32 cannot hold (a genuinely float64 raster, or integer heights
+ * beyond 2^24 converted exactly to float64).  The reference takes every height difference in the raster's
+ * OWN dtype -- slope.py:244-258 under Numba typing (float64 - float64), flowhand.py:436-438
+ * `dem - dem[indices]`, downslope.py:468 -- and hands a float64 HAND to gfi.py:289-294 / :429-440, whose
+ * `hand + 0.01` is then a float64 sum of a float64 value.  Pinned by tests/golden/f64.npz, the reference's own
+ * run on such a raster (oracle/gen_golden.py f64).  D8 and flow accumulation take no part: they are inputs.
+ * ---------------------------------------------------------------------------------- */
+int dt_oracle_slope_f64(const double *dem, int64_t H, int64_t W, double px, float *slope) {
+  const double dcard = px, ddiag = px * sqrt(2.0);
+  DT_OMP_FOR
+  for (int64_t y = 0; y < H; y++)
+    for (int64_t x = 0; x < W; x++) {
+      int64_t i = y * W + x;
+      double c = dem[i];
+      if (c <= -100.0) { /* slope.py:231 */
+        slope[i] = DT_NODATA;
+        continue;
+      }
+      double aux = 0.0;
+      for (int k = 0; k < 8; k++) {
+        int64_t yy = y + DT_DY[k], xx = x + DT_DX[k];
+        if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue; /* -100 ring */
+        double nb = dem[yy * W + xx];
+        if (nb == -100.0) continue; /* slope.py:247 */
+        volatile double diff = c - nb;
+        double v = diff / ((DT_DY[k] == 0 || DT_DX[k] == 0) ? dcard : ddiag);
+        if (aux < v) aux = v;
+      }
+      slope[i] = (float)(aux * 100.0);
+    }
+  return 0;
+}
+
+int dt_oracle_hand_f64(const double *dem, const int64_t *idx, int64_t N, double *hand) {
+  DT_OMP_FOR
+  for (int64_t i = 0; i < N; i++) {
+    double h = -100.0;
+    if (dem[i] != -100.0 && idx[i] != -100) {
+      volatile double d = dem[i] - dem[idx[i]]; /* flowhand.py:436 */
+      h = d;
+      if (h < 0.0 && h != -100.0) h = 0.0; /* :438 */
+    }
+    hand[i] = h;
+  }
+  return 0;
+}
+
+int dt_oracle_downslope_f64(const double *dem, const uint8_t *fdr, int64_t H, int64_t W, double px, double dz,
+                            float *out) {
+  const int64_t N = H * W;
+  const double dcard = px, ddiag = px * sqrt(2.0);
+  DT_OMP_FOR
+  for (int64_t i = 0; i < N; i++) {
+    double z0 = dem[i];
+    if (z0 <= -100.0) {
+      out[i] = DT_NODATA;
+      continue;
+    }
+    int64_t pos = i;
+    double dist = 0.0;
+    int loop = 0;
+    for (;;) {
+      volatile double drop = z0 - dem[pos]; /* downslope.py:468, the DEM's own dtype */
+      if (!(drop < dz)) break;
+      int diag = 0;
+      int64_t t = dt_step(pos, fdr[pos], H, W, &diag);
+      if (t == -2) break;
+      if (t >= 0) {
+        if (dem[t] == -100.0) break;
+        pos = t;
+        dist += diag ? ddiag : dcard;
+      }
+      if (++loop == 5000) break;
+    }
+    volatile double drop = z0 - dem[pos];
+    out[i] = dist == 0.0 ? 0.0f : (float)(drop / dist);
+  }
+  return 0;
+}
+
+int dt_oracle_gfi_f64h(const double *hand, const int64_t *fac, const int64_t *idx, int64_t N, double n, double b,
+                       double size, float *gfi) {
+  DT_OMP_FOR
+  for (int64_t i = 0; i < N; i++) {
+    if (hand[i] <= -100.0) {
+      gfi[i] = DT_NODATA;
+      continue;
+    }
+    int64_t ar = idx[i] != -100 ? fac[idx[i]] : fac[0];
+    gfi[i] = (float)log(b * pow((double)ar * (size * size), n) / (hand[i] + 0.01));
+  }
+  return 0;
+}
+
+int dt_oracle_lnhlh_f64h(const double *hand, const int64_t *fac, int64_t N, double n, double b, double size,
+                         float *out) {
+  DT_OMP_FOR
+  for (int64_t i = 0; i < N; i++) {
+    if (hand[i] <= -100.0) {
+      out[i] = DT_NODATA;
+      continue;
+    }
+    double a = fac[i] == 0 ? 1.0 * (size * size) : (double)fac[i] * (size * size);
+    out[i] = (float)log((b * pow(a, n)) / (hand[i] + 0.01));
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------
  * E2+E3 confusion counts for many thresholds in one pass -- evaluation.py:90-123 and
  * :126-171.  desc is float64 (minMaxScale output, :5-9); cells equal to desc[0] or NaN
  * classify 0 (:111-121); 'under' -> desc <= th else desc >= th; benchmark map remap

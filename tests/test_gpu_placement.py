@@ -86,10 +86,16 @@ def test_search_with_spacers_when_the_first_blocks_are_all_alike(monkeypatch):
     ctx.sync()
     want = {k: ref.buf[k].to_host() for k, _ in chain.OUTPUTS}
     ref.free()
-    # (a) the chain's own allocator
+    # the library's default works with the blocks at hand: nothing else is allocated
     ch = chain.Chain(n, n, ctx=ctx)
+    assert ch.placement["tuned"] and ch.placement["candidates_tried"] == 0 and ch.placement["spacer_GiB"] == 0
+    assert ch.placement["mode"] == "own blocks" and ch.placement["setup_s"] >= 0
+    ch.free()
+    # (a) the chain's own allocator, search opted in
+    ch = chain.Chain(n, n, ctx=ctx, tune_placement="search")
     info = ch.placement
-    assert info["tuned"] and info["n_classes"] == 3 and info["spacer_GiB"] >= 4
+    assert info["tuned"] and info["n_classes"] == 3 and info["spacer_GiB"] >= 4 and info["mode"] == "search"
+    assert info["spacer_GiB"] <= info["spacer_budget_GiB"]
     assert len({info["classes"][r] for r in ("slope", "ti", "mti")}) >= 2
     ch.run(dem.ptr)
     ctx.sync()
@@ -107,7 +113,7 @@ def test_search_with_spacers_when_the_first_blocks_are_all_alike(monkeypatch):
 
     def release(q):
         del held[q]
-    ch = chain.Chain(n, n, ctx=ctx, alloc=alloc, release=release)
+    ch = chain.Chain(n, n, ctx=ctx, alloc=alloc, release=release, tune_placement="search")
     assert ch.placement["spacer_GiB"] >= 4 and len(held) == len(chain.OUTPUTS)
     ch.run(dem.ptr)
     ctx.sync()
@@ -115,9 +121,58 @@ def test_search_with_spacers_when_the_first_blocks_are_all_alike(monkeypatch):
     held.clear()
     # (c) a rank tile
     layout = tiling.Layout([n], [n])
-    tl = tiling.RankTile(layout, 0, device=0)
+    tl = tiling.RankTile(layout, 0, device=0, tune_placement="search")
     assert tl.placement["tuned"] and tl.placement["spacer_GiB"] >= 4
     tl.free()
     dem.free()
     ctx.close()
     torch.cuda.empty_cache()
+
+
+def test_a_full_device_during_the_search_is_not_a_fault_and_leaves_no_stale_error(monkeypatch):
+    """the search uses "the device is full" as control flow.  A candidate / spacer allocation that fails with
+    out-of-memory must end the search quietly (MemoryError from the C ABI's DT_ENOMEM, torch's OutOfMemoryError), must
+    not leave a sticky HIP error behind for the next entry point -- and any OTHER error must propagate."""
+    from descriptools_amd import _lib, chain, placement
+    from descriptools_amd.device import Context
+    monkeypatch.setattr(placement, "WriteClassifier", _RunOfOneClass)
+    n = 2048
+    ctx = Context()
+    L = _lib.lib()
+    dem = ctx.empty((n, n), np.float32)
+    _lib.check(L.dt_dev_synth_dem(ctx.h, 3, n, n, 0, 0, n, n, 1, dem.ptr))
+    # a real out-of-memory from the C ABI: MemoryError, and the next kernel launch does not see its ghost
+    with pytest.raises(MemoryError):
+        ctx.empty((1 << 50,), np.uint8)
+    ch = chain.Chain(n, n, ctx=ctx, tune_placement=False)
+    ch.run(dem.ptr)
+    ctx.sync()
+    want = {k: ch.buf[k].to_host() for k, _ in chain.OUTPUTS}
+    ch.free()
+    # spacers that cannot be had: the search carries on back to back and then works with what it found
+    real_empty = Context.empty
+
+    def stingy(self, shape, dtype):
+        if int(np.prod(shape)) * np.dtype(dtype).itemsize >= (1 << 30):
+            return real_empty(self, (1 << 50,), np.uint8)  # -> DT_ENOMEM -> MemoryError
+        return real_empty(self, shape, dtype)
+    monkeypatch.setattr(Context, "empty", stingy)
+    ch = chain.Chain(n, n, ctx=ctx, tune_placement="search")
+    assert ch.placement["tuned"] and ch.placement["spacer_GiB"] == 0 and ch.placement["candidates_tried"] >= 1
+    ch.run(dem.ptr)
+    ctx.sync()
+    for k, _ in chain.OUTPUTS:
+        assert np.array_equal(ch.buf[k].to_host(), want[k], equal_nan=True), k
+    ch.free()
+    # a fault that is not out-of-memory is not swallowed
+
+    def broken(self, shape, dtype):
+        if int(np.prod(shape)) * np.dtype(dtype).itemsize >= (1 << 30):
+            raise RuntimeError("descriptools_hip error -2: injected fault")
+        return real_empty(self, shape, dtype)
+    monkeypatch.setattr(Context, "empty", broken)
+    with pytest.raises(RuntimeError, match="injected fault"):
+        chain.Chain(n, n, ctx=ctx, tune_placement="search")
+    monkeypatch.setattr(Context, "empty", real_empty)
+    dem.free()
+    ctx.close()
