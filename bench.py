@@ -136,6 +136,8 @@ def main():
                     "blocks the chain allocates anyway), off")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end_to_end block (host-tier API, PCIe included)")
     ap.add_argument("--e2e-size", type=int, default=16384, help="edge of the host DEM of the end_to_end block")
+    ap.add_argument("--real-rep", type=int, default=8, help="end_to_end.real_terrain: the bundled Example tiled REP x REP "
+                    "(8: 214 M cells)")
     ap.add_argument("--graph", action="store_true", help="N = 1: the headline loop replays the step as one HIP graph "
                     "launch (chain.Chain.capture) instead of ~45 kernel launches")
     ap.add_argument("--no-overlap", action="store_true", help="headline loop on ONE stream, kernels back to back "
@@ -324,7 +326,7 @@ def main():
     ch.free()
     torch.cuda.empty_cache()
     if not args.no_e2e:
-        out["end_to_end"] = end_to_end(args.e2e_size, args.seed)
+        out["end_to_end"] = end_to_end(args.e2e_size, args.seed, args.real_rep)
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_n)
     print(json.dumps(out), flush=True)
@@ -582,7 +584,7 @@ def verify_tiled(torch, tile, layout, allreduce):
             "checksums": {n: int(v) for n, v in zip(names, tot[2:])}}
 
 
-def end_to_end(n, seed):
+def end_to_end(n, seed, real_rep=8):
     """What a user of the reference's API sees (SURVEY.md 8d "end-to-end incl. H2D/D2H, reported separately"; never
     `value`): (a) chain.run_host on an n x n HOST DEM -- one H2D of the DEM, the resident chain, 13 rasters back over
     PCIe into page-locked memory -- with the split; (b) the reference's call sequence (Example/example.py:59-91) through
@@ -656,7 +658,12 @@ def end_to_end(n, seed):
     except Exception as e:  # the example's rasters are test fixtures: report, do not fail the bench
         ex = {"error": repr(e)}
     cells = n * n
+    try:
+        real = real_terrain(real_rep, 4096 if real_rep >= 8 else 1024)
+    except Exception as e:  # fixtures / memory: report, do not fail the bench
+        real = {"error": repr(e)}
     return {
+        "real_terrain": real,
         "size": "%dx%d host DEM" % (n, n),
         "run_host_split": {"h2d_dem_pageable_ms": round((t1 - t0) * 1e3, 1), "kernels_ms": round((t2 - t1) * 1e3, 1),
                            "d2h_11_rasters_pinned_ms": round((t3 - t2) * 1e3, 1), "d2h_GBs": round(nbytes_out / (t3 - t2) / 1e9, 1),
@@ -673,6 +680,104 @@ def end_to_end(n, seed):
                                "numpy lines between them (astype / arctan / where, example.py:63)"},
         "example": ex,
     }
+
+
+def real_terrain(rep=8, rough_n=4096):
+    """The reference's only workload is real terrain with a GIS D8 raster (Example/example.py:33-39); the headline's
+    synthetic DEM has no flats.  (a) the bundled Example tiled rep x rep (214 M cells at rep = 8) with its GIS D8 codes
+    through the resident chain (Chain(external_fdr=True, long_walks="auto")): per-op ms on one stream, the number of
+    long downslope walks queued, the step with the long walks finished.  (b) a rough synthetic rough_n^2 DEM (noise,
+    pits, integer plateaus, nodata) through the CONDITIONED chain (depression filling + flat routing + D8, then
+    everything else; Chain(condition=True, long_walks=True)) beside its unconditioned chain."""
+    import torch
+    import descriptools_amd.rasterio_lite as rio
+    from descriptools_amd import _lib, chain
+    from descriptools_amd.device import Context
+    L = _lib.lib()
+    ex = os.path.join(ROOT, "tests", "golden", "example")
+    dem0, _ = rio.read_masked(os.path.join(ex, "12_dem.tif"), -100, "int16")
+    fdr0 = np.ascontiguousarray(rio.read(os.path.join(ex, "12_fdr.tif"))[0], np.uint8)
+    dem = np.tile(dem0.astype(np.float32), (rep, rep))
+    fdr = np.tile(fdr0, (rep, rep))
+    H, W = dem.shape
+    N, px = H * W, 12.5
+    st = torch.cuda.Stream()
+    ctx = Context(0, st.cuda_stream)
+    out = {}
+    with torch.cuda.stream(st):
+        d = ctx.to_device(dem)
+        ch = chain.Chain(H, W, ctx=ctx, px=px, river_threshold=N // 512, want_slope_rad=False, overlap=False,
+                         tune_placement=False, long_walks="auto", external_fdr=True)
+        ch.buf["fdr"].copy_from(fdr)
+        ops = ch.ops(d.ptr, want_a_river=False, serial=True)
+
+        def step():
+            for _, _, fn in ops:
+                _lib.check(fn())
+            return ch.finish_long_walks()
+        step()
+        ctx.sync()
+        reps = 3
+        ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(len(ops) + 1)]
+              for _ in range(reps)]
+        t0 = time.perf_counter()
+        queued = 0
+        for k in range(reps):
+            for i, (_, _, fn) in enumerate(ops):
+                ev[k][i][0].record(st)
+                _lib.check(fn())
+                ev[k][i][1].record(st)
+            ev[k][-1][0].record(st)
+            queued = ch.finish_long_walks()   # a synchronisation point: looks at the queue, builds the skip tables
+            ev[k][-1][1].record(st)
+        ctx.sync()
+        dt = (time.perf_counter() - t0) / reps
+        names = [n for n, _, _ in ops] + ["downslope_long_walks_finish"]
+        per_op = {n: round(float(np.mean([ev[k][i][0].elapsed_time(ev[k][i][1]) for k in range(reps)])), 3)
+                  for i, n in enumerate(names)}
+        valid = int((dem != -100).sum())
+        out["example_tiled"] = {
+            "raster": "%dx%d = bundled Example x %d x %d, GIS D8 codes (Example/input/12_fdr.tif)" % (H, W, rep, rep),
+            "cells": N, "valid_cells": valid, "ms_per_step": round(dt * 1e3, 3), "Mcells_s": round(N / dt / 1e6, 1),
+            "per_op_ms": per_op, "downslope_walks_queued": int(queued),
+            "note": "resident chain without a D8 op (codes given), one stream; downslope queues its long walks "
+                    "(valley floors, flats: thousands of moves) and finish_long_walks() crosses them with skip tables"}
+        ch.free()
+        d.free()
+        del dem, fdr
+        # (b) the conditioned chain on rough terrain
+        g = ctx.empty((rough_n, rough_n), np.float32)
+        _lib.check(L.dt_dev_synth_dem(ctx.h, 3, rough_n, rough_n, 0, 0, rough_n, rough_n, 2, g.ptr))
+        base = g.to_host()
+        rng = np.random.default_rng(3)
+        nod = base == -100
+        rough = np.floor(base + rng.normal(0, 6.0, base.shape).astype(np.float32)).astype(np.float32)
+        rough[rng.random(rough.shape) < 0.02] -= 40
+        rough[nod] = -100
+        g.copy_from(rough)
+        times = {}
+        for cond in (False, True):
+            c2 = chain.Chain(rough_n, rough_n, ctx=ctx, px=10.0, condition=cond, condition_rounds=96, tune_placement=False,
+                             long_walks=cond, overlap=False)
+            for _ in range(2):
+                c2.run(g.ptr)
+            ctx.sync()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                c2.run(g.ptr)
+            ctx.sync()
+            times[cond] = (time.perf_counter() - t0) / 5
+            c2.check_status()
+            c2.free()
+        out["rough_conditioned"] = {
+            "raster": "%dx%d synthetic DEM + noise, pits, integer plateaus, 2 %% nodata" % (rough_n, rough_n),
+            "chain_ms": round(times[False] * 1e3, 3), "conditioned_chain_ms": round(times[True] * 1e3, 3),
+            "note": "conditioned = depression filling + flat routing + D8 on the filled surface (dt_dev_condition_d8_async), "
+                    "then the flow kernels, descriptors and downslope with the long-walk workspace"}
+        g.free()
+    ctx.close()
+    torch.cuda.empty_cache()
+    return out
 
 
 def cpu_baseline(n=3584, seeds=(1,)):

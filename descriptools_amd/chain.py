@@ -46,7 +46,10 @@ class Chain:
 
     def __init__(self, H, W, ctx=None, px=10.0, n_top=0.1, n_gfi=0.4, b=0.1, dz=5.0,
                  river_threshold=None, alloc=None, want_slope_rad=True, side_ctx=None, overlap=True,
-                 condition=False, condition_rounds=64, tune_placement=True, release=None, long_walks=False):
+                 condition=False, condition_rounds=64, tune_placement=True, release=None, long_walks=False,
+                 external_fdr=False):
+        # external_fdr: the D8 codes are GIVEN (a GIS tool's raster, as the reference's example reads one:
+        # Example/example.py:36) -- the step has no D8 op; the caller writes the codes into buf["fdr"] (p("fdr")) first.
         # tune_placement: True (default) -- hand the blocks this chain allocates anyway to their roles by measured
         # write-conflict class (placement.py; ~100 probe launches, nothing else allocated); "search" -- also look for
         # blocks of other classes when those are all alike (bounded, transient allocations of tens of GiB: a set-up
@@ -66,6 +69,8 @@ class Chain:
         # the raster has enough of them; run_host does this.  False: the plain kernel (the synthetic benchmark terrain
         # has no long walks).
         assert long_walks in (False, True, "auto")
+        assert not (external_fdr and condition), "conditioning computes the codes itself"
+        self.external_fdr = bool(external_fdr)
         self.long_walks = long_walks
         self._lift = self._lift_q = self._lift_dem = None
         self.condition, self.condition_rounds = bool(condition), int(condition_rounds)
@@ -206,8 +211,7 @@ class Chain:
         if self.condition:
             first = ("condition_d8", c, lambda: L.dt_dev_condition_d8_async(c.h, dem_ptr, H, W, self.px, p("filled"),
                                                                              p("fdr"), self.condition_rounds))
-        return [
-            first,
+        return ([] if self.external_fdr else [first]) + [
             ("downslope", side, (lambda: L.dt_dev_downslope_lift(side.h, dem_ptr, p("fdr"), H, W, self.px, self.dz, 0,
                                                                   p("down"), self._lift_ptr(), self._lift_bytes))
              if self.long_walks is True else

@@ -24,6 +24,13 @@
 
 #define HT 64
 #define HLD (HT + 2)
+// LDS row strides.  Two of a tile's four sweeps walk COLUMNS with a lane per row: with the window's natural stride of
+// 66 words (= 2 mod 32 banks) the 64 lanes of such a wave fall on 16 banks, four deep, and with the 64-word stride of
+// the tile's own heights on ONE bank, sixty-four deep -- round 3's relaxation rounds spent most of their time in
+// those two reads (rough 16384^2: 3.9-4.4 ms for a round that visits every tile).  Odd strides put the lanes of a
+// column sweep on all 32 banks; the row sweeps (a lane per column) do not care.
+#define HLS (HLD + 1) /* 67 */
+#define HZS (HT + 1)  /* 65 */
 #define H_CPT (HT * HT / 256)
 #define H_INF_DIST 0x7FFFFFFFu
 
@@ -84,7 +91,7 @@ __device__ __forceinline__ void hy_stage(T *s, const T *__restrict__ src, const 
 #pragma unroll
   for (int k = 0; k < N; k++) {
     const int i = threadIdx.x + 256 * k;
-    if (i < HLD * HLD) s[i] = v[k];
+    if (i < HLD * HLD) s[(i / HLD) * HLS + (i - (i / HLD) * HLD)] = v[k];
   }
 }
 
@@ -114,8 +121,8 @@ __global__ __launch_bounds__(256) void k_fill_relax(const float *__restrict__ de
                                                    const uint8_t *__restrict__ act_prev,
                                                    uint8_t *__restrict__ act_cur, int tiles_y) {
   const int H = w.H, W = w.W;
-  __shared__ float s_w[HLD * HLD];
-  __shared__ float s_z[HT * HT];  // the tile's own heights (nodata beyond the raster)
+  __shared__ float s_w[HLD * HLS];
+  __shared__ float s_z[HT * HZS];  // the tile's own heights (nodata beyond the raster)
   if (prev && __hip_atomic_load(prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
   const int y0 = ty * HT, x0 = tx * HT;
@@ -127,8 +134,8 @@ __global__ __launch_bounds__(256) void k_fill_relax(const float *__restrict__ de
   // and already hold their final value)
   hy_stage<float>(s_w, wsurf, w, y0, x0, __builtin_inff());
   __syncthreads();
-  for (int i = threadIdx.x; i < HLD * HLD; i += 256)
-    if (hy_nodata(s_w[i])) s_w[i] = __builtin_inff();
+  for (int i = threadIdx.x; i < HLD * HLS; i += 256)
+    if (hy_nodata(s_w[i])) s_w[i] = __builtin_inff();  // (the pad column holds garbage nobody reads)
   float z[H_CPT];
 #pragma unroll
   for (int j = 0; j < H_CPT; j++) {
@@ -138,7 +145,10 @@ __global__ __launch_bounds__(256) void k_fill_relax(const float *__restrict__ de
     z[j] = (y < H && x < W) ? dem[(long long)y * w.ld + x] : DT_NODATA;
   }
 #pragma unroll
-  for (int j = 0; j < H_CPT; j++) s_z[threadIdx.x + 256 * j] = z[j];
+  for (int j = 0; j < H_CPT; j++) {
+    const int c = threadIdx.x + 256 * j;
+    s_z[(c / HT) * HZS + (c % HT)] = z[j];
+  }
   __syncthreads();
   // DIRECTIONAL in-place sweeps (round 3; Jacobi sweeps to the tile's local fixed point before: one cell of progress
   // per sweep and barrier, ~100 of them for a front crossing the tile).  Each of the four waves walks the whole tile
@@ -160,12 +170,12 @@ __global__ __launch_bounds__(256) void k_fill_relax(const float *__restrict__ de
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const bool by_rows = !(wave & 2);                 // waves 0 / 1 walk rows (a lane per column), 2 / 3 columns
   const int dir = (wave & 1) ? -1 : 1;
-  const int SA = by_rows ? dir * HLD : dir;         // one step along the sweep
-  const int SC = by_rows ? 1 : HLD;                 // one lane across it
-  const int ZA = by_rows ? dir * HT : dir;
+  const int SA = by_rows ? dir * HLS : dir;         // one step along the sweep
+  const int SC = by_rows ? 1 : HLS;                 // one lane across it
+  const int ZA = by_rows ? dir * HZS : dir;
   const int k0 = (wave & 1) ? HT - 1 : 0;
-  int p = by_rows ? (k0 + 1) * HLD + lane + 1 : (lane + 1) * HLD + k0 + 1;
-  int zi = by_rows ? k0 * HT + lane : lane * HT + k0;
+  int p = by_rows ? (k0 + 1) * HLS + lane + 1 : (lane + 1) * HLS + k0 + 1;
+  int zi = by_rows ? k0 * HZS + lane : lane * HZS + k0;
   float up = s_w[p - SA];                              // the line before the tile (halo: nobody writes it)
   float hl = s_w[p - SA - SC], hr = s_w[p - SA + SC];  // its cells beside lanes 0 / 63
   float cur = s_w[p], lf = s_w[p - SC], rt = s_w[p + SC];
@@ -201,7 +211,7 @@ __global__ __launch_bounds__(256) void k_fill_relax(const float *__restrict__ de
   for (int j = 0; j < H_CPT; j++) {
     int c = threadIdx.x + 256 * j;
     int y = y0 + c / HT, x = x0 + c % HT;
-    if (y < H && x < W && !hy_nodata(z[j])) wsurf[(long long)y * w.ld + x] = s_w[(c / HT + 1) * HLD + (c % HT) + 1];
+    if (y < H && x < W && !hy_nodata(z[j])) wsurf[(long long)y * w.ld + x] = s_w[(c / HT + 1) * HLS + (c % HT) + 1];
   }
   if (threadIdx.x == 0) atomicOr(changed, 1);
 }
@@ -218,28 +228,51 @@ __device__ __forceinline__ void hy_scan_delta(int k, int &dy, int &dx) {
 }
 
 // flats: dist = 0 for cells that have a code (and for nodata, which nobody asks), "infinite" for valid cells
-// without one; a code-less cell next to nodata drains into its first nodata neighbour right away
+// without one; a code-less cell next to nodata drains into its first nodata neighbour right away.  One workgroup per
+// 64 x 64 tile with the surface staged in LDS (round 4; one thread per cell on global memory before: 2.4 ms at
+// 16384^2, up to 9 scattered loads per code-less cell); has_flat[tile] (may be NULL) = the tile has cells that need a
+// distance: the relaxation rounds and the assignment never look at the others.
 __global__ __launch_bounds__(256) void k_flat_init(const float *__restrict__ wsurf, uint8_t *__restrict__ fdr, DtWin w,
-                                                  uint32_t *__restrict__ dist) {
-  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (int64_t)w.H * w.W) return;
-  int y = (int)(i / w.W), x = (int)(i - (int64_t)y * w.W);
-  const long long o = (long long)y * w.ld + x;
-  uint32_t d = 0u;
-  if (!hy_nodata(wsurf[o]) && fdr[o] == 0) {
-    d = H_INF_DIST;
-    for (int k = 0; k < 8; k++) {
-      int dy, dx;
-      hy_scan_delta(k, dy, dx);
-      if (!dt_in_global(w, y + dy, x + dx)) continue;  // raster-edge cells got their outward code from the stencil
-      if (hy_nodata(wsurf[(long long)(y + dy) * w.ld + x + dx])) {
-        fdr[o] = hy_code_of_scan(k);
+                                                  uint32_t *__restrict__ dist, int tiles_x,
+                                                  uint8_t *__restrict__ has_flat) {
+  __shared__ float s_w[HLD * HLS];
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int y0 = ty * HT, x0 = tx * HT;
+  hy_stage<float>(s_w, wsurf, w, y0, x0, __builtin_inff());  // beyond the raster: not nodata (those cells got their
+  __syncthreads();                                           // outward code from the stencil), never equal to anything
+  int any = 0;
+#pragma unroll
+  for (int j = 0; j < H_CPT; j++) {
+    const int c = threadIdx.x + 256 * j;
+    const int ly = c / HT, lx = c % HT;
+    const int y = y0 + ly, x = x0 + lx;
+    if (y >= w.H || x >= w.W) continue;
+    const long long o = (long long)y * w.ld + x;
+    const int p = (ly + 1) * HLS + lx + 1;
+    uint32_t d = 0u;
+    if (!hy_nodata(s_w[p]) && fdr[o] == 0) {
+      d = H_INF_DIST;
+      // scan order NW N NE W E SW S SE
+      uint32_t code = 0u;
+      if (hy_nodata(s_w[p - HLS - 1])) code = 32u;
+      else if (hy_nodata(s_w[p - HLS])) code = 64u;
+      else if (hy_nodata(s_w[p - HLS + 1])) code = 128u;
+      else if (hy_nodata(s_w[p - 1])) code = 16u;
+      else if (hy_nodata(s_w[p + 1])) code = 1u;
+      else if (hy_nodata(s_w[p + HLS - 1])) code = 8u;
+      else if (hy_nodata(s_w[p + HLS])) code = 4u;
+      else if (hy_nodata(s_w[p + HLS + 1])) code = 2u;
+      if (code) {
+        fdr[o] = (uint8_t)code;
         d = 0u;
-        break;
+      } else {
+        any = 1;
       }
     }
+    dist[o] = d;
   }
-  dist[o] = d;
+  any = __syncthreads_or(any);
+  if (has_flat && threadIdx.x == 0) has_flat[blockIdx.x] = (uint8_t)any;
 }
 
 // one round of the flat distances: d(c) = 1 + min d(n) over neighbours of the same filled height
@@ -249,8 +282,8 @@ __global__ __launch_bounds__(256) void k_flat_relax(const float *__restrict__ ws
                                                    const uint8_t *__restrict__ act_prev,
                                                    uint8_t *__restrict__ act_cur, int tiles_y) {
   const int H = w.H, W = w.W;
-  __shared__ float s_w[HLD * HLD];
-  __shared__ uint32_t s_d[HLD * HLD];
+  __shared__ float s_w[HLD * HLS];
+  __shared__ uint32_t s_d[HLD * HLS];
   if (prev && __hip_atomic_load(prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
   const int y0 = ty * HT, x0 = tx * HT;
@@ -273,11 +306,11 @@ __global__ __launch_bounds__(256) void k_flat_relax(const float *__restrict__ ws
     for (int step = 0; step < HT; step++) {
       const int k = (wave & 1) ? HT - 1 - step : step;
       const int ly = (wave & 2) ? lane : k, lx = (wave & 2) ? k : lane;
-      const int p = (ly + 1) * HLD + lx + 1;
+      const int p = (ly + 1) * HLS + lx + 1;
       const uint32_t cur = s_d[p];
       const float wc = s_w[p];
       uint32_t m = H_INF_DIST;
-      HY_N(-HLD - 1) HY_N(-HLD) HY_N(-HLD + 1) HY_N(-1) HY_N(1) HY_N(HLD - 1) HY_N(HLD) HY_N(HLD + 1)
+      HY_N(-HLS - 1) HY_N(-HLS) HY_N(-HLS + 1) HY_N(-1) HY_N(1) HY_N(HLS - 1) HY_N(HLS) HY_N(HLS + 1)
       // coded cells (0) and cells next to one (1) are final; positions beyond the raster edge are staged as nodata
       if (cur > 1u && !hy_nodata(wc) && m != H_INF_DIST && m + 1u < cur) {
         s_d[p] = m + 1u;
@@ -293,37 +326,51 @@ __global__ __launch_bounds__(256) void k_flat_relax(const float *__restrict__ ws
   for (int j = 0; j < H_CPT; j++) {
     int c = threadIdx.x + 256 * j;
     int y = y0 + c / HT, x = x0 + c % HT;
-    if (y < H && x < W) dist[(long long)y * w.ld + x] = s_d[(c / HT + 1) * HLD + (c % HT) + 1];
+    if (y < H && x < W) dist[(long long)y * w.ld + x] = s_d[(c / HT + 1) * HLS + (c % HT) + 1];
   }
   if (threadIdx.x == 0) atomicOr(changed, 1);
 }
 
-// flat cells point at the first neighbour (scan order) of the same filled height that is one hop closer
+// flat cells point at a neighbour of the same filled height that is one hop closer: the first of N, W, E, S, else the
+// first of NW, NE, SW, SE.  One workgroup per tile that has flat cells, surface and distances staged in LDS (round 4;
+// one thread per cell with up to 16 scattered loads before: 5.3 ms at 16384^2).
 __global__ __launch_bounds__(256) void k_flat_assign(const float *__restrict__ wsurf, const uint32_t *__restrict__ dist,
                                                     DtWin w, uint8_t *__restrict__ fdr,
-                                                    int *__restrict__ unresolved) {
-  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (int64_t)w.H * w.W) return;
-  int y = (int)(i / w.W), x = (int)(i - (int64_t)y * w.W);
-  const long long o = (long long)y * w.ld + x;
-  uint32_t d = dist[o];
-  if (d == 0u) return;
-  float wc = wsurf[o];
-  uint8_t code = 0;
-  if (d != H_INF_DIST) {
-    // cardinal neighbours first (N, W, E, S), then the diagonals (NW, NE, SW, SE)
-    const int pref[8] = {1, 3, 4, 6, 0, 2, 5, 7};
-    for (int q = 0; q < 8 && !code; q++) {
-      const int k = pref[q];
-      int dy, dx;
-      hy_scan_delta(k, dy, dx);
-      if (!dt_in_global(w, y + dy, x + dx)) continue;
-      long long n = (long long)(y + dy) * w.ld + x + dx;
-      if (wsurf[n] == wc && dist[n] == d - 1u) code = hy_code_of_scan(k);
+                                                    int *__restrict__ unresolved, int tiles_x,
+                                                    const uint8_t *__restrict__ has_flat) {
+  __shared__ float s_w[HLD * HLS];
+  __shared__ uint32_t s_d[HLD * HLS];
+  if (has_flat && has_flat[blockIdx.x] == 0) return;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int y0 = ty * HT, x0 = tx * HT;
+  hy_stage<float>(s_w, wsurf, w, y0, x0, DT_NODATA);       // beyond the raster: equal to no valid height
+  hy_stage<uint32_t>(s_d, dist, w, y0, x0, H_INF_DIST);
+  __syncthreads();
+  int bad = 0;
+#pragma unroll
+  for (int j = 0; j < H_CPT; j++) {
+    const int c = threadIdx.x + 256 * j;
+    const int ly = c / HT, lx = c % HT;
+    const int y = y0 + ly, x = x0 + lx;
+    if (y >= w.H || x >= w.W) continue;
+    const int p = (ly + 1) * HLS + lx + 1;
+    const uint32_t d = s_d[p];
+    if (d == 0u) continue;
+    uint32_t code = 0u;
+    if (d != H_INF_DIST) {
+      const float wc = s_w[p];
+      const uint32_t want = d - 1u;
+#define HY_A(off, c_)                                                  \
+  if (!code && s_w[p + (off)] == wc && s_d[p + (off)] == want) code = (c_);
+      HY_A(-HLS, 64u) HY_A(-1, 16u) HY_A(1, 1u) HY_A(HLS, 4u)
+      HY_A(-HLS - 1, 32u) HY_A(-HLS + 1, 128u) HY_A(HLS - 1, 8u) HY_A(HLS + 1, 2u)
+#undef HY_A
     }
+    if (!code) bad++;
+    fdr[(long long)y * w.ld + x] = (uint8_t)code;
   }
-  if (!code) atomicAdd(unresolved, 1);
-  fdr[o] = code;
+  for (int o = 32; o; o >>= 1) bad += __shfl_xor(bad, o);
+  if ((threadIdx.x & 63) == 0 && bad) atomicAdd(unresolved, bad);
 }
 
 // scratch: flag words + the distance raster
@@ -332,9 +379,9 @@ __global__ __launch_bounds__(256) void k_flat_assign(const float *__restrict__ w
 #define DT_HYDRO_FLAG_BYTES 4096
 #define DT_HYDRO_MAX_ASYNC_ROUNDS 500
 static size_t hy_tiles(int64_t H, int64_t W) { return (size_t)((W + HT - 1) / HT) * (size_t)((H + HT - 1) / HT); }
-// flags | distance raster | two per-tile activity arrays (the rounds alternate between them)
+// flags | distance raster | two per-tile activity arrays (the rounds alternate between them) | has_flat per tile
 size_t dt_hydro_scratch(int64_t H, int64_t W) {
-  return DT_HYDRO_FLAG_BYTES + dt_align256((size_t)H * W * 4) + 2 * dt_align256(hy_tiles(H, W));
+  return DT_HYDRO_FLAG_BYTES + dt_align256((size_t)H * W * 4) + 3 * dt_align256(hy_tiles(H, W));
 }
 
 // raise the context's status when the budget of rounds did not reach the fixed point, or a flat cell got no code
@@ -399,19 +446,21 @@ int dt_launch_condition(hipStream_t s, const float *dem, int64_t H, int64_t W, d
   uint8_t *act[2];
   act[0] = (uint8_t *)scratch + DT_HYDRO_FLAG_BYTES + dt_align256((size_t)n * 4);
   act[1] = act[0] + dt_align256(hy_tiles(H, W));
+  uint8_t *has_flat = act[1] + dt_align256(hy_tiles(H, W));
   DT_TRY(hy_iterate(s, flag, max_rounds, [&](int *f, const int *prev, int64_t r) {
     hipLaunchKernelGGL(k_fill_relax, gt, b, 0, s, dem, filled, w, tiles_x, f, prev,
                        r ? (const uint8_t *)act[(r - 1) & 1] : (const uint8_t *)nullptr, act[r & 1], tiles_y);
   }, &r1));
   if (fdr) {
     DT_TRY(dt_launch_stencil(s, w, filled, px, nullptr, fdr, nullptr, nullptr, 0, 0.0, nullptr, nullptr));
-    hipLaunchKernelGGL(k_flat_init, gc, b, 0, s, filled, fdr, w, dist);
+    hipLaunchKernelGGL(k_flat_init, gt, b, 0, s, filled, fdr, w, dist, tiles_x, has_flat);
+    // the first round visits the tiles that have flat cells (and their neighbours), not every tile
     DT_TRY(hy_iterate(s, flag, max_rounds, [&](int *f, const int *prev, int64_t r) {
       hipLaunchKernelGGL(k_flat_relax, gt, b, 0, s, filled, dist, w, tiles_x, f, prev,
-                         r ? (const uint8_t *)act[(r - 1) & 1] : (const uint8_t *)nullptr, act[r & 1], tiles_y);
+                         r ? (const uint8_t *)act[(r - 1) & 1] : (const uint8_t *)has_flat, act[r & 1], tiles_y);
     }, &r2));
     DT_HIP(hipMemsetAsync(flag + 64, 0, sizeof(int), s));
-    hipLaunchKernelGGL(k_flat_assign, gc, b, 0, s, filled, dist, w, fdr, flag + 64);
+    hipLaunchKernelGGL(k_flat_assign, gt, b, 0, s, filled, dist, w, fdr, flag + 64, tiles_x, (const uint8_t *)has_flat);
     int u = 0;
     DT_HIP(hipMemcpyAsync(&u, flag + 64, sizeof(int), hipMemcpyDeviceToHost, s));
     DT_HIP(hipStreamSynchronize(s));
@@ -446,18 +495,20 @@ int dt_launch_condition_async(hipStream_t s, const float *dem, int64_t H, int64_
   uint8_t *act[2];
   act[0] = (uint8_t *)scratch + DT_HYDRO_FLAG_BYTES + dt_align256((size_t)n * 4);
   act[1] = act[0] + dt_align256(hy_tiles(H, W));
+  uint8_t *has_flat = act[1] + dt_align256(hy_tiles(H, W));
   for (int r = 0; r < rounds; r++)
     hipLaunchKernelGGL(k_fill_relax, gt, b, 0, s, dem, filled, w, tiles_x, flags + r,
                        r ? (const int *)(flags + r - 1) : (const int *)nullptr,
                        r ? (const uint8_t *)act[(r - 1) & 1] : (const uint8_t *)nullptr, act[r & 1], tiles_y);
   DT_TRY(dt_launch_stencil(s, w, filled, px, nullptr, fdr, nullptr, nullptr, 0, 0.0, nullptr, nullptr));
-  hipLaunchKernelGGL(k_flat_init, gc, b, 0, s, filled, fdr, w, dist);
+  hipLaunchKernelGGL(k_flat_init, gt, b, 0, s, filled, fdr, w, dist, tiles_x, has_flat);
   int *fl2 = flags + rounds;
   for (int r = 0; r < rounds; r++)
     hipLaunchKernelGGL(k_flat_relax, gt, b, 0, s, filled, dist, w, tiles_x, fl2 + r,
                        r ? (const int *)(fl2 + r - 1) : (const int *)nullptr,
-                       r ? (const uint8_t *)act[(r - 1) & 1] : (const uint8_t *)nullptr, act[r & 1], tiles_y);
-  hipLaunchKernelGGL(k_flat_assign, gc, b, 0, s, filled, dist, w, fdr, flags + 2 * rounds);
+                       r ? (const uint8_t *)act[(r - 1) & 1] : (const uint8_t *)has_flat, act[r & 1], tiles_y);
+  hipLaunchKernelGGL(k_flat_assign, gt, b, 0, s, filled, dist, w, fdr, flags + 2 * rounds, tiles_x,
+                     (const uint8_t *)has_flat);
   hipLaunchKernelGGL(k_hydro_verdict, dim3(1), dim3(1), 0, s, (const int *)(flags + rounds - 1),
                      (const int *)(fl2 + rounds - 1), (const int *)(flags + 2 * rounds), status);
   return DT_OK;
@@ -488,7 +539,7 @@ int dt_launch_condition_stage(hipStream_t s, const DtWin &w, int stage, int roun
       break;
     case 2:
       DT_REQUIRE(filled && fdr && dist, "NULL pointer");
-      hipLaunchKernelGGL(k_flat_init, gc, b, 0, s, filled, fdr, w, dist);
+      hipLaunchKernelGGL(k_flat_init, gt, b, 0, s, filled, fdr, w, dist, tiles_x, (uint8_t *)nullptr);
       break;
     case 3:
       DT_REQUIRE(filled && dist && flag_dev, "NULL pointer");
@@ -498,7 +549,7 @@ int dt_launch_condition_stage(hipStream_t s, const DtWin &w, int stage, int roun
       break;
     case 4:
       DT_REQUIRE(filled && dist && fdr && flag_dev, "NULL pointer");
-      hipLaunchKernelGGL(k_flat_assign, gc, b, 0, s, filled, dist, w, fdr, flag_dev);
+      hipLaunchKernelGGL(k_flat_assign, gt, b, 0, s, filled, dist, w, fdr, flag_dev, tiles_x, (const uint8_t *)nullptr);
       break;
     default:
       DT_REQUIRE(false, "stage must be 0..4");

@@ -11,6 +11,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def rough_dem(Hg, Wg, seed):
+    """synthetic terrain with noise, pits and integer plateaus (depressions and flats across the rank borders): what
+    the conditioning is for; the same array in the ranks and in the parent test"""
+    import oracle  # test infrastructure: the generator on the host
+    base = oracle.synth_dem(seed, Hg, Wg, 0, 0, Hg, Wg, 2)
+    rng = np.random.default_rng(seed)
+    nod = base == -100
+    dem = np.floor(base + rng.normal(0, 4.0, base.shape).astype(np.float32)).astype(np.float32)
+    dem[rng.random(dem.shape) < 0.02] -= 30
+    dem[nod] = -100
+    return dem
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", required=True)
@@ -22,7 +35,10 @@ def main():
     ap.add_argument("--halo", default="synth", choices=["synth", "exchange"])
     ap.add_argument("--overlap", type=int, default=0)
     ap.add_argument("--force-world", type=int, default=0)
-    ap.add_argument("--terrain", default="synth", choices=["synth", "plane"])
+    ap.add_argument("--terrain", default="synth", choices=["synth", "plane", "rough"])
+    ap.add_argument("--condition", type=int, default=0, help="tiling.condition_rank (depression filling + flat routing "
+                    "over the ranks: point-to-point halo exchanges, an all-reduce of the flag per iteration), then "
+                    "run_rank(d8=False) on the conditioned codes")
     ap.add_argument("--logical", type=int, default=0, help="this ONE process plays that many logical ranks: their DEM "
                     "halos are exchanged with isend / irecv pairs to itself over the process group (RCCL: the "
                     "point-to-point path of the 8-GPU run on a 1-GPU box), then the ranks step in lock-step")
@@ -41,13 +57,22 @@ def main():
     layout = tiling.Layout.uniform(world, a.h, a.w)
     thr = (layout.Hg * layout.Wg) // 512
     # (the plane terrain runs downslope with the long-walk workspace: the queue and the tables in real processes)
-    tile = tiling.RankTile(layout, rank, device=0, px=10.0, river_threshold=thr, long_walks=(a.terrain == "plane"))
+    tile = tiling.RankTile(layout, rank, device=0, px=10.0, river_threshold=thr,
+                           long_walks=(a.terrain == "plane" or bool(a.condition)))
     if a.terrain == "plane":
         # a 1 per mille plane: every downslope walk is thousands of moves long and crosses the rank borders
         h = tiling.HALO
         y0, x0 = layout.origin(rank)
         yy, xx = np.mgrid[y0 - h:y0 + tile.H + h, x0 - h:x0 + tile.W + h]
         tile.set_dem_ext((200.0 - 0.001 * xx - 0.0002 * yy).astype(np.float32))
+    elif a.terrain == "rough":
+        h = tiling.HALO
+        y0, x0 = layout.origin(rank)
+        full = rough_dem(layout.Hg, layout.Wg, a.seed)
+        ext = torch.full((tile.He, tile.We), float("nan"))  # NaN = never received, must never be read
+        ext[h:h + tile.H, h:h + tile.W] = torch.as_tensor(full[y0:y0 + tile.H, x0:x0 + tile.W])
+        tiling.exchange_halo(ext, layout, rank)
+        tile.set_dem_ext(torch.nan_to_num(ext, nan=-100.0).numpy())  # outside the raster: nodata
     elif a.halo == "synth":
         tile.synth_dem(a.seed, a.nodata)
     else:
@@ -60,12 +85,15 @@ def main():
         tiling.exchange_halo(ext, layout, rank)  # gloo: CPU tensors (RCCL: the same call on device tensors)
         tile.set_dem_ext(ext.numpy())
     exchange = tiling.Exchange(tile, layout, max(world, a.force_world))
+    if a.condition:
+        left, it_fill, it_flat = tiling.condition_rank(tile, layout)
+        assert left == 0 and it_fill >= 1 and it_flat >= 1
     for _ in range(2):  # twice: the step reuses its buffers
-        tiling.run_rank(tile, layout, exchange, overlap=bool(a.overlap))
+        tiling.run_rank(tile, layout, exchange, overlap=bool(a.overlap), d8=not a.condition)
     tile.check_status()
     # walks that left this rank's memory travel on as walkers (none on the synthetic terrain: returns 0 at once)
     sent = tiling.finish_downslope(tile, tiling.DistComm())
-    assert (sent > 0) == (a.terrain == "plane")
+    assert (sent > 0) == (a.terrain == "plane") or a.condition
     assert tile.unresolved_downslope() == 0
     names = ["dem", "fdr", "fac", "river", "fdist", "idx", "hand", "slope", "ti", "mti", "gfi", "lnhlh", "down"]
     np.savez(os.path.join(a.out, "rank%d.npz" % rank), origin=np.array(layout.origin(rank)),

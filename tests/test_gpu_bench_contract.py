@@ -38,7 +38,7 @@ def _check_common(d, cells_per_gpu):
 
 
 def test_bench_line_contract():
-    d = _run("--cpu-n", "512", "--e2e-size", "1024")
+    d = _run("--cpu-n", "512", "--e2e-size", "1024", "--real-rep", "2")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "end_to_end"):
         assert k in d, k
@@ -47,6 +47,14 @@ def test_bench_line_contract():
     e = d["end_to_end"]
     assert e["run_host"]["Mcells_s"] > 0 and e["dropin_api"]["Mcells_s"] > 0 and e["run_host_split"]["kernels_ms"] > 0
     assert e["example"]["class_map_mismatches"] == 0 and e["example"]["threshold"] == 0.012
+    rt = e["real_terrain"]  # real terrain (GIS D8 codes, long walks) and the conditioned chain
+    assert "error" not in rt, rt
+    assert rt["example_tiled"]["cells"] == 4 * 2178 * 1534 and rt["example_tiled"]["downslope_walks_queued"] > 0
+    assert set(rt["example_tiled"]["per_op_ms"]) == {"downslope", "flowacc_flowhand_local", "slope_twi",
+                                                      "flowhand_gfi_finish", "downslope_long_walks_finish"}
+    assert rt["rough_conditioned"]["conditioned_chain_ms"] > rt["rough_conditioned"]["chain_ms"] > 0
+    p = d["config"]["placement"]
+    assert p["tuned"] is False or (p["setup_s"] >= 0 and p["spacer_GiB"] <= p["spacer_budget_GiB"])
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["unit"] == "Mcells/s" and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]

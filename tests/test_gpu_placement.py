@@ -50,7 +50,7 @@ def test_tuned_chain_gives_identical_rasters():
 class _RunOfOneClass:
     """stands in for placement.WriteClassifier: the first `run` distinct blocks it sees are class 0 (a long run of one
     class in allocation order, as on some boxes: profiles/r3/placement_classes.txt), later ones alternate 1 / 2"""
-    run = 30
+    run = 14   # the chain's twelve blocks and the first two candidates
 
     def __init__(self, ctx, nbytes):
         self.seen, self.reps, self.single_ms = {}, [], 0.1
@@ -94,7 +94,7 @@ def test_search_with_spacers_when_the_first_blocks_are_all_alike(monkeypatch):
     # (a) the chain's own allocator, search opted in
     ch = chain.Chain(n, n, ctx=ctx, tune_placement="search")
     info = ch.placement
-    assert info["tuned"] and info["n_classes"] == 3 and info["spacer_GiB"] >= 4 and info["mode"] == "search"
+    assert info["tuned"] and info["n_classes"] == 3 and info["spacer_GiB"] >= 16 and info["mode"] == "search"
     assert info["spacer_GiB"] <= info["spacer_budget_GiB"]
     assert len({info["classes"][r] for r in ("slope", "ti", "mti")}) >= 2
     ch.run(dem.ptr)
@@ -114,7 +114,7 @@ def test_search_with_spacers_when_the_first_blocks_are_all_alike(monkeypatch):
     def release(q):
         del held[q]
     ch = chain.Chain(n, n, ctx=ctx, alloc=alloc, release=release, tune_placement="search")
-    assert ch.placement["spacer_GiB"] >= 4 and len(held) == len(chain.OUTPUTS)
+    assert ch.placement["spacer_GiB"] >= 16 and len(held) == len(chain.OUTPUTS)
     ch.run(dem.ptr)
     ctx.sync()
     ch.free()
@@ -122,7 +122,7 @@ def test_search_with_spacers_when_the_first_blocks_are_all_alike(monkeypatch):
     # (c) a rank tile
     layout = tiling.Layout([n], [n])
     tl = tiling.RankTile(layout, 0, device=0, tune_placement="search")
-    assert tl.placement["tuned"] and tl.placement["spacer_GiB"] >= 4
+    assert tl.placement["tuned"] and tl.placement["spacer_GiB"] >= 16
     tl.free()
     dem.free()
     ctx.close()
@@ -159,6 +159,7 @@ def test_a_full_device_during_the_search_is_not_a_fault_and_leaves_no_stale_erro
     monkeypatch.setattr(Context, "empty", stingy)
     ch = chain.Chain(n, n, ctx=ctx, tune_placement="search")
     assert ch.placement["tuned"] and ch.placement["spacer_GiB"] == 0 and ch.placement["candidates_tried"] >= 1
+    assert ch.placement["n_classes"] == 3  # (back to back the candidates leave the stand-in's run after two)
     ch.run(dem.ptr)
     ctx.sync()
     for k, _ in chain.OUTPUTS:

@@ -38,11 +38,11 @@ def _launch(tmp_path, world, h, w, nparts=None, **kw):
     return [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(nparts or world)]
 
 
-def _check(parts, Hg, Wg, seed, nodata, dem=None):
+def _check(parts, Hg, Wg, seed, nodata, dem=None, **chain_kw):
     from descriptools_amd import chain
     if dem is None:
         dem = oracle.synth_dem(seed, Hg, Wg, 0, 0, Hg, Wg, nodata)
-    ref = chain.run_host(dem, 10.0, river_threshold=(Hg * Wg) // 512)
+    ref = chain.run_host(dem, 10.0, river_threshold=(Hg * Wg) // 512, **chain_kw)
     for r, p in enumerate(parts):
         y0, x0 = (int(v) for v in p["origin"])
         H, W = p["fdr"].shape
@@ -77,6 +77,20 @@ def test_long_walks_travel_between_real_processes(tmp_path):
     layout = tiling.Layout.uniform(2, 256, 384)
     yy, xx = np.mgrid[0:layout.Hg, 0:layout.Wg]
     _check(parts, layout.Hg, layout.Wg, 1, 0, dem=(200.0 - 0.001 * xx - 0.0002 * yy).astype(np.float32))
+
+
+def test_conditioning_over_real_processes_then_the_rank_step_on_its_codes(tmp_path):
+    """tiling.condition_rank over torch.distributed (halo exchanges of the filled surface / the flat
+    distances / the codes between two processes, an all-reduce of the flag per iteration), then run_rank(d8=False) -- the
+    step starts from the conditioned codes instead of overwriting them -- and the walkers; every raster equals the
+    single raster's conditioned chain"""
+    parts = _launch(tmp_path, 2, 320, 256, seed=6, terrain="rough", condition=1)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _rank_child import rough_dem
+    from descriptools_amd import tiling
+    layout = tiling.Layout.uniform(2, 320, 256)
+    dem = rough_dem(layout.Hg, layout.Wg, 6)
+    _check(parts, layout.Hg, layout.Wg, 6, 0, dem=dem, condition=True, condition_rounds=256, long_walks=True)
 
 
 def test_run_rank_rccl_single_rank(tmp_path):
