@@ -95,19 +95,29 @@ __device__ __forceinline__ void hy_stage(T *s, const T *__restrict__ src, const 
   }
 }
 
-// Which tiles a round has to visit.  A tile at its local fixed point stays there until a cell of its one-cell halo
-// changes, i.e. until one of its eight neighbours (or itself) wrote something: `act_prev` holds one byte per tile,
-// non-zero when the tile CHANGED in the previous round; a tile none of whose 3 x 3 neighbourhood did is skipped (it
-// still records "unchanged" in `act_cur`).  act_prev == NULL: the first round of a phase, every tile is visited.
-// After the first two or three rounds only the tiles around large depressions / flats are left, so a round costs
-// what those tiles cost, not a sweep over the raster (16384^2 rough terrain: 149 -> ~40 ms for the conditioning).
+// Which tiles a round has to visit.  A visit makes up to `sweeps` rounds of four directional sweeps over its tile and
+// leaves one byte per tile: HY_CHANGED -- its cells changed, the eight tiles around it have a new halo to look at --
+// and HY_OPEN -- its last round of sweeps still moved something, so it must be visited again whatever its neighbours
+// do.  A round visits the tiles that have a changed NEIGHBOUR or are open themselves; a tile at its local fixed point
+// rests until its halo changes.  (With one round of sweeps per visit -- the measured optimum, HY_FILL_SWEEPS -- a
+// tile that changed is open: round 3's rule.)  act_prev == NULL: the first round of a phase, every tile is visited.
+#define HY_CHANGED 1
+#define HY_OPEN 2
+// rounds of sweeps per visit at most (dt_debug_set(6 / 7, n) overrides: tools/condition_bench.py N sweeps).  Measured,
+// round 4 (profiles/r4/conditioning_sweeps.txt): ONE is best for both relaxations on rough 8192^2 terrain and on the
+// Example (6.8 / 1.08 ms against 8.2 / 1.28 with up to six flat sweeps, 7.4 / 1.14 with two fill sweeps) -- what bounds
+// the number of global rounds is how many tiles a depression or a flat spans, not how far a tile is from its local
+// fixed point, so sweeping a tile to that point only repeats work the next visit does anyway.
+#define HY_FILL_SWEEPS 1
+#define HY_FLAT_SWEEPS 1
 __device__ __forceinline__ bool hy_tile_active(const uint8_t *__restrict__ act_prev, int ty, int tx, int tiles_x,
                                                int tiles_y) {
   if (!act_prev) return true;
   int v = 0;
   if (threadIdx.x < 9) {
     const int y = ty + (int)threadIdx.x / 3 - 1, x = tx + (int)threadIdx.x % 3 - 1;
-    if (y >= 0 && y < tiles_y && x >= 0 && x < tiles_x) v = act_prev[(size_t)y * tiles_x + x];
+    if (y >= 0 && y < tiles_y && x >= 0 && x < tiles_x)
+      v = act_prev[(size_t)y * tiles_x + x] & (threadIdx.x == 4 ? HY_OPEN : HY_CHANGED);
   }
   return __syncthreads_or(v) != 0;
 }
@@ -115,15 +125,22 @@ __device__ __forceinline__ bool hy_tile_active(const uint8_t *__restrict__ act_p
 // one round of the fill: one round of four directional sweeps on every tile that has to be visited
 // `prev` (may be NULL): the previous round's flag -- a round that follows a quiet one has nothing to do and
 // returns at once (the asynchronous form enqueues a fixed budget of rounds and never asks the host)
+// INIT: the first round of a single raster's fill starts from the heights themselves -- W = z on the outlets (edge of
+// the raster / next to nodata), +inf elsewhere, the other tiles' cells taken as +inf (an upper bound, like every
+// intermediate value of this relaxation) -- and writes every cell: no separate initialisation pass over the raster.
+template <bool INIT>
 __global__ __launch_bounds__(256) void k_fill_relax(const float *__restrict__ dem, float *__restrict__ wsurf, DtWin w,
                                                    int tiles_x, int *__restrict__ changed,
                                                    const int *__restrict__ prev,
                                                    const uint8_t *__restrict__ act_prev,
-                                                   uint8_t *__restrict__ act_cur, int tiles_y) {
+                                                   uint8_t *__restrict__ act_cur, int tiles_y, int sweeps) {
   const int H = w.H, W = w.W;
   __shared__ float s_w[HLD * HLS];
   __shared__ float s_z[HT * HZS];  // the tile's own heights (nodata beyond the raster)
-  if (prev && __hip_atomic_load(prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+  // (the previous round's flag was written by the previous KERNEL: a plain, scalar load sees it.  Round 3 read it with
+  // a device-scope atomic load in every thread -- 260 K wave-level requests on one address at 16384^2, served one
+  // after the other by the memory system: the rounds that had a `prev` took 3.9-4.4 ms, the ones without 1.5)
+  if (prev && *prev == 0) return;
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
   const int y0 = ty * HT, x0 = tx * HT;
   if (!hy_tile_active(act_prev, ty, tx, tiles_x, tiles_y)) {
@@ -132,17 +149,47 @@ __global__ __launch_bounds__(256) void k_fill_relax(const float *__restrict__ de
   }
   // outside the raster and nodata both read as +inf: they never lower a minimum (cells next to them are outlets
   // and already hold their final value)
-  hy_stage<float>(s_w, wsurf, w, y0, x0, __builtin_inff());
-  __syncthreads();
-  for (int i = threadIdx.x; i < HLD * HLS; i += 256)
-    if (hy_nodata(s_w[i])) s_w[i] = __builtin_inff();  // (the pad column holds garbage nobody reads)
   float z[H_CPT];
+  if (INIT) {
+    // the HEIGHTS of the window: a cell is an outlet when it lies on the raster's edge or has a nodata neighbour
+    // (cells beyond the raster are staged as +inf: not nodata)
+    hy_stage<float>(s_w, dem, w, y0, x0, __builtin_inff());
+    __syncthreads();
+    float w0[H_CPT];
 #pragma unroll
-  for (int j = 0; j < H_CPT; j++) {
-    int c = threadIdx.x + 256 * j;
-    int ly = c / HT, lx = c % HT;
-    int y = y0 + ly, x = x0 + lx;
-    z[j] = (y < H && x < W) ? dem[(long long)y * w.ld + x] : DT_NODATA;
+    for (int j = 0; j < H_CPT; j++) {
+      const int c = threadIdx.x + 256 * j;
+      const int ly = c / HT, lx = c % HT;
+      const int y = y0 + ly, x = x0 + lx;
+      const int p = (ly + 1) * HLS + lx + 1;
+      z[j] = (y < H && x < W) ? s_w[p] : DT_NODATA;
+      const int gy = w.gy0 + y, gx = w.gx0 + x;
+      bool outlet = gy == 0 || gx == 0 || gy == w.Hg - 1 || gx == w.Wg - 1;
+      outlet = outlet || hy_nodata(s_w[p - HLS - 1]) || hy_nodata(s_w[p - HLS]) || hy_nodata(s_w[p - HLS + 1]) ||
+               hy_nodata(s_w[p - 1]) || hy_nodata(s_w[p + 1]) || hy_nodata(s_w[p + HLS - 1]) ||
+               hy_nodata(s_w[p + HLS]) || hy_nodata(s_w[p + HLS + 1]);
+      w0[j] = (!hy_nodata(z[j]) && outlet) ? z[j] : __builtin_inff();
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < HLD * HLS; i += 256) s_w[i] = __builtin_inff();  // the other tiles' cells: unknown yet
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < H_CPT; j++) {
+      const int c = threadIdx.x + 256 * j;
+      s_w[(c / HT + 1) * HLS + (c % HT) + 1] = w0[j];
+    }
+  } else {
+    hy_stage<float>(s_w, wsurf, w, y0, x0, __builtin_inff());
+    __syncthreads();
+    for (int i = threadIdx.x; i < HLD * HLS; i += 256)
+      if (hy_nodata(s_w[i])) s_w[i] = __builtin_inff();  // (the pad column holds garbage nobody reads)
+#pragma unroll
+    for (int j = 0; j < H_CPT; j++) {
+      int c = threadIdx.x + 256 * j;
+      int ly = c / HT, lx = c % HT;
+      int y = y0 + ly, x = x0 + lx;
+      z[j] = (y < H && x < W) ? dem[(long long)y * w.ld + x] : DT_NODATA;
+    }
   }
 #pragma unroll
   for (int j = 0; j < H_CPT; j++) {
@@ -158,10 +205,8 @@ __global__ __launch_bounds__(256) void k_fill_relax(const float *__restrict__ de
   // few sweeps along a winding one.  The four sweeps run concurrently on the same LDS image; the operator is
   // monotone (values only decrease, towards the same greatest fixed point), so any interleaving and any stale read are
   // harmless, and a round of four sweeps that lowers nothing proves the fixed point.
-  // ONE such round of four sweeps per visit: a tile that changed is visited again in the next global round anyway
-  // (it is in its own 3 x 3 neighbourhood), so iterating it to its local fixed point here only re-proves, with one
-  // more round of sweeps, what the next visit proves as well (Example: 3.7 -> 2.1 ms, rough 8192^2: 25 -> 18 ms, a few
-  // more global rounds, the same surface).
+  // (Round 3 made ONE such round of four sweeps per visit, because a tile that had changed was visited again in the
+  // next global round anyway; with the HY_CHANGED / HY_OPEN rule a visit iterates to the tile's local fixed point.)
   // A step's dependent chain is short: the line the sweep comes from is in REGISTERS (a lane's own previous result,
   // its two neighbours' through DPP; the halo cells beside the edge lanes from LDS), the line it stands on and the
   // line ahead were fetched a step earlier (the line ahead of this step IS the next step's line), and the one fresh
@@ -174,13 +219,15 @@ __global__ __launch_bounds__(256) void k_fill_relax(const float *__restrict__ de
   const int SC = by_rows ? 1 : HLS;                 // one lane across it
   const int ZA = by_rows ? dir * HZS : dir;
   const int k0 = (wave & 1) ? HT - 1 : 0;
-  int p = by_rows ? (k0 + 1) * HLS + lane + 1 : (lane + 1) * HLS + k0 + 1;
-  int zi = by_rows ? k0 * HZS + lane : lane * HZS + k0;
-  float up = s_w[p - SA];                              // the line before the tile (halo: nobody writes it)
-  float hl = s_w[p - SA - SC], hr = s_w[p - SA + SC];  // its cells beside lanes 0 / 63
-  float cur = s_w[p], lf = s_w[p - SC], rt = s_w[p + SC];
-  int any = 0;
-  {
+  const int p0 = by_rows ? (k0 + 1) * HLS + lane + 1 : (lane + 1) * HLS + k0 + 1;
+  const int zi0 = by_rows ? k0 * HZS + lane : lane * HZS + k0;
+  int any = 0, open = 0;
+  // rounds of four sweeps until one of them lowers nothing (round 4; one round per visit before)
+  for (int it = 0; it < sweeps; it++) {
+    int p = p0, zi = zi0;
+    float up = s_w[p - SA];                              // the line before the tile (halo: nobody writes it)
+    float hl = s_w[p - SA - SC], hr = s_w[p - SA + SC];  // its cells beside lanes 0 / 63
+    float cur = s_w[p], lf = s_w[p - SC], rt = s_w[p + SC];
     int ch = 0;
     for (int step = 0; step < HT; step++) {
       const float fresh = s_w[p];
@@ -203,15 +250,21 @@ __global__ __launch_bounds__(256) void k_fill_relax(const float *__restrict__ de
       p += SA;
       zi += ZA;
     }
-    any = __syncthreads_or(ch);
+    open = __syncthreads_or(ch);
+    if (!open) break;
+    any = 1;
   }
-  if (act_cur && threadIdx.x == 0) act_cur[blockIdx.x] = (uint8_t)any;
+  if (INIT) any = 1;  // every cell is written, and the neighbours have yet to see this tile
+  if (act_cur && threadIdx.x == 0) act_cur[blockIdx.x] = (uint8_t)((any ? HY_CHANGED : 0) | (open ? HY_OPEN : 0));
   if (!any) return;
 #pragma unroll
   for (int j = 0; j < H_CPT; j++) {
     int c = threadIdx.x + 256 * j;
     int y = y0 + c / HT, x = x0 + c % HT;
-    if (y < H && x < W && !hy_nodata(z[j])) wsurf[(long long)y * w.ld + x] = s_w[(c / HT + 1) * HLS + (c % HT) + 1];
+    if (y < H && x < W) {
+      if (!hy_nodata(z[j])) wsurf[(long long)y * w.ld + x] = s_w[(c / HT + 1) * HLS + (c % HT) + 1];
+      else if (INIT) wsurf[(long long)y * w.ld + x] = DT_NODATA;
+    }
   }
   if (threadIdx.x == 0) atomicOr(changed, 1);
 }
@@ -238,6 +291,13 @@ __global__ __launch_bounds__(256) void k_flat_init(const float *__restrict__ wsu
   __shared__ float s_w[HLD * HLS];
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
   const int y0 = ty * HT, x0 = tx * HT;
+  uint8_t f[H_CPT];  // the tile's codes, all loads in flight with the staging's
+#pragma unroll
+  for (int j = 0; j < H_CPT; j++) {
+    const int c = threadIdx.x + 256 * j;
+    const int y = y0 + c / HT, x = x0 + c % HT;
+    f[j] = (y < w.H && x < w.W) ? fdr[(long long)y * w.ld + x] : (uint8_t)1;
+  }
   hy_stage<float>(s_w, wsurf, w, y0, x0, __builtin_inff());  // beyond the raster: not nodata (those cells got their
   __syncthreads();                                           // outward code from the stencil), never equal to anything
   int any = 0;
@@ -250,7 +310,7 @@ __global__ __launch_bounds__(256) void k_flat_init(const float *__restrict__ wsu
     const long long o = (long long)y * w.ld + x;
     const int p = (ly + 1) * HLS + lx + 1;
     uint32_t d = 0u;
-    if (!hy_nodata(s_w[p]) && fdr[o] == 0) {
+    if (!hy_nodata(s_w[p]) && f[j] == 0) {
       d = H_INF_DIST;
       // scan order NW N NE W E SW S SE
       uint32_t code = 0u;
@@ -272,7 +332,9 @@ __global__ __launch_bounds__(256) void k_flat_init(const float *__restrict__ wsu
     dist[o] = d;
   }
   any = __syncthreads_or(any);
-  if (has_flat && threadIdx.x == 0) has_flat[blockIdx.x] = (uint8_t)any;
+  // (read as the activity byte of "round -1" by the first relaxation round: the tile itself is open, its neighbours
+  // have something to look at)
+  if (has_flat && threadIdx.x == 0) has_flat[blockIdx.x] = (uint8_t)(any ? (HY_CHANGED | HY_OPEN) : 0);
 }
 
 // one round of the flat distances: d(c) = 1 + min d(n) over neighbours of the same filled height
@@ -280,11 +342,11 @@ __global__ __launch_bounds__(256) void k_flat_relax(const float *__restrict__ ws
                                                    int tiles_x, int *__restrict__ changed,
                                                    const int *__restrict__ prev,
                                                    const uint8_t *__restrict__ act_prev,
-                                                   uint8_t *__restrict__ act_cur, int tiles_y) {
+                                                   uint8_t *__restrict__ act_cur, int tiles_y, int sweeps) {
   const int H = w.H, W = w.W;
   __shared__ float s_w[HLD * HLS];
   __shared__ uint32_t s_d[HLD * HLS];
-  if (prev && __hip_atomic_load(prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+  if (prev && *prev == 0) return;  // (a plain scalar load: see k_fill_relax)
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
   const int y0 = ty * HT, x0 = tx * HT;
   if (!hy_tile_active(act_prev, ty, tx, tiles_x, tiles_y)) {
@@ -294,33 +356,67 @@ __global__ __launch_bounds__(256) void k_flat_relax(const float *__restrict__ ws
   hy_stage<float>(s_w, wsurf, w, y0, x0, DT_NODATA);
   hy_stage<uint32_t>(s_d, dist, w, y0, x0, H_INF_DIST);
   __syncthreads();
-  // directional in-place sweeps, as k_fill_relax: distances only decrease, towards the same fixed point.  (Tried: a
-  // few plain sweeps over all cells first, for the small features: 133 instead of 101 ms at 16384^2 -- tiles that are
-  // still moving after them pay for both.)
+  // directional in-place sweeps, as k_fill_relax: distances only decrease, towards the same fixed point; rounds of four
+  // sweeps until one changes nothing.  The heights never change, and the line a sweep comes from is in registers
+  // (heights and distances: the lane's own, its neighbours' through DPP), the line it stands on and the line ahead were
+  // fetched a step earlier: 7 LDS reads per step where round 3 made 17.
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  int any = 0;
-#define HY_N(off)                                   \
-  if (s_w[p + (off)] == wc) m = min(m, s_d[p + (off)]);
-  {
+  const bool by_rows = !(wave & 2);
+  const int dir = (wave & 1) ? -1 : 1;
+  const int SA = by_rows ? dir * HLS : dir, SC = by_rows ? 1 : HLS;
+  const int k0 = (wave & 1) ? HT - 1 : 0;
+  const int p0 = by_rows ? (k0 + 1) * HLS + lane + 1 : (lane + 1) * HLS + k0 + 1;
+  int any = 0, open = 0;
+  auto dpp_prev = [](uint32_t edge, uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x138, 0xF, 0xF, false);
+  };
+  auto dpp_next = [](uint32_t edge, uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x130, 0xF, 0xF, false);
+  };
+#define HY_M(wn, dn) m = min(m, (wn) == wc ? (dn) : H_INF_DIST);
+  for (int it = 0; it < sweeps; it++) {
+    int p = p0;
+    float wu = s_w[p - SA], whl = s_w[p - SA - SC], whr = s_w[p - SA + SC];   // heights: line before, its edge cells
+    uint32_t du = s_d[p - SA], dhl = s_d[p - SA - SC], dhr = s_d[p - SA + SC];
+    float wcur = s_w[p], wlf = s_w[p - SC], wrt = s_w[p + SC];
+    uint32_t dcur = s_d[p], dlf = s_d[p - SC], drt = s_d[p + SC];
     int ch = 0;
     for (int step = 0; step < HT; step++) {
-      const int k = (wave & 1) ? HT - 1 - step : step;
-      const int ly = (wave & 2) ? lane : k, lx = (wave & 2) ? k : lane;
-      const int p = (ly + 1) * HLS + lx + 1;
-      const uint32_t cur = s_d[p];
-      const float wc = s_w[p];
+      const uint32_t fresh = s_d[p];
+      const float w0 = s_w[p + SA - SC], w1 = s_w[p + SA], w2 = s_w[p + SA + SC];
+      const uint32_t d0 = s_d[p + SA - SC], d1 = s_d[p + SA], d2 = s_d[p + SA + SC];
+      const float wc = wcur;
+      const float wum = hy_from_prev_lane(whl, wu), wup = hy_from_next_lane(whr, wu);
+      const uint32_t dum = dpp_prev(dhl, du), dup = dpp_next(dhr, du);
       uint32_t m = H_INF_DIST;
-      HY_N(-HLS - 1) HY_N(-HLS) HY_N(-HLS + 1) HY_N(-1) HY_N(1) HY_N(HLS - 1) HY_N(HLS) HY_N(HLS + 1)
+      HY_M(wum, dum) HY_M(wu, du) HY_M(wup, dup) HY_M(wlf, dlf) HY_M(wrt, drt) HY_M(w0, d0) HY_M(w1, d1) HY_M(w2, d2)
       // coded cells (0) and cells next to one (1) are final; positions beyond the raster edge are staged as nodata
-      if (cur > 1u && !hy_nodata(wc) && m != H_INF_DIST && m + 1u < cur) {
-        s_d[p] = m + 1u;
+      const bool lower = dcur > 1u && !hy_nodata(wc) && m != H_INF_DIST;
+      const uint32_t nd = m + 1u;
+      if (lower && nd < fresh) {
+        s_d[p] = nd;
         ch = 1;
       }
+      du = (lower && nd < dcur) ? nd : dcur;  // what this lane leaves behind
+      wu = wc;
+      whl = wlf;
+      whr = wrt;
+      dhl = dlf;
+      dhr = drt;
+      wcur = w1;
+      wlf = w0;
+      wrt = w2;
+      dcur = d1;
+      dlf = d0;
+      drt = d2;
+      p += SA;
     }
-    any = __syncthreads_or(ch);
+    open = __syncthreads_or(ch);
+    if (!open) break;
+    any = 1;
   }
-#undef HY_N
-  if (act_cur && threadIdx.x == 0) act_cur[blockIdx.x] = (uint8_t)any;
+#undef HY_M
+  if (act_cur && threadIdx.x == 0) act_cur[blockIdx.x] = (uint8_t)((any ? HY_CHANGED : 0) | (open ? HY_OPEN : 0));
   if (!any) return;
 #pragma unroll
   for (int j = 0; j < H_CPT; j++) {
@@ -433,6 +529,10 @@ static DtWin hy_full_window(int64_t H, int64_t W) {
 // without a code (0 on any raster: every flat of a filled surface reaches a coded cell).  Synchronous.
 int dt_launch_condition(hipStream_t s, const float *dem, int64_t H, int64_t W, double px, float *filled, uint8_t *fdr,
                         void *scratch, int *unresolved_host, int *rounds_host) {
+  const int fill_sweeps = dt_debug_get(DT_DBG_HY_FILL_SWEEPS) > 0 ? dt_debug_get(DT_DBG_HY_FILL_SWEEPS) : HY_FILL_SWEEPS;
+  const int flat_sweeps = dt_debug_get(DT_DBG_HY_FLAT_SWEEPS) > 0 ? dt_debug_get(DT_DBG_HY_FLAT_SWEEPS) : HY_FLAT_SWEEPS;
+  (void)fill_sweeps;
+  (void)flat_sweeps;
   const int64_t n = H * W;
   if (n == 0) return DT_OK;
   int *flag = (int *)scratch;
@@ -440,7 +540,6 @@ int dt_launch_condition(hipStream_t s, const float *dem, int64_t H, int64_t W, d
   const DtWin w = hy_full_window(H, W);
   const int tiles_x = (int)((W + HT - 1) / HT), tiles_y = (int)((H + HT - 1) / HT);
   dim3 gc((unsigned)((n + 255) / 256)), gt((unsigned)(tiles_x * tiles_y)), b(256);
-  hipLaunchKernelGGL(k_fill_init, gc, b, 0, s, dem, w, filled);
   int r1 = 0, r2 = 0;
   const int64_t max_rounds = n + 8;
   uint8_t *act[2];
@@ -448,8 +547,12 @@ int dt_launch_condition(hipStream_t s, const float *dem, int64_t H, int64_t W, d
   act[1] = act[0] + dt_align256(hy_tiles(H, W));
   uint8_t *has_flat = act[1] + dt_align256(hy_tiles(H, W));
   DT_TRY(hy_iterate(s, flag, max_rounds, [&](int *f, const int *prev, int64_t r) {
-    hipLaunchKernelGGL(k_fill_relax, gt, b, 0, s, dem, filled, w, tiles_x, f, prev,
-                       r ? (const uint8_t *)act[(r - 1) & 1] : (const uint8_t *)nullptr, act[r & 1], tiles_y);
+    if (r == 0)  // the first round initialises the surface itself (no k_fill_init pass)
+      hipLaunchKernelGGL(k_fill_relax<true>, gt, b, 0, s, dem, filled, w, tiles_x, f, prev, (const uint8_t *)nullptr,
+                         act[0], tiles_y, fill_sweeps);
+    else
+      hipLaunchKernelGGL(k_fill_relax<false>, gt, b, 0, s, dem, filled, w, tiles_x, f, prev,
+                         (const uint8_t *)act[(r - 1) & 1], act[r & 1], tiles_y, fill_sweeps);
   }, &r1));
   if (fdr) {
     DT_TRY(dt_launch_stencil(s, w, filled, px, nullptr, fdr, nullptr, nullptr, 0, 0.0, nullptr, nullptr));
@@ -457,7 +560,7 @@ int dt_launch_condition(hipStream_t s, const float *dem, int64_t H, int64_t W, d
     // the first round visits the tiles that have flat cells (and their neighbours), not every tile
     DT_TRY(hy_iterate(s, flag, max_rounds, [&](int *f, const int *prev, int64_t r) {
       hipLaunchKernelGGL(k_flat_relax, gt, b, 0, s, filled, dist, w, tiles_x, f, prev,
-                         r ? (const uint8_t *)act[(r - 1) & 1] : (const uint8_t *)has_flat, act[r & 1], tiles_y);
+                         r ? (const uint8_t *)act[(r - 1) & 1] : (const uint8_t *)has_flat, act[r & 1], tiles_y, flat_sweeps);
     }, &r2));
     DT_HIP(hipMemsetAsync(flag + 64, 0, sizeof(int), s));
     hipLaunchKernelGGL(k_flat_assign, gt, b, 0, s, filled, dist, w, fdr, flag + 64, tiles_x, (const uint8_t *)has_flat);
@@ -481,6 +584,10 @@ int dt_launch_condition(hipStream_t s, const float *dem, int64_t H, int64_t W, d
 // the fixed point whatever it takes.  The bundled Example raster needs 12 rounds, rough 4096^2 terrain a few dozen.
 int dt_launch_condition_async(hipStream_t s, const float *dem, int64_t H, int64_t W, double px, float *filled,
                               uint8_t *fdr, void *scratch, int rounds, int *status) {
+  const int fill_sweeps = dt_debug_get(DT_DBG_HY_FILL_SWEEPS) > 0 ? dt_debug_get(DT_DBG_HY_FILL_SWEEPS) : HY_FILL_SWEEPS;
+  const int flat_sweeps = dt_debug_get(DT_DBG_HY_FLAT_SWEEPS) > 0 ? dt_debug_get(DT_DBG_HY_FLAT_SWEEPS) : HY_FLAT_SWEEPS;
+  (void)fill_sweeps;
+  (void)flat_sweeps;
   const int64_t n = H * W;
   if (n == 0) return DT_OK;
   DT_REQUIRE(fdr != nullptr, "the asynchronous conditioning writes the D8 codes");
@@ -491,22 +598,22 @@ int dt_launch_condition_async(hipStream_t s, const float *dem, int64_t H, int64_
   const int tiles_x = (int)((W + HT - 1) / HT), tiles_y = (int)((H + HT - 1) / HT);
   dim3 gc((unsigned)((n + 255) / 256)), gt((unsigned)(tiles_x * tiles_y)), b(256);
   DT_HIP(hipMemsetAsync(flags, 0, DT_HYDRO_FLAG_BYTES, s));
-  hipLaunchKernelGGL(k_fill_init, gc, b, 0, s, dem, w, filled);
   uint8_t *act[2];
   act[0] = (uint8_t *)scratch + DT_HYDRO_FLAG_BYTES + dt_align256((size_t)n * 4);
   act[1] = act[0] + dt_align256(hy_tiles(H, W));
   uint8_t *has_flat = act[1] + dt_align256(hy_tiles(H, W));
-  for (int r = 0; r < rounds; r++)
-    hipLaunchKernelGGL(k_fill_relax, gt, b, 0, s, dem, filled, w, tiles_x, flags + r,
-                       r ? (const int *)(flags + r - 1) : (const int *)nullptr,
-                       r ? (const uint8_t *)act[(r - 1) & 1] : (const uint8_t *)nullptr, act[r & 1], tiles_y);
+  hipLaunchKernelGGL(k_fill_relax<true>, gt, b, 0, s, dem, filled, w, tiles_x, flags, (const int *)nullptr,
+                     (const uint8_t *)nullptr, act[0], tiles_y, fill_sweeps);
+  for (int r = 1; r < rounds; r++)
+    hipLaunchKernelGGL(k_fill_relax<false>, gt, b, 0, s, dem, filled, w, tiles_x, flags + r, (const int *)(flags + r - 1),
+                       (const uint8_t *)act[(r - 1) & 1], act[r & 1], tiles_y, fill_sweeps);
   DT_TRY(dt_launch_stencil(s, w, filled, px, nullptr, fdr, nullptr, nullptr, 0, 0.0, nullptr, nullptr));
   hipLaunchKernelGGL(k_flat_init, gt, b, 0, s, filled, fdr, w, dist, tiles_x, has_flat);
   int *fl2 = flags + rounds;
   for (int r = 0; r < rounds; r++)
     hipLaunchKernelGGL(k_flat_relax, gt, b, 0, s, filled, dist, w, tiles_x, fl2 + r,
                        r ? (const int *)(fl2 + r - 1) : (const int *)nullptr,
-                       r ? (const uint8_t *)act[(r - 1) & 1] : (const uint8_t *)has_flat, act[r & 1], tiles_y);
+                       r ? (const uint8_t *)act[(r - 1) & 1] : (const uint8_t *)has_flat, act[r & 1], tiles_y, flat_sweeps);
   hipLaunchKernelGGL(k_flat_assign, gt, b, 0, s, filled, dist, w, fdr, flags + 2 * rounds, tiles_x,
                      (const uint8_t *)has_flat);
   hipLaunchKernelGGL(k_hydro_verdict, dim3(1), dim3(1), 0, s, (const int *)(flags + rounds - 1),
@@ -521,6 +628,10 @@ int dt_launch_condition_async(hipStream_t s, const float *dem, int64_t H, int64_
 // iteration) is raised by stages 1 / 3 when something changed, and counts the unresolved cells in stage 4.
 int dt_launch_condition_stage(hipStream_t s, const DtWin &w, int stage, int rounds, const float *dem, float *filled,
                               uint8_t *fdr, uint32_t *dist, int *flag_dev) {
+  const int fill_sweeps = dt_debug_get(DT_DBG_HY_FILL_SWEEPS) > 0 ? dt_debug_get(DT_DBG_HY_FILL_SWEEPS) : HY_FILL_SWEEPS;
+  const int flat_sweeps = dt_debug_get(DT_DBG_HY_FLAT_SWEEPS) > 0 ? dt_debug_get(DT_DBG_HY_FLAT_SWEEPS) : HY_FLAT_SWEEPS;
+  (void)fill_sweeps;
+  (void)flat_sweeps;
   const int64_t n = (int64_t)w.H * w.W;
   if (n == 0) return DT_OK;
   const int tiles_x = (w.W + HT - 1) / HT, tiles_y = (w.H + HT - 1) / HT;
@@ -534,8 +645,8 @@ int dt_launch_condition_stage(hipStream_t s, const DtWin &w, int stage, int roun
     case 1:
       DT_REQUIRE(dem && filled && flag_dev, "NULL pointer");
       for (int r = 0; r < rounds; r++)
-        hipLaunchKernelGGL(k_fill_relax, gt, b, 0, s, dem, filled, w, tiles_x, flag_dev, (const int *)nullptr,
-                           (const uint8_t *)nullptr, (uint8_t *)nullptr, tiles_y);
+        hipLaunchKernelGGL(k_fill_relax<false>, gt, b, 0, s, dem, filled, w, tiles_x, flag_dev, (const int *)nullptr,
+                           (const uint8_t *)nullptr, (uint8_t *)nullptr, tiles_y, fill_sweeps);
       break;
     case 2:
       DT_REQUIRE(filled && fdr && dist, "NULL pointer");
@@ -545,7 +656,7 @@ int dt_launch_condition_stage(hipStream_t s, const DtWin &w, int stage, int roun
       DT_REQUIRE(filled && dist && flag_dev, "NULL pointer");
       for (int r = 0; r < rounds; r++)
         hipLaunchKernelGGL(k_flat_relax, gt, b, 0, s, filled, dist, w, tiles_x, flag_dev, (const int *)nullptr,
-                           (const uint8_t *)nullptr, (uint8_t *)nullptr, tiles_y);
+                           (const uint8_t *)nullptr, (uint8_t *)nullptr, tiles_y, flat_sweeps);
       break;
     case 4:
       DT_REQUIRE(filled && dist && fdr && flag_dev, "NULL pointer");

@@ -78,6 +78,19 @@ def bench(name, dem, px):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[2] == "sweeps":  # N sweeps: rounds of sweeps per visit, fill x flat
+        n = int(sys.argv[1])
+        dem_r, dem_e = rough(n), example()
+        for fs in (1, 2, 3):
+            for ls in (1, 2, 3, 6):
+                L.dt_debug_set(6, fs)
+                L.dt_debug_set(7, ls)
+                print("fill sweeps %d, flat sweeps %d:" % (fs, ls), flush=True)
+                bench("   rough synthetic DEM", dem_r, 10.0)
+                bench("   Example DEM", dem_e, 12.5)
+        L.dt_debug_set(6, 0)
+        L.dt_debug_set(7, 0)
+        sys.exit(0)
     if len(sys.argv) > 1:  # python tools/condition_bench.py N: the rough DEM at N x N only
         n = int(sys.argv[1])
         bench("rough synthetic DEM", rough(n), 10.0)
