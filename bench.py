@@ -27,7 +27,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r3", "pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r4", "pmc_traffic.json")
 
 
 def pmc_traffic(kernels, size):

@@ -1,4 +1,4 @@
-"""CPU: the committed rocprofv3 summaries of this round (profiles/r3/) are what bench.py attaches as
+"""CPU: the committed rocprofv3 summaries of this round (profiles/r4/) are what bench.py attaches as
 roofline.traffic / per_op.traffic_bytes, and DESIGN.md's measurement table is generated from them."""
 import csv
 import json
@@ -9,7 +9,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R2 = os.path.join(ROOT, "profiles", "r3")  # this round's set
+R2 = os.path.join(ROOT, "profiles", "r4")  # this round's set
 sys.path.insert(0, ROOT)
 
 needs_profiles = pytest.mark.skipif(not os.path.exists(os.path.join(R2, "pmc_traffic.json")),

@@ -39,10 +39,11 @@ echo "bench done"
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-e2e --no-overlap > $OUT/bench16384_serial.json 2>/dev/null
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --tiled > $OUT/bench16384_tiled.json 2>/dev/null
 rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/sq_a $OUT/sq_b $OUT/trace
-# the placement study: write-conflict classes of consecutive allocations, the read / write mixes, counters
-python3 tools/placement_probe.py classes 40 plain > $OUT/placement_classes.txt 2>&1 || true
-python3 tools/placement_probe.py classes 40 bench >> $OUT/placement_classes.txt 2>&1 || true
-PROBE_MIX=1 python3 tools/placement_probe.py gens 8 > $OUT/placement_mix.txt 2>&1 || true
-python3 tools/placement_probe.py pick 9 12 > $OUT/placement_pick.txt 2>&1 || true
+# round 4: the placement study is tools/micro/placement_map (physical blocks, delta scan) and tools/arena_probe.py,
+# run on their own (profiles/r4/placement_map_*.txt, placement_arena_probe.txt); the conditioning and the real-terrain
+# walkers likewise (tools/condition_bench.py, tools/ds_ranks_real.py)
+python3 tools/condition_bench.py > $OUT/conditioning.txt 2>&1 || true
+python3 tools/condition_bench.py 16384 >> $OUT/conditioning.txt 2>&1 || true
+python3 tools/ds_ranks_real.py check finish > $OUT/downslope_ranks_real_terrain.txt 2>&1 || true
 rocm-smi --showclocks --showpower > $OUT/rocm_smi.txt 2>&1 || true
 ls -la $OUT

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Prints DESIGN.md section 6's measurement table from the committed profile set (profiles/r3/): the un-profiled
+"""Prints DESIGN.md section 6's measurement table from the committed profile set (profiles/r4/): the un-profiled
 bench line (per-op HIP-event times), the rocprofv3 kernel-trace summary (per-kernel averages) and the PMC traffic
 summary.  tests/test_profiles.py checks that DESIGN.md contains exactly this output."""
 import csv
@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from descriptools_amd import chain  # noqa: E402
 
-R = os.path.join(ROOT, "profiles", "r3")
+R = os.path.join(ROOT, "profiles", "r4")
 LABEL = {"d8": "D8", "downslope": "downslope",
          "flowacc_flowhand_local": "flow accumulation + river mask + HAND phase 1 (tile solves, node jumps)",
          "flowhand_gfi_finish": "HAND last pass: fdist, idx, hand + GFI + ln(hl/H)",
