@@ -43,9 +43,14 @@ def _flood(t, torch):
     return ((h >= 0) & (h < 1.5) & keep).to(torch.int8).contiguous()
 
 
-def _run_layout(layout, seed, thr, idx64, sample):
+LOCAL = ("slope", "ti", "mti", "gfi", "lnhlh", "down")   # rasters no other stage or rank reads
+
+
+def _run_layout(layout, seed, thr, idx64, sample, lean=False):
     """one decomposition: run the step on every logical rank, collect block checksums, properties, the classifier and
-    the sampled cells; frees everything before returning"""
+    the sampled cells; frees everything before returning.  lean: the six rasters nothing downstream reads (LOCAL) exist
+    ONCE and serve every logical rank in turn -- each rank's are reduced to their block checksums before the next rank
+    overwrites them -- so that eight ranks of 2^29 cells fit one device."""
     import gc
     import torch
     from descriptools_amd import tiling
@@ -53,13 +58,49 @@ def _run_layout(layout, seed, thr, idx64, sample):
     torch.cuda.empty_cache()  # earlier tests' cached blocks are invisible to the library's own allocations
     Hg, Wg = layout.Hg, layout.Wg
     tiles = []
-    for r in range(layout.size):
-        t = tiling.RankTile(layout, r, device=0, px=10.0, river_threshold=thr, idx64=idx64, acc64=True)
-        assert t.acc64 and t.t["fac"].dtype == torch.int64 and t.t["a_river"].dtype == torch.int64
-        t.synth_dem(seed)
-        tiles.append(t)
-    tiling.simulate_dev(tiles, layout)
     out = {"sums": {n: np.zeros((Hg // BLK, Wg // BLK), np.int64) for n in NAMES}}
+    if lean:
+        keep = ("dem", "fdr", "fac", "river", "fdist", "idx", "hand")
+        shared = None
+        for r in range(layout.size):
+            t = tiling.RankTile(layout, r, device=0, px=10.0, river_threshold=thr, idx64=idx64, acc64=True, rasters=keep,
+                                tune_placement=False)
+            if shared is None:  # (every rank tile of a uniform layout has the same extended shape)
+                shared = {n: torch.zeros((t.He, t.We), dtype=torch.float32, device="cuda") for n in LOCAL}
+            assert all(tuple(shared[n].shape) == (t.He, t.We) for n in LOCAL)
+            t.t.update(shared)
+            t.synth_dem(seed)
+            tiles.append(t)
+        # tiling.simulate_dev, with the last stage rank by rank
+        for t in tiles:
+            t.d8()
+            t.fa_local(sync=False)
+            t.fill_ring_codes()
+        for t in tiles:
+            t.ctx.sync()
+        rows = torch.cat([t.fa_row for t in tiles])
+        torch.cuda.synchronize()
+        for t in tiles:
+            t.fa_solve_finish_fh_local(rows)
+        for t in tiles:
+            t.ctx.sync()
+        rows = torch.cat([t.fh_row for t in tiles])
+        torch.cuda.synchronize()
+        for t in tiles:
+            t.fh_solve_finish(rows, fuse_gfi=True, want_a_river=False)
+            t.slope_twi()
+            t.downslope()
+            t.ctx.sync()
+            y0, x0 = layout.origin(t.rank)
+            for n in LOCAL:
+                out["sums"][n][y0 // BLK:(y0 + t.H) // BLK, x0 // BLK:(x0 + t.W) // BLK] = _block_sums(t, torch, n)
+    else:
+        for r in range(layout.size):
+            t = tiling.RankTile(layout, r, device=0, px=10.0, river_threshold=thr, idx64=idx64, acc64=True)
+            assert t.acc64 and t.t["fac"].dtype == torch.int64 and t.t["a_river"].dtype == torch.int64
+            t.synth_dem(seed)
+            tiles.append(t)
+        tiling.simulate_dev(tiles, layout)
     dy = torch.zeros(256, dtype=torch.int64, device="cuda")
     dx = torch.zeros(256, dtype=torch.int64, device="cuda")
     for c, (a, b) in {1: (0, 1), 2: (1, 1), 4: (1, 0), 8: (1, -1), 16: (0, -1), 32: (-1, -1), 64: (-1, 0),
@@ -74,6 +115,8 @@ def _run_layout(layout, seed, thr, idx64, sample):
         assert t.unresolved_downslope() == 0
         y0, x0 = layout.origin(t.rank)
         for n in NAMES:
+            if lean and n in LOCAL:
+                continue  # (reduced right after the rank computed them)
             out["sums"][n][y0 // BLK:(y0 + t.H) // BLK, x0 // BLK:(x0 + t.W) // BLK] = _block_sums(t, torch, n)
         fdr, fac, river, idx, fdist = (t.core(n) for n in ("fdr", "fac", "river", "idx", "fdist"))
         assert int((fac < 0).sum()) == 0
@@ -225,3 +268,48 @@ def test_config5_2x4_ranks_of_16384():
     assert a["capped"] == b["capped"]
     assert a["eval"]["threshold"] == b["eval"]["threshold"] and np.array_equal(a["eval"]["counts"], b["eval"]["counts"])
     assert a["eval"]["mn"] == b["eval"]["mn"] and a["eval"]["mx"] == b["eval"]["mx"]
+
+
+def test_config5_at_its_named_size_65536x65536_as_8_logical_ranks():
+    """BASELINE.json configs[4] at the size it names: 65536 x 65536 = 2^32 cells as 2 x 4 logical ranks of
+    32768 x 16384 on ONE MI355X (the six rasters nothing downstream reads exist once and serve the ranks in turn:
+    ~200 GB of the 288).  What only this size has: a global river index beyond 2^32 (the int64 raster's upper half is
+    live), accumulations of up to 2^32 - 1 cells, the rank-tile shape of the 8-GPU run in all eight positions of the
+    grid.  Checks as at 2^31 cells: conservation over the global raster, river cells indexing themselves with their
+    64-bit global index, an independent host walk of the reference's kernel from sampled cells on both sides of the
+    20000-move cap, the classifier's rank reductions against plain tensor operations, and invariance of every raster
+    under a second decomposition (4 x 2 ranks of 16384 x 32768)."""
+    import gc
+    import torch
+    from descriptools_amd import device, tiling
+    gc.collect()
+    device.trim()
+    torch.cuda.empty_cache()
+    free, total = torch.cuda.mem_get_info()
+    if total < 250 * 2 ** 30 or free < 230 * 2 ** 30:
+        pytest.skip("needs ~200 GB of free HBM (an MI355X to itself)")
+    la = tiling.Layout([32768, 32768], [16384] * 4)            # the bench's N = 8 layout
+    lb = tiling.Layout([16384] * 4, [32768, 32768])
+    Hg, Wg = la.Hg, la.Wg
+    assert (Hg, Wg) == (65536, 65536) == (lb.Hg, lb.Wg) and Hg * Wg == 2 ** 32
+    thr = (Hg * Wg) // 512
+    rng = np.random.default_rng(6)
+    sy, sx = rng.integers(0, Hg, 6000), rng.integers(0, Wg, 6000)
+    a = _run_layout(la, 1, thr, idx64=True, sample=(sy, sx), lean=True)
+    print("65536^2 as 2 x 4 ranks: %d cells beyond the 20000-move cap; threshold %r fit %r" %
+          (a["capped"], a["eval"]["threshold"], a["eval"]["fit"]))
+    want_idx, want_fd = _walk(a["fdr_g"], a["riv_g"], sy, sx, 10.0)
+    got_idx, got_fd = np.zeros_like(want_idx), np.zeros_like(want_fd)
+    for pos, gi, gf in a["picked"].values():
+        got_idx[pos], got_fd[pos] = gi, gf
+    assert np.array_equal(got_idx, want_idx), int((got_idx != want_idx).sum())
+    assert np.array_equal(got_fd, want_fd), int((got_fd != want_fd).sum())
+    assert (want_idx >= 2 ** 32 // 2).sum() > 500 and (want_idx >= 2 ** 31).sum() > 1000, "river indices beyond 2^31 sampled"
+    assert int(want_idx.max()) > 2 ** 31 and (want_idx == -100).sum() > 50
+    del a["fdr_g"], a["riv_g"]
+    b = _run_layout(lb, 1, thr, idx64=True, sample=None, lean=True)
+    for n in NAMES:
+        bad = np.argwhere(a["sums"][n] != b["sums"][n])
+        assert len(bad) == 0, "%s differs between the decompositions in %d blocks, first %s" % (n, len(bad), bad[0])
+    assert a["capped"] == b["capped"]
+    assert a["eval"]["threshold"] == b["eval"]["threshold"] and np.array_equal(a["eval"]["counts"], b["eval"]["counts"])
