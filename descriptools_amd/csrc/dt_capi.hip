@@ -6,6 +6,7 @@
 #include <atomic>
 #include <chrono>
 #include <mutex>
+#include <system_error>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -450,7 +451,6 @@ extern "C" int dt_dev_condition_d8_async(dt_ctx *c, const float *dem, int64_t H,
   size_t need = dt_hydro_scratch(H, W);
   DT_TRY(dt_scratch_reset(c, need));
   void *scr = dt_scratch_take(c, need);
-  DT_TRY(dt_side_reserve(c, &c->aux, &c->aux_bytes, dt_stencil_aux_bytes(H, W)));
   DT_TRY(dt_launch_condition_async(c->stream, dem, H, W, px, filled, fdr, scr, rounds, c->status));
   DT_HIP(hipGetLastError());
   return DT_OK;
@@ -1304,10 +1304,16 @@ extern "C" int dt_host_alloc(int64_t bytes, void **out) {
       const int threads = (int)(hc == 0 ? 1 : (hc > 8 ? 8 : hc));
       const size_t per = ((n / (size_t)threads) + DT_HUGE - 1) & ~(DT_HUGE - 1);
       std::vector<std::thread> th;
-      for (int t = 0; t < threads; t++)
-        th.emplace_back([=] {
-          for (size_t o = per * (size_t)t; o < n && o < per * (size_t)(t + 1); o += 4096) a[o] = 0;
-        });
+      auto touch = [=](int t) {
+        for (size_t o = per * (size_t)t; o < n && o < per * (size_t)(t + 1); o += 4096) a[o] = 0;
+      };
+      for (int t = 0; t < threads; t++) {
+        try {
+          th.emplace_back(touch, t);
+        } catch (const std::system_error &) {  // no thread to be had: this one does the work (nothing may be thrown
+          touch(t);                             // through extern "C")
+        }
+      }
       for (auto &t : th) t.join();
       const double touch_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_touch).count();
       if (thp && touch_s > 0.1 * ((double)n / (double)(1ull << 30)) + 0.02) g_host_thp.store(false);
@@ -1362,7 +1368,13 @@ extern "C" int dt_host_f32_to_f64(const float *src, double *dst, int64_t n) {
     return DT_OK;
   }
   std::vector<std::thread> th;
-  for (int t = 0; t < threads; t++) th.emplace_back(work, t);
+  for (int t = 0; t < threads; t++) {
+    try {
+      th.emplace_back(work, t);
+    } catch (const std::system_error &) {  // no thread to be had: this one does the work
+      work(t);
+    }
+  }
   for (auto &t : th) t.join();
   return DT_OK;
 }

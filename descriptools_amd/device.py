@@ -21,16 +21,26 @@ class PinnedPool:
         # idle blocks beyond this budget are unlocked and freed when they come back (DT_PINNED_CACHE_MB, default
         # 4096; 0 = recycle nothing): one run_host on a 16384^2 DEM would otherwise leave ~20 GiB page-locked
         self.budget = max(int(os.environ.get("DT_PINNED_CACHE_MB", "4096")), 0) << 20
+        # page-locked bytes in the callers' hands at any moment: beyond this cap (DT_PINNED_MAX_MB, default 32768) an
+        # array is plain pageable numpy memory -- a workflow that keeps ten float64 rasters of 16384^2 alive would
+        # otherwise hold 20 GiB of the host locked
+        self.max_live = max(int(os.environ.get("DT_PINNED_MAX_MB", "32768")), 0) << 20
+        self._live = 0
 
     @staticmethod
     def _klass(nbytes):
-        return max(4096, 1 << (int(nbytes) - 1).bit_length()) if nbytes > (1 << 26) else max(4096, (int(nbytes) + 4095) // 4096 * 4096)
+        """size class of a block: 4 KiB granules up to 64 MiB, 2 MiB granules beyond (powers of two, the first form,
+        locked 2 GiB for a 1.01 GiB raster)"""
+        g = (2 << 20) if nbytes > (1 << 26) else 4096
+        return max(4096, (int(nbytes) + g - 1) // g * g)
 
     def empty(self, shape, dtype):
         import weakref
         dtype = np.dtype(dtype)
         n = int(np.prod(shape)) * dtype.itemsize
         k = self._klass(max(n, 1))
+        if self._live + k > self.max_live:
+            return np.empty(shape, dtype)
         lst = self._free.get(k)
         if lst:
             addr = lst.pop()
@@ -39,12 +49,14 @@ class PinnedPool:
             out = C.c_void_p()
             check(_lib.lib().dt_host_alloc(k, C.byref(out)))
             addr = out.value
+        self._live += k
         buf = (C.c_char * k).from_address(addr)
         arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
         weakref.finalize(buf, self._give_back, k, addr)  # buf lives as long as any view of it
         return arr
 
     def _give_back(self, k, addr):
+        self._live -= k
         if self._idle + k > self.budget:
             _lib.lib().dt_host_free(C.c_void_p(addr))
             return
@@ -116,6 +128,9 @@ class DeviceArray:
             return self.to_host()
         out = PINNED.empty(self.shape, self.dtype)
         check(_lib.lib().dt_dev_d2h_async(self.ctx.h, out.ctypes.data_as(C.c_void_p), self.ptr, self.nbytes))
+        # the DMA is in flight: the context holds the array until its next sync(), so that a caller who drops it early
+        # cannot send its block back to the pool (and on to somebody else) under the copy
+        self.ctx._inflight.append(out)
         return out
 
     def free(self):
@@ -134,6 +149,7 @@ class Context:
         check(_lib.lib().dt_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h)))
         self.h = h
         self.device = device
+        self._inflight = []  # host arrays of asynchronous copies not yet waited for (DeviceArray.to_host_async)
         if priority is not None:
             check(_lib.lib().dt_ctx_set_priority(self.h, int(priority)))
 
@@ -146,6 +162,7 @@ class Context:
 
     def sync(self):
         check(_lib.lib().dt_ctx_sync(self.h))
+        self._inflight.clear()
 
     def status(self):
         """sticky DT_STATUS_* bits raised by kernels since the last call (synchronises, clears)"""

@@ -144,3 +144,18 @@ def test_bench_gpus8_defaults_to_config5():
     assert bench.default_workload(1, None, None) == (16384, None)
     layout, _ = bench.tiled_layout(2, 0, "1024x2048")
     assert (layout.ty, layout.tx) == (1, 2) and layout.shape(1) == (1024, 1024)
+
+
+def test_pinned_pool_size_classes_and_cap(monkeypatch):
+    """a 1.01 GiB raster must not lock 2 GiB, and the page-locked bytes in callers' hands are capped
+    (pure bookkeeping: no allocation happens in this test)"""
+    from descriptools_amd import device
+    k = device.PinnedPool._klass
+    assert k(100) == 4096 and k((1 << 26)) == 1 << 26
+    big = int(1.01 * (1 << 30))
+    assert big <= k(big) < big + (2 << 20) and k(big) % (2 << 20) == 0
+    pool = device.PinnedPool()
+    pool.max_live = 1 << 20
+    pool._live = 1 << 20       # the cap is reached: the next array is pageable numpy, no library call
+    a = pool.empty((1 << 18,), "float32")
+    assert a.shape == (1 << 18,) and pool._live == 1 << 20
