@@ -42,7 +42,18 @@ def _check(parts, Hg, Wg, seed, nodata, dem=None, **chain_kw):
     from descriptools_amd import chain
     if dem is None:
         dem = oracle.synth_dem(seed, Hg, Wg, 0, 0, Hg, Wg, nodata)
-    ref = chain.run_host(dem, 10.0, river_threshold=(Hg * Wg) // 512, **chain_kw)
+    thr = (Hg * Wg) // 512
+    ref = chain.run_host(dem, 10.0, river_threshold=thr, **chain_kw)
+    if Hg * Wg <= 1 << 20 and not chain_kw.get("condition"):
+        # ... and the untiled chain against the ORACLE on this very DEM, so that "the ranks equal the chain" means "the
+        # ranks equal the reference's algorithms" in this test too (the conditioned chain: tests/test_gpu_hydro.py)
+        sl_o, fdr_o = oracle.slope_d8(dem, 10.0)
+        acc_o = oracle.flowacc(fdr_o, dem)
+        fd_o, idx_o, hand_o = oracle.flowhand(dem, fdr_o, (acc_o > thr).astype(np.int8), 10.0)
+        assert np.array_equal(ref["fdr"], fdr_o) and np.array_equal(ref["slope"], sl_o) and np.array_equal(ref["fac"], acc_o)
+        assert np.array_equal(ref["idx"], idx_o) and np.array_equal(ref["hand"], hand_o)
+        assert np.array_equal(ref["fdist"] == -100, fd_o == -100) and np.allclose(ref["fdist"], fd_o, rtol=1e-6, atol=0)
+        assert np.array_equal(ref["down"], oracle.downslope(dem, fdr_o, 10.0, 5.0))
     for r, p in enumerate(parts):
         y0, x0 = (int(v) for v in p["origin"])
         H, W = p["fdr"].shape
