@@ -72,7 +72,7 @@ class Chain:
         assert not (external_fdr and condition), "conditioning computes the codes itself"
         self.external_fdr = bool(external_fdr)
         self.long_walks = long_walks
-        self._lift = self._lift_q = self._lift_dem = None
+        self._lift = self._lift_q = self._lift_dem = self._lift_tables = None
         self.condition, self.condition_rounds = bool(condition), int(condition_rounds)
         self._alloc, self._release = alloc, release
         self.want_slope_rad = want_slope_rad
@@ -178,17 +178,19 @@ class Chain:
             return 0
         tables, tb = None, 0
         if n.value >= int(L.dt_downslope_tables_threshold(self.H, self.W)):
+            # the skip tables (24 bytes per cell) are kept once a step needed them: a raster that has long walks has
+            # them in every step, and allocating 5 GB per step is not free
             tb = int(L.dt_downslope_tables_workspace(self.H, self.W))
-            try:
-                tables = c.empty((tb,), np.uint8)
-            except MemoryError:  # (DT_ENOMEM: the walks are then made move by move)
-                tables, tb = None, 0
+            if self._lift_tables is None:
+                try:
+                    self._lift_tables = c.empty((tb,), np.uint8)
+                except MemoryError:  # (DT_ENOMEM: the walks are then made move by move)
+                    tb = 0
+            tables = self._lift_tables
         check(L.dt_dev_downslope_finish(c.h, self._lift_dem, self.p("fdr"), self.H, self.W, self.px, self.dz, 0,
                                         self.p("down"), self._lift_q.ptr, self._lift_q_bytes,
-                                        tables.ptr if tables is not None else None, tb))
+                                        tables.ptr if tables is not None else None, tb if tables is not None else 0))
         c.sync()
-        if tables is not None:
-            tables.free()
         return int(n.value)
 
     def p(self, name):
@@ -284,7 +286,7 @@ class Chain:
             if hasattr(b, "free"):
                 b.free()
         self.buf = {}
-        for name in ("_lift", "_lift_q"):
+        for name in ("_lift", "_lift_q", "_lift_tables"):
             if getattr(self, name) is not None:
                 getattr(self, name).free()
                 setattr(self, name, None)
