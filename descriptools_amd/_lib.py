@@ -134,6 +134,9 @@ _SIGS = {
                                               vp, vp, vp, vp, vp, vp, vp, vp]),
     "dt_dev_gfi_lnhlh_a64": (ci, [vp, vp, vp, vp, i64, f64, f64, f64, vp, vp]),
     "dt_dev_flowacc_river_flowhand_local": (ci, [vp, vp, vp, i64, i64, i64, vp, vp]),
+    "dt_dev_flowacc_river_flowhand_local_m": (ci, [vp, vp, vp, vp, i64, i64, i64, vp, vp]),
+    "dt_dev_slope_d8_m": (ci, [vp, vp, i64, i64, f64, vp, vp]),
+    "dt_nodata_mask_bytes": (i64, [i64, i64]),
     "dt_dev_flowacc_finish_flowhand_local_w": (ci, [vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp]),
     "dt_dev_flowacc_finish_flowhand_local_w_a64": (ci, [vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp]),
     "dt_dev_i32_to_i64": (ci, [vp, vp, i64, vp]),

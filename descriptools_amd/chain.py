@@ -34,7 +34,7 @@ WRITE_GROUPS = (("slope", "ti", "mti"), ("fdist", "idx", "hand", "gfi", "lnhlh")
 OPS = (
     ("d8", 5, ["k_d8<false>", "k_d8_fix"]),
     ("downslope", 9, ["k_downslope_win<24>"]),
-    ("flowacc_flowhand_local", 5 + 1 + 2, ["k_fa_tile1", "k_fa_reduce", "k_fa_poison", "k_fa3fh1<true>", "k_fh_tile1",
+    ("flowacc_flowhand_local", 5 + 1 + 2, ["k_fa_tile1", "k_fa_reduce", "k_fa_poison", "k_fa3fh1<2>", "k_fh_tile1",
                                            "k_fh_ghost_init", "k_fh_node_jump"]),
     ("slope_twi", 20, ["k_slope_twi<true, false, 1, int, 1>", "k_slope_twi_fix<int, 1>"]),
     ("flowhand_gfi_finish", 28, ["k_fh_tile3<false, 1, 5, int>"]),
@@ -88,6 +88,10 @@ class Chain:
         self._graphs = []
         for name, dt in OUTPUTS + ((("filled", F32),) if self.condition else ()):
             self.buf[name] = alloc((H, W), dt) if alloc else self.ctx.empty((H, W), dt)
+        # the D8 kernel's nodata mask (one byte per four cells): what the accumulation pass needs of the DEM
+        self._nodata4 = None
+        if not (self.external_fdr or self.condition):
+            self._nodata4 = self.ctx.empty((int(_lib.lib().dt_nodata_mask_bytes(H, W)),), U8)
         assert tune_placement in (False, True, "search")
         self.placement = {"tuned": False, "why": "tune_placement=False"}
         if tune_placement:
@@ -209,7 +213,8 @@ class Chain:
             self._full = _lib.Window(H, W, W, 0, 0, H, W, 0)
         full = self._full
         rad = p("slope_rad") if self.want_slope_rad else None
-        first = ("d8", c, lambda: L.dt_dev_slope_d8(c.h, dem_ptr, H, W, self.px, None, p("fdr"), None))
+        m4 = self._nodata4.ptr if self._nodata4 is not None else None
+        first = ("d8", c, lambda: L.dt_dev_slope_d8_m(c.h, dem_ptr, H, W, self.px, p("fdr"), m4))
         if self.condition:
             first = ("condition_d8", c, lambda: L.dt_dev_condition_d8_async(c.h, dem_ptr, H, W, self.px, p("filled"),
                                                                              p("fdr"), self.condition_rounds))
@@ -219,8 +224,11 @@ class Chain:
              if self.long_walks is True else
              (lambda: self._queue_downslope(side, dem_ptr)) if self.long_walks == "auto" else
              (lambda: L.dt_dev_downslope(side.h, dem_ptr, p("fdr"), H, W, self.px, self.dz, 0, p("down")))),
-            ("flowacc_flowhand_local", c, lambda: L.dt_dev_flowacc_river_flowhand_local(
-                c.h, p("fdr"), dem_ptr, H, W, self.river_threshold, p("fac"), p("river"))),
+            ("flowacc_flowhand_local", c,
+             (lambda: L.dt_dev_flowacc_river_flowhand_local_m(c.h, p("fdr"), dem_ptr, m4, H, W, self.river_threshold,
+                                                              p("fac"), p("river"))) if m4 is not None else
+             (lambda: L.dt_dev_flowacc_river_flowhand_local(c.h, p("fdr"), dem_ptr, H, W, self.river_threshold,
+                                                            p("fac"), p("river")))),
             ("slope_twi", side, lambda: L.dt_dev_slope_twi(side.h, dem_ptr, p("fac"), H, W, self.px, self.n_top,
                                                            p("slope"), rad, p("ti"), p("mti"))),
             ("flowhand_gfi_finish", c, lambda: L.dt_dev_flowhand_gfi_finish_w(
@@ -286,7 +294,7 @@ class Chain:
             if hasattr(b, "free"):
                 b.free()
         self.buf = {}
-        for name in ("_lift", "_lift_q", "_lift_tables"):
+        for name in ("_lift", "_lift_q", "_lift_tables", "_nodata4"):
             if getattr(self, name) is not None:
                 getattr(self, name).free()
                 setattr(self, name, None)

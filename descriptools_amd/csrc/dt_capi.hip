@@ -995,8 +995,8 @@ extern "C" int dt_dev_flowacc_finish_flowhand_local_w_a64(dt_ctx *c, const dt_wi
 
 // single raster: flow accumulation (all phases), river mask and HAND's phase 1; dt_dev_flowhand_finish_w /
 // dt_dev_flowhand_gfi_finish_w with the whole raster as the window follow
-extern "C" int dt_dev_flowacc_river_flowhand_local(dt_ctx *c, const uint8_t *fdr, const float *dem, int64_t H, int64_t W,
-                                                   int64_t threshold, int32_t *acc32, int8_t *river) {
+static int dev_flowacc_river_flowhand_local(dt_ctx *c, const uint8_t *fdr, const float *dem, const uint8_t *nod4,
+                                           int64_t H, int64_t W, int64_t threshold, int32_t *acc32, int8_t *river) {
   DT_CTX(c);
   DT_TRY(dt_check_hw(H, W));
   DT_REQUIRE((fdr && acc32 && river) || H * W == 0, "NULL raster");
@@ -1007,13 +1007,41 @@ extern "C" int dt_dev_flowacc_river_flowhand_local(dt_ctx *c, const uint8_t *fdr
   DtWin w = dt_full_window(H, W);
   DT_TRY(dt_launch_fa_local(c->stream, w, fdr, scr, need, acc32, 0));
   DT_TRY(dt_launch_fa_finish_fh_local(c->stream, w, fdr, dem, scr, scr2, need2, nullptr, threshold, acc32, 0, river,
-                                      c->status));
+                                      c->status, nod4, dt_nodata4_ld(W)));
   DT_HIP(hipGetLastError());
   c->scratch_owner = 2;
   c->owner_h = H;
   c->owner_w = W;
   c->owner_ptr = (char *)scr2;
   c->owner_ptr2 = nullptr;
+  return DT_OK;
+}
+extern "C" int dt_dev_flowacc_river_flowhand_local(dt_ctx *c, const uint8_t *fdr, const float *dem, int64_t H, int64_t W,
+                                                   int64_t threshold, int32_t *acc32, int8_t *river) {
+  return dev_flowacc_river_flowhand_local(c, fdr, dem, nullptr, H, W, threshold, acc32, river);
+}
+// ... with the nodata mask the D8 kernel wrote (dt_dev_slope_d8_m): the pass reads 0.25 instead of 4 bytes per cell to
+// learn which cells are nodata.  `dem` is still required (it serves the raster shapes the fused kernel does not take).
+extern "C" int dt_dev_flowacc_river_flowhand_local_m(dt_ctx *c, const uint8_t *fdr, const float *dem,
+                                                     const uint8_t *nodata4, int64_t H, int64_t W, int64_t threshold,
+                                                     int32_t *acc32, int8_t *river) {
+  DT_REQUIRE((dem && nodata4) || H * W == 0, "dem and the nodata mask are both required");
+  return dev_flowacc_river_flowhand_local(c, fdr, dem, nodata4, H, W, threshold, acc32, river);
+}
+extern "C" int64_t dt_nodata_mask_bytes(int64_t H, int64_t W) {
+  return (H < 0 || W < 0) ? -1 : (int64_t)dt_nodata4_bytes(H, W);
+}
+// D8 codes (the hot / cold kernel pair) and, on the way, the nodata mask: one byte per four cells of a row (bit k =
+// cell 4 i + k holds the sentinel, z <= -100), rows of dt_nodata_mask_bytes(1, W) bytes
+extern "C" int dt_dev_slope_d8_m(dt_ctx *c, const float *dem, int64_t H, int64_t W, double px, uint8_t *fdr,
+                                 uint8_t *nodata4) {
+  DT_CTX(c);
+  DT_TRY(dt_check_hw(H, W));
+  DT_REQUIRE((dem && fdr && nodata4) || H * W == 0, "NULL raster");
+  DT_TRY(dt_side_reserve(c, &c->aux, &c->aux_bytes, dt_stencil_aux_bytes(H, W)));
+  DT_TRY(dt_launch_stencil(c->stream, dt_full_window(H, W), dem, px, nullptr, fdr, nullptr, nullptr, 0, 0.0, nullptr,
+                           nullptr, c->aux, nodata4, dt_nodata4_ld(W)));
+  DT_HIP(hipGetLastError());
   return DT_OK;
 }
 extern "C" int dt_dev_flowacc_finish_w(dt_ctx *c, const dt_window *win, const uint8_t *fdr, const float *dem,

@@ -6,7 +6,10 @@ int dt_launch_synth_dem(hipStream_t s, uint32_t seed, int O, int64_t Hg, int64_t
                         int64_t h, int64_t w, int nodata_pct, float *out);
 int dt_launch_stencil(hipStream_t s, const DtWin &w, const float *dem, double px, float *slope,
                       uint8_t *fdr, float *slope_rad, const void *acc, int acc64, double n_top, float *ti,
-                      float *mti, void *aux = nullptr);
+                      float *mti, void *aux = nullptr, uint8_t *nod4 = nullptr, int ldm = 0);
+// the nodata mask of the D8-only kernel: one byte per four cells of a row (bit k = cell 4 i + k is nodata), rows ldm bytes
+static inline int dt_nodata4_ld(int64_t W) { return (int)((((W + 3) / 4) + 15) & ~(int64_t)15); }
+static inline size_t dt_nodata4_bytes(int64_t H, int64_t W) { return (size_t)H * (size_t)dt_nodata4_ld(W); }
 // workspace (tile marks + lane masks) of the fused slope + TI + MTI launch; see dt_stencil.hip
 size_t dt_stencil_aux_bytes(int64_t H, int64_t W);
 int dt_launch_flowacc(hipStream_t s, const uint8_t *fdr, const float *dem, int64_t H, int64_t W,
@@ -65,9 +68,11 @@ int dt_launch_fa_finish(hipStream_t s, const DtWin &w, const uint8_t *fdr, const
                         const unsigned long long *ext_perim, int64_t river_thr, void *acc, int acc64,
                         int8_t *river, int *status = nullptr);
 size_t dt_flowhand_tiled_scratch(int64_t H, int64_t W);
+// nod4 (optional): the D8 kernel's nodata mask; when the fused kernel runs it replaces the read of `dem`
 int dt_launch_fa_finish_fh_local(hipStream_t s, const DtWin &w, const uint8_t *fdr, const float *dem, void *fa_scratch,
                                  void *fh_scratch, size_t fh_bytes, const unsigned long long *ext_perim,
-                                 int64_t river_thr, void *acc, int acc64, int8_t *river, int *status);
+                                 int64_t river_thr, void *acc, int acc64, int8_t *river, int *status,
+                                 const uint8_t *nod4 = nullptr, int ldm = 0);
 int dt_launch_fh_local(hipStream_t s, const DtWin &w, const uint8_t *fdr, const int8_t *river, void *scratch,
                        size_t scratch_bytes);
 int dt_launch_fh_summary(hipStream_t s, const DtWin &w, void *scratch, const float *dem, const void *acc, int acc64,

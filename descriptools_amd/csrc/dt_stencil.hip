@@ -646,10 +646,14 @@ __device__ __forceinline__ bool sd_d8_fast(float c, float nw, float n, float ne,
   return hi != 0.0f && (fabsf(cb - t) <= hi * 4.76837158e-7f || !(hi < 3.0e38f) || hi < 1.0e-30f);
 }
 
+// nod4 (may be NULL): one byte per four cells of a row, bit k = cell 4 i + k holds the nodata sentinel (z <= -100; a
+// NaN height is not nodata, as in `dem <= -100`) -- what the flow-accumulation pass needs of the DEM (-100 on nodata
+// cells), so that it reads 0.25 instead of 4 bytes per cell (dt_dev_slope_d8_m / dt_dev_flowacc_river_flowhand_local_m).
+// Row stride ldm bytes.  Only for a single raster (window origin on the 4-cell grid).
 template <bool NT>
 __global__ __launch_bounds__(256, 8) void k_d8(const float *__restrict__ dem, DtWin w, uint8_t *__restrict__ fdr,
                                               int tiles_x, int tiles_y, int vec_ok, uint8_t *__restrict__ tile_mark,
-                                              uint16_t *__restrict__ lane_mask) {
+                                              uint16_t *__restrict__ lane_mask, uint8_t *__restrict__ nod4, int ldm) {
   __shared__ __attribute__((aligned(16))) float t[(SD_TY + 2) * SD_LDW];
   const int tile = sd_tile_of_block(blockIdx.x, tiles_x * tiles_y);
   const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
@@ -684,11 +688,12 @@ __global__ __launch_bounds__(256, 8) void k_d8(const float *__restrict__ dem, Dt
   for (int j = 0; j < 4; j++) {
     const int gy = y0 + ry + j;
     load_row(ry + 2 + j, cc);
-    uint32_t codes = 0;
+    uint32_t codes = 0, nodbits = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const float c = bb[k + 1];
       const bool nod = !(c < pinf) || c <= DT_NODATA;  // staged nodata (+inf), NaN, or below the sentinel: code 0
+      nodbits |= ((c == pinf || c <= DT_NODATA) ? 1u : 0u) << k;  // the sentinel itself (staged as +inf) or below it
       uint32_t code;
       bool flag = sd_d8_fast(c, a[k], a[k + 1], a[k + 2], bb[k], bb[k + 2], cc[k], cc[k + 1], cc[k + 2], code);
       if (on_border) {
@@ -702,6 +707,7 @@ __global__ __launch_bounds__(256, 8) void k_d8(const float *__restrict__ dem, Dt
     }
     if (gy < H) {
       const long long o = (long long)gy * w.ld + gx;
+      if (nod4 && gx < W) nod4[(long long)gy * ldm + (gx >> 2)] = (uint8_t)nodbits;
       if (full) {
         if (NT) __builtin_nontemporal_store(codes, reinterpret_cast<uint32_t *>(fdr + o));
         else *reinterpret_cast<uint32_t *>(fdr + o) = codes;
@@ -836,7 +842,7 @@ static int launch_slope_twi(hipStream_t s, const DtWin &w, const float *dem, dou
 // `acc` (fused TI / MTI only): int32_t* raster, or int64_t* with acc64 != 0
 int dt_launch_stencil(hipStream_t s, const DtWin &w, const float *dem, double px, float *slope,
                       uint8_t *fdr, float *slope_rad, const void *acc, int acc64, double n_top, float *ti,
-                      float *mti, void *aux) {
+                      float *mti, void *aux, uint8_t *nod4, int ldm) {
   const int64_t H = w.H, W = w.W;
   if (H == 0 || W == 0) return DT_OK;
   int tiles_x = (int)((W + SD_TX - 1) / SD_TX), tiles_y = (int)((H + SD_TY - 1) / SD_TY);
@@ -849,6 +855,8 @@ int dt_launch_stencil(hipStream_t s, const DtWin &w, const float *dem, double px
                (!acc || ((uintptr_t)acc & 15) == 0);
   dim3 g((unsigned)ntiles), b(256);
   bool ws = slope != nullptr, wf = fdr != nullptr, wr = slope_rad != nullptr, wt = ti != nullptr;
+  DT_REQUIRE(!nod4 || (wf && aux && !ws && !wr && !wt),
+             "the nodata mask comes from the D8-only kernel (fdr and a workspace, no other output)");
 #define DT_GO(S, F, R) \
   hipLaunchKernelGGL((k_stencil<S, F, R>), g, b, 0, s, dem, w, px, slope, fdr, slope_rad, tiles_x, tiles_y, vec_ok)
   if (wt) {
@@ -875,7 +883,7 @@ int dt_launch_stencil(hipStream_t s, const DtWin &w, const float *dem, double px
   else if (wf && aux) {  // D8 alone with a workspace: the hot / cold pair
     uint8_t *mark = (uint8_t *)aux;
     uint16_t *lmask = (uint16_t *)((char *)aux + dt_align256((size_t)ntiles));
-    hipLaunchKernelGGL(k_d8<false>, g, b, 0, s, dem, w, fdr, tiles_x, tiles_y, vec_ok, mark, lmask);
+    hipLaunchKernelGGL(k_d8<false>, g, b, 0, s, dem, w, fdr, tiles_x, tiles_y, vec_ok, mark, lmask, nod4, ldm);
     unsigned fix_blocks = SD_FIX_SPLIT * (unsigned)((ntiles + 255) / 256 < 1024 ? (ntiles + 255) / 256 : 1024);
     hipLaunchKernelGGL(k_d8_fix, dim3(fix_blocks), b, 0, s, dem, w, px, fdr, tiles_x, tiles_y, vec_ok, mark, lmask);
   } else if (wf) DT_GO(false, true, false);

@@ -1266,9 +1266,11 @@ __global__ __launch_bounds__(256, 6) void k_fh_tile1n(const uint8_t *__restrict_
 // The common form only: int32 accumulation, tiles of whole 64-cell rows on 16-byte aligned rasters (the launcher
 // falls back to the two separate kernels otherwise).  The accumulation half is k_fa_tile3's vector path, the HAND
 // half fh_tile1n_body; they run one after the other in the same 25.5 KiB of LDS.
-template <bool HAS_DEM>
+// ND: where "this cell is nodata" (accumulation -100) comes from -- 0 nowhere, 1 the DEM (4 B/cell read for one bit),
+// 2 the D8 kernel's mask (one byte per four cells, row stride ldm: round 4, the chain's form)
+template <int ND>
 __global__ __launch_bounds__(256, 6) void k_fa3fh1(const uint8_t *__restrict__ fdr, const float *__restrict__ dem,
-                                                  DtWin w, int tiles_x,
+                                                  const uint8_t *__restrict__ nod4, int ldm, DtWin w, int tiles_x,
                                                   const unsigned long long *__restrict__ ext,
                                                   const uint16_t *__restrict__ loc16, int32_t *__restrict__ acc32,
                                                   int32_t river_thr, int8_t *__restrict__ river,
@@ -1299,7 +1301,12 @@ __global__ __launch_bounds__(256, 6) void k_fa3fh1(const uint8_t *__restrict__ f
     int y = y0 + c / TW;
     l4[u] = *reinterpret_cast<const uint2 *>(loc16 + (size_t)tile * NT + c);
     z4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (HAS_DEM && y < w.H) z4[u] = *reinterpret_cast<const float4 *>(dem + (long long)y * w.ld + x0 + c % TW);
+    if (ND == 1 && y < w.H) z4[u] = *reinterpret_cast<const float4 *>(dem + (long long)y * w.ld + x0 + c % TW);
+    if (ND == 2 && y < w.H) {  // the four cells' bits, turned into the sentinel where set: finish() tests z <= -100
+      const uint32_t m = nod4[(long long)y * ldm + ((x0 + c % TW) >> 2)];
+      z4[u] = make_float4((m & 1u) ? DT_NODATA : 0.f, (m & 2u) ? DT_NODATA : 0.f, (m & 4u) ? DT_NODATA : 0.f,
+                          (m & 8u) ? DT_NODATA : 0.f);
+    }
   }
   if (threadIdx.x == 0) s_ovf = 0;
   if (__syncthreads_or(!(e & FA_CYCLE) && FA_VALUE(e) >= (1ull << 22))) {  // see k_fa_tile3
@@ -1353,7 +1360,7 @@ __global__ __launch_bounds__(256, 6) void k_fa3fh1(const uint8_t *__restrict__ f
     int32_t v = l16 == 0xFFFFu ? -100 : (int32_t)l16;
     if (v != -100) v += (int32_t)(d & 0x7FFFFFFFu);
     if (d & 0x80000000u) v = -100;
-    if (HAS_DEM && z <= DT_NODATA) v = -100;
+    if (ND != 0 && z <= DT_NODATA) v = -100;
     return v;
   };
   uint32_t riv4[VPT];  // the river mask of the lane's 4 x 4 cells, one byte per cell
@@ -1843,7 +1850,8 @@ int dt_launch_fh_local(hipStream_t s, const DtWin &w, const uint8_t *fdr, const 
 // (k_fa3fh1); otherwise they run one after the other.  Same results either way.
 int dt_launch_fa_finish_fh_local(hipStream_t s, const DtWin &w, const uint8_t *fdr, const float *dem, void *fa_scratch,
                                  void *fh_scratch, size_t fh_bytes, const unsigned long long *ext_perim,
-                                 int64_t river_thr, void *acc, int acc64, int8_t *river, int *status) {
+                                 int64_t river_thr, void *acc, int acc64, int8_t *river, int *status,
+                                 const uint8_t *nod4, int ldm) {
   if (w.H == 0 || w.W == 0) return DT_OK;
   DT_REQUIRE(fh_bytes >= dt_flowhand_tiled_scratch(w.H, w.W), "scratch too small");
   DT_REQUIRE(river != nullptr, "HAND needs the river mask");
@@ -1861,12 +1869,17 @@ int dt_launch_fa_finish_fh_local(hipStream_t s, const DtWin &w, const uint8_t *f
                      (((uintptr_t)acc | (uintptr_t)dem) & 15) == 0 && ((uintptr_t)river & 3) == 0;
   if (fused) {
     int32_t thr = river_thr > 2147483647ll ? 2147483647 : (river_thr < -2147483647ll ? -2147483647 : (int32_t)river_thr);
-    if (dem)
-      hipLaunchKernelGGL(k_fa3fh1<true>, gt, b, 0, s, fdr, dem, w, f.tiles_x, f.ext, f.loc16, (int32_t *)acc, thr, river,
-                         status, (uint32_t)h.nnodes, h.nodes, h.cache, h.cache_wide);
+    // the single raster's window starts on the mask's 4-cell grid; a rank's window need not: the DEM there
+    const bool use_mask = nod4 != nullptr && w.halo == 0 && w.gx0 == 0 && w.gy0 == 0;
+    if (use_mask)
+      hipLaunchKernelGGL(k_fa3fh1<2>, gt, b, 0, s, fdr, dem, nod4, ldm, w, f.tiles_x, f.ext, f.loc16, (int32_t *)acc, thr,
+                         river, status, (uint32_t)h.nnodes, h.nodes, h.cache, h.cache_wide);
+    else if (dem)
+      hipLaunchKernelGGL(k_fa3fh1<1>, gt, b, 0, s, fdr, dem, nod4, ldm, w, f.tiles_x, f.ext, f.loc16, (int32_t *)acc, thr,
+                         river, status, (uint32_t)h.nnodes, h.nodes, h.cache, h.cache_wide);
     else
-      hipLaunchKernelGGL(k_fa3fh1<false>, gt, b, 0, s, fdr, dem, w, f.tiles_x, f.ext, f.loc16, (int32_t *)acc, thr, river,
-                         status, (uint32_t)h.nnodes, h.nodes, h.cache, h.cache_wide);
+      hipLaunchKernelGGL(k_fa3fh1<0>, gt, b, 0, s, fdr, dem, nod4, ldm, w, f.tiles_x, f.ext, f.loc16, (int32_t *)acc, thr,
+                         river, status, (uint32_t)h.nnodes, h.nodes, h.cache, h.cache_wide);
   } else {
     if (acc64) {
       fa_launch_tile3<long long>(s, gt, w, fdr, dem, f, (long long *)acc, (long long)river_thr, river, status);

@@ -474,3 +474,47 @@ def test_slope_twi_cold_path_equals_hot_path(dt):
         for got in (a, b):
             assert_float_close(got["ti"], ti_o, rtol=1e-5, what="ti")
             assert_float_close(got["mti"], mti_o, rtol=1e-5, atol=1e-6, what="mti")
+
+
+def test_d8_nodata_mask_and_the_flow_pass_that_reads_it():
+    """round 4: the D8 kernel writes one nodata bit per cell on its way (dt_dev_slope_d8_m) and the fused accumulation /
+    HAND pass reads that instead of the DEM (dt_dev_flowacc_river_flowhand_local_m).  The mask must be exactly
+    `dem <= -100`, row by row, for ragged widths too, and the rasters must equal the DEM-reading entry point's."""
+    import ctypes as C
+    from descriptools_amd import _lib
+    from descriptools_amd.device import Context
+    L = _lib.lib()
+    ctx = Context()
+    for H, W, nod in ((192, 256, 4), (130, 201, 3), (64, 64, 0), (257, 515, 6)):
+        dem = oracle.synth_dem(21, 2048, 2048, 100, 300, H, W, nod)
+        dem[5, 7] = -250.0                       # below the sentinel: nodata as well (dem <= -100)
+        d = ctx.to_device(dem)
+        fdr = ctx.empty((H, W), np.uint8)
+        nb = int(L.dt_nodata_mask_bytes(H, W))
+        ld = int(L.dt_nodata_mask_bytes(1, W))
+        assert nb == H * ld and ld >= (W + 3) // 4 and ld % 16 == 0
+        mask = ctx.empty((nb,), np.uint8)
+        _lib.check(L.dt_dev_slope_d8_m(ctx.h, d.ptr, H, W, 10.0, fdr.ptr, mask.ptr))
+        ctx.sync()
+        m = mask.to_host().reshape(H, ld)
+        bits = np.zeros((H, ld * 4), bool)
+        for k in range(4):
+            bits[:, k::4] = (m >> k) & 1
+        assert np.array_equal(bits[:, :W], dem <= -100), (H, W)
+        assert np.array_equal(fdr.to_host(), oracle.slope_d8(dem, 10.0)[1])
+        outs = []
+        for use_mask in (False, True):
+            fac, river = ctx.empty((H, W), np.int32), ctx.empty((H, W), np.int8)
+            if use_mask:
+                _lib.check(L.dt_dev_flowacc_river_flowhand_local_m(ctx.h, fdr.ptr, d.ptr, mask.ptr, H, W, 50, fac.ptr, river.ptr))
+            else:
+                _lib.check(L.dt_dev_flowacc_river_flowhand_local(ctx.h, fdr.ptr, d.ptr, H, W, 50, fac.ptr, river.ptr))
+            ctx.sync()
+            outs.append((fac.to_host(), river.to_host()))
+            fac.free()
+            river.free()
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+        assert np.array_equal(outs[1][0], oracle.flowacc(oracle.slope_d8(dem, 10.0)[1], dem))
+        for b in (d, fdr, mask):
+            b.free()
+    ctx.close()
