@@ -1020,7 +1020,7 @@ extern "C" int dt_dev_flowacc_river_flowhand_local(dt_ctx *c, const uint8_t *fdr
                                                    int64_t threshold, int32_t *acc32, int8_t *river) {
   return dev_flowacc_river_flowhand_local(c, fdr, dem, nullptr, H, W, threshold, acc32, river);
 }
-// ... with the nodata mask the D8 kernel wrote (dt_dev_slope_d8_m): the pass reads 0.25 instead of 4 bytes per cell to
+// ... with the nodata mask the D8 kernel wrote (dt_dev_slope_d8_m): the pass reads 0.125 instead of 4 bytes per cell to
 // learn which cells are nodata.  `dem` is still required (it serves the raster shapes the fused kernel does not take).
 extern "C" int dt_dev_flowacc_river_flowhand_local_m(dt_ctx *c, const uint8_t *fdr, const float *dem,
                                                      const uint8_t *nodata4, int64_t H, int64_t W, int64_t threshold,
@@ -1031,8 +1031,8 @@ extern "C" int dt_dev_flowacc_river_flowhand_local_m(dt_ctx *c, const uint8_t *f
 extern "C" int64_t dt_nodata_mask_bytes(int64_t H, int64_t W) {
   return (H < 0 || W < 0) ? -1 : (int64_t)dt_nodata4_bytes(H, W);
 }
-// D8 codes (the hot / cold kernel pair) and, on the way, the nodata mask: one byte per four cells of a row (bit k =
-// cell 4 i + k holds the sentinel, z <= -100), rows of dt_nodata_mask_bytes(1, W) bytes
+// D8 codes (the hot / cold kernel pair) and, on the way, the nodata mask: one 16-bit word per 4 x 4 patch of cells
+// (bit 4 j + k = cell (4 r + j, 4 i + k) holds the sentinel, z <= -100)
 extern "C" int dt_dev_slope_d8_m(dt_ctx *c, const float *dem, int64_t H, int64_t W, double px, uint8_t *fdr,
                                  uint8_t *nodata4) {
   DT_CTX(c);

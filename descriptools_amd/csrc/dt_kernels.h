@@ -7,9 +7,10 @@ int dt_launch_synth_dem(hipStream_t s, uint32_t seed, int O, int64_t Hg, int64_t
 int dt_launch_stencil(hipStream_t s, const DtWin &w, const float *dem, double px, float *slope,
                       uint8_t *fdr, float *slope_rad, const void *acc, int acc64, double n_top, float *ti,
                       float *mti, void *aux = nullptr, uint8_t *nod4 = nullptr, int ldm = 0);
-// the nodata mask of the D8-only kernel: one byte per four cells of a row (bit k = cell 4 i + k is nodata), rows ldm bytes
-static inline int dt_nodata4_ld(int64_t W) { return (int)((((W + 3) / 4) + 15) & ~(int64_t)15); }
-static inline size_t dt_nodata4_bytes(int64_t H, int64_t W) { return (size_t)H * (size_t)dt_nodata4_ld(W); }
+// the nodata mask of the D8-only kernel: one 16-bit word per 4 x 4 patch of cells (bit 4 j + k = cell (4 r + j, 4 i + k)
+// is nodata), ldm words per row of patches
+static inline int dt_nodata4_ld(int64_t W) { return (int)((((W + 3) / 4) + 7) & ~(int64_t)7); }
+static inline size_t dt_nodata4_bytes(int64_t H, int64_t W) { return (size_t)((H + 3) / 4) * (size_t)dt_nodata4_ld(W) * 2; }
 // workspace (tile marks + lane masks) of the fused slope + TI + MTI launch; see dt_stencil.hip
 size_t dt_stencil_aux_bytes(int64_t H, int64_t W);
 int dt_launch_flowacc(hipStream_t s, const uint8_t *fdr, const float *dem, int64_t H, int64_t W,

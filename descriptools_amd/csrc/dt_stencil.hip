@@ -646,10 +646,12 @@ __device__ __forceinline__ bool sd_d8_fast(float c, float nw, float n, float ne,
   return hi != 0.0f && (fabsf(cb - t) <= hi * 4.76837158e-7f || !(hi < 3.0e38f) || hi < 1.0e-30f);
 }
 
-// nod4 (may be NULL): one byte per four cells of a row, bit k = cell 4 i + k holds the nodata sentinel (z <= -100; a
-// NaN height is not nodata, as in `dem <= -100`) -- what the flow-accumulation pass needs of the DEM (-100 on nodata
-// cells), so that it reads 0.25 instead of 4 bytes per cell (dt_dev_slope_d8_m / dt_dev_flowacc_river_flowhand_local_m).
-// Row stride ldm bytes.  Only for a single raster (window origin on the 4-cell grid).
+// nod4 (may be NULL): the nodata mask, one 16-bit word per 4 x 4 patch of cells -- bit 4 j + k = cell (4 r + j, 4 i + k)
+// holds the nodata sentinel (z <= -100; a non-finite height counts as nodata here, as for the codes) -- what the flow-accumulation
+// pass needs of the DEM (-100 on nodata cells), so that it reads 0.125 instead of 4 bytes per cell (dt_dev_slope_d8_m /
+// dt_dev_flowacc_river_flowhand_local_m).  A patch is what one thread of this kernel owns: ONE store per thread (four
+// byte stores, a row each, cost this issue-bound kernel 12 %).  ldm = words per row of patches.  Only for a single
+// raster (window origin on the 4-cell grid).
 template <bool NT>
 __global__ __launch_bounds__(256, 8) void k_d8(const float *__restrict__ dem, DtWin w, uint8_t *__restrict__ fdr,
                                               int tiles_x, int tiles_y, int vec_ok, uint8_t *__restrict__ tile_mark,
@@ -683,17 +685,17 @@ __global__ __launch_bounds__(256, 8) void k_d8(const float *__restrict__ dem, Dt
   float a[6], bb[6], cc[6];
   load_row(ry, a);
   load_row(ry + 1, bb);
-  uint32_t mask = 0;
+  uint32_t mask = 0, nodmask = 0;
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const int gy = y0 + ry + j;
     load_row(ry + 2 + j, cc);
-    uint32_t codes = 0, nodbits = 0;
+    uint32_t codes = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const float c = bb[k + 1];
       const bool nod = !(c < pinf) || c <= DT_NODATA;  // staged nodata (+inf), NaN, or below the sentinel: code 0
-      nodbits |= ((c == pinf || c <= DT_NODATA) ? 1u : 0u) << k;  // the sentinel itself (staged as +inf) or below it
+      nodmask |= (nod ? 1u : 0u) << (4 * j + k);
       uint32_t code;
       bool flag = sd_d8_fast(c, a[k], a[k + 1], a[k + 2], bb[k], bb[k + 2], cc[k], cc[k + 1], cc[k + 2], code);
       if (on_border) {
@@ -707,7 +709,6 @@ __global__ __launch_bounds__(256, 8) void k_d8(const float *__restrict__ dem, Dt
     }
     if (gy < H) {
       const long long o = (long long)gy * w.ld + gx;
-      if (nod4 && gx < W) nod4[(long long)gy * ldm + (gx >> 2)] = (uint8_t)nodbits;
       if (full) {
         if (NT) __builtin_nontemporal_store(codes, reinterpret_cast<uint32_t *>(fdr + o));
         else *reinterpret_cast<uint32_t *>(fdr + o) = codes;
@@ -727,6 +728,8 @@ __global__ __launch_bounds__(256, 8) void k_d8(const float *__restrict__ dem, Dt
       bb[q] = cc[q];
     }
   }
+  if (nod4 && gx < W && y0 + ry < H)
+    reinterpret_cast<uint16_t *>(nod4)[(long long)((y0 + ry) >> 2) * ldm + (gx >> 2)] = (uint16_t)nodmask;
   const int any = __syncthreads_or(mask != 0u);
   if (threadIdx.x == 0) tile_mark[tile] = (uint8_t)(any != 0);
   if (any) lane_mask[(size_t)tile * 256 + threadIdx.x] = (uint16_t)mask;

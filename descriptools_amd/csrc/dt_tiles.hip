@@ -1267,7 +1267,7 @@ __global__ __launch_bounds__(256, 6) void k_fh_tile1n(const uint8_t *__restrict_
 // falls back to the two separate kernels otherwise).  The accumulation half is k_fa_tile3's vector path, the HAND
 // half fh_tile1n_body; they run one after the other in the same 25.5 KiB of LDS.
 // ND: where "this cell is nodata" (accumulation -100) comes from -- 0 nowhere, 1 the DEM (4 B/cell read for one bit),
-// 2 the D8 kernel's mask (one byte per four cells, row stride ldm: round 4, the chain's form)
+// 2 the D8 kernel's mask (a 16-bit word per 4 x 4 patch, ldm words per row of patches: round 4, the chain's form)
 template <int ND>
 __global__ __launch_bounds__(256, 6) void k_fa3fh1(const uint8_t *__restrict__ fdr, const float *__restrict__ dem,
                                                   const uint8_t *__restrict__ nod4, int ldm, DtWin w, int tiles_x,
@@ -1303,7 +1303,8 @@ __global__ __launch_bounds__(256, 6) void k_fa3fh1(const uint8_t *__restrict__ f
     z4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ND == 1 && y < w.H) z4[u] = *reinterpret_cast<const float4 *>(dem + (long long)y * w.ld + x0 + c % TW);
     if (ND == 2 && y < w.H) {  // the four cells' bits, turned into the sentinel where set: finish() tests z <= -100
-      const uint32_t m = nod4[(long long)y * ldm + ((x0 + c % TW) >> 2)];
+      const uint32_t m = (uint32_t)reinterpret_cast<const uint16_t *>(nod4)[(long long)(y >> 2) * ldm + ((x0 + c % TW) >> 2)] >>
+                         (4 * (y & 3));
       z4[u] = make_float4((m & 1u) ? DT_NODATA : 0.f, (m & 2u) ? DT_NODATA : 0.f, (m & 4u) ? DT_NODATA : 0.f,
                           (m & 8u) ? DT_NODATA : 0.f);
     }

@@ -252,11 +252,11 @@ int dt_dev_flowacc_river(dt_ctx *ctx, const uint8_t *fdr, const float *dem, int6
 int dt_dev_flowacc_river_flowhand_local(dt_ctx *ctx, const uint8_t *fdr, const float *dem, int64_t H, int64_t W,
                                         int64_t threshold, int32_t *acc32, int8_t *river);
 /* The same with the nodata mask the D8 kernel can write on its way: dt_dev_slope_d8_m = dt_dev_slope_d8 (codes only)
- * that also fills `nodata4` -- one byte per four cells of a row, bit k = cell 4 i + k holds the sentinel (z <= -100),
- * rows of dt_nodata_mask_bytes(1, W) bytes, dt_nodata_mask_bytes(H, W) in all -- and
+ * that also fills `nodata4` -- one 16-bit word per 4 x 4 patch of cells, bit 4 j + k = cell (4 r + j, 4 i + k) holds the
+ * sentinel (z <= -100); dt_nodata_mask_bytes(4, W) bytes per row of patches, dt_nodata_mask_bytes(H, W) in all -- and
  * dt_dev_flowacc_river_flowhand_local_m reads that mask instead of the DEM where it only needs "is this cell nodata"
- * (0.25 instead of 4 bytes per cell; the resident chain's form).  Heights that are NaN or +inf are outside the
- * contract of the mask (the D8 kernel treats them as nodata, `dem <= -100` does not). */
+ * (0.125 instead of 4 bytes per cell; the resident chain's form).  Heights that are NaN or +inf are outside the
+ * contract of the mask (the D8 kernel treats them as nodata -- code 0, mask bit set --, `dem <= -100` does not). */
 int64_t dt_nodata_mask_bytes(int64_t H, int64_t W);
 int dt_dev_slope_d8_m(dt_ctx *ctx, const float *dem, int64_t H, int64_t W, double px, uint8_t *fdr, uint8_t *nodata4);
 int dt_dev_flowacc_river_flowhand_local_m(dt_ctx *ctx, const uint8_t *fdr, const float *dem, const uint8_t *nodata4,

@@ -477,7 +477,8 @@ def test_slope_twi_cold_path_equals_hot_path(dt):
 
 
 def test_d8_nodata_mask_and_the_flow_pass_that_reads_it():
-    """round 4: the D8 kernel writes one nodata bit per cell on its way (dt_dev_slope_d8_m) and the fused accumulation /
+    """round 4: the D8 kernel writes one nodata bit per cell on its way (dt_dev_slope_d8_m; a 16-bit word per 4 x 4
+    patch) and the fused accumulation /
     HAND pass reads that instead of the DEM (dt_dev_flowacc_river_flowhand_local_m).  The mask must be exactly
     `dem <= -100`, row by row, for ragged widths too, and the rasters must equal the DEM-reading entry point's."""
     import ctypes as C
@@ -491,16 +492,17 @@ def test_d8_nodata_mask_and_the_flow_pass_that_reads_it():
         d = ctx.to_device(dem)
         fdr = ctx.empty((H, W), np.uint8)
         nb = int(L.dt_nodata_mask_bytes(H, W))
-        ld = int(L.dt_nodata_mask_bytes(1, W))
-        assert nb == H * ld and ld >= (W + 3) // 4 and ld % 16 == 0
+        ldw = int(L.dt_nodata_mask_bytes(4, W)) // 2          # 16-bit words per row of 4 x 4 patches
+        assert nb == ((H + 3) // 4) * ldw * 2 and ldw >= (W + 3) // 4
         mask = ctx.empty((nb,), np.uint8)
         _lib.check(L.dt_dev_slope_d8_m(ctx.h, d.ptr, H, W, 10.0, fdr.ptr, mask.ptr))
         ctx.sync()
-        m = mask.to_host().reshape(H, ld)
-        bits = np.zeros((H, ld * 4), bool)
-        for k in range(4):
-            bits[:, k::4] = (m >> k) & 1
-        assert np.array_equal(bits[:, :W], dem <= -100), (H, W)
+        m = mask.to_host().view(np.uint16).reshape((H + 3) // 4, ldw)
+        bits = np.zeros((4 * m.shape[0], 4 * ldw), bool)
+        for j in range(4):
+            for k in range(4):
+                bits[j::4, k::4] = (m >> (4 * j + k)) & 1
+        assert np.array_equal(bits[:H, :W], dem <= -100), (H, W)
         assert np.array_equal(fdr.to_host(), oracle.slope_d8(dem, 10.0)[1])
         outs = []
         for use_mask in (False, True):
