@@ -126,6 +126,31 @@ def test_long_walks_with_the_skip_table(env):
     torch.cuda.empty_cache()
 
 
+def test_walks_that_end_with_a_drop_of_exactly_zero(env):
+    """flats that drain into nodata, off the raster's edge or onto a non-D8 code: the walk fails with a drop of exactly
+    zero and the reference stores 0 / distance = 0.  (Until round 4 the count form's rounding test sent every such
+    walk to the move-by-move form -- correct, and 6 of the 6.6 ms of the long-walk kernel on the tiled Example; the
+    exemption is ds_quotient's.)  Short walks (window kernel) and long ones (queue + skip tables), integer metres like
+    the Example and a height of -0.0, against the oracle's literal walk."""
+    oracle, downslope, L = env
+    rng = np.random.default_rng(5)
+    H, W = 330, 1400
+    dem = np.full((H, W), 37.0, np.float32)
+    fdr = np.full((H, W), 1, np.uint8)             # east, row by row: walks of 1 .. 1399 moves, all on one height
+    fdr[::3, :] = 16                               # every third row west (off the raster's edge at column 0)
+    dem[:, 900] = -100                             # a nodata column ahead of the walks from both sides
+    fdr[100:130, 400] = 7                          # a non-D8 code: walks spin there (failed, drop 0)
+    dem[200:260, :] = np.float32(-0.0)             # 0 - (-0) and (-0) - 0: the sign of the zero is the reference's
+    dem[230:260, 300:600] = np.float32(0.0)
+    dem[rng.random((H, W)) < 0.0003] = -100
+    dem[300:, :] = np.floor(rng.random((H - 300, W)) * 3).astype(np.float32) + 50   # and a strip that does drop
+    for dz in (5.0, 0.5):
+        got, want = downslope.downsloper(dem, fdr, 12.5, dz), oracle.downslope(dem, fdr, 12.5, dz)
+        _same(got, want)
+        assert np.array_equal(np.signbit(got), np.signbit(want))
+    assert (oracle.downslope(dem, fdr, 12.5, 5.0)[:200] == 0).mean() > 0.9
+
+
 def test_chain_with_long_walks_on_the_example():
     """Chain(long_walks=True) on the bundled Example (its GIS D8 raster has the flats): same downslope raster"""
     import os
