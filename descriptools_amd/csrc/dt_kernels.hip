@@ -1069,60 +1069,165 @@ __global__ __launch_bounds__(1024, 8) void k_downslope_win_rq(const float *__res
 // ---- skip table ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float ds_lift_z(float z) { return z != z ? -__builtin_inff() : z; }  // a NaN height ends a walk
 // the 8-move table straight from the rasters, for every cell of the window's memory (core + halo; a single raster: the
-// raster): a lane walks its cell's eight moves itself -- neighbouring cells, cache hits -- instead of three rounds of
-// doubling over one-move entries.  A skip ends (stop flag) where the move-by-move code would have to decide something:
-// a cell without a code in memory (non-D8, or the last ring of a rank's halo), a move off the raster or out of the
-// rank's memory, nodata ahead.
+// raster) instead of three rounds of doubling over one-move entries.  A skip ends (stop flag) where the move-by-move
+// code would have to decide something: a cell without a code in memory (non-D8, or the last ring of a rank's halo), a
+// move off the raster or out of the rank's memory, nodata ahead.
+// One workgroup per 64 x 64 tile, the tile and 8 cells around it staged in LDS (round 4; a lane walked its cell's
+// eight moves on global memory before -- 16 dependent loads that mostly hit the caches, and 2.0 ms for 214 M cells) as
+// one 8-byte entry per cell: the height (a NaN as -inf, what is not in memory as nodata) and a MOVE WORD
+//   bits 0-15  byte offset of the D8 successor's entry from this one (signed)
+//   bits 16-19 1 (a move)        bits 24-27 1 when the move is diagonal
+//   0          no move from here: no code / non-D8 code / successor not in memory / successor nodata / window ring
+// so a move is one 64-bit LDS read and four vector instructions without a branch -- a walk that has stopped adds
+// zeros and re-reads the entry it stands on.  Each lane walks 16 cells, four at a time.  (The first LDS version spent
+// 220 instructions per cell, most of them on bounds tests and D8 decoding in the staging: 1.45 ms, issue-bound.  The
+// move words now come from a 256-entry table by code, and a tile whose window lies inside the memory stages without
+// tests.)
+#define LT_M 8
+#define LT_WIN (64 + 2 * LT_M)
+#define LT_LD (LT_WIN + 1)
 template <bool RANKED>
 __global__ __launch_bounds__(256) void k_ds_lift_init(const float *__restrict__ dem, const uint8_t *__restrict__ fdr,
-                                                     DtWin w, uint2 *__restrict__ T, const uint32_t *__restrict__ qcount, uint32_t lift_min) {
+                                                     DtWin w, uint2 *__restrict__ T, const uint32_t *__restrict__ qcount,
+                                                     uint32_t lift_min, int tiles_x) {
   if (*qcount < lift_min) return;
-  const int x0 = (int)(blockIdx.x * 256u + threadIdx.x) - w.halo;
-  if (x0 >= w.W + w.halo) return;
-  auto has_code = [&](int yy, int xx) { return RANKED ? dt_has_code(w, yy, xx) : dt_readable(w, yy, xx); };
-  for (int y0 = (int)blockIdx.y - w.halo; y0 < w.H + w.halo; y0 += (int)gridDim.y) {  // a row per workgroup row: no division per cell
-    int y = y0, x = x0;
-    float minz = __builtin_inff();
-    uint32_t len = 0, nd = 0, stop = 0;
-    uint32_t code = has_code(y, x) ? (uint32_t)fdr[(long long)y * w.ld + x] : 0u;
-#pragma unroll 1
-    for (int k = 0; k < 8; k++) {
-      if (!dt_d8_valid(code)) { stop = DS_LIFT_STOP; break; }
+  __shared__ uint2 s_c[LT_WIN * LT_LD];
+  __shared__ uint32_t s_tab[256];
+  {  // move word by D8 code
+    const uint32_t code = threadIdx.x;
+    uint32_t m = 0u;
+    if (dt_d8_valid(code)) {
       int dy, dx;
       dt_d8_delta(code, dy, dx);
-      const int ny = y + dy, nx = x + dx;
-      if (!dt_readable(w, ny, nx)) { stop = DS_LIFT_STOP; break; }
-      const long long on = (long long)ny * w.ld + nx;
-      const float zt = dem[on];
-      code = has_code(ny, nx) ? (uint32_t)fdr[on] : 0u;
-      if (zt == DT_NODATA) { stop = DS_LIFT_STOP; break; }
-      y = ny;
-      x = nx;
-      len++;
-      nd += (dy != 0 && dx != 0) ? 1u : 0u;
-      minz = fminf(minz, ds_lift_z(zt));
+      m = ((uint32_t)((dy * LT_LD + dx) * 8) & 0xFFFFu) | (1u << 16) | ((dy != 0 && dx != 0) ? (1u << 24) : 0u);
     }
-    T[ds_mem_index(w, y0, x0)] = make_uint2(ds_lift_pack(y - y0, x - x0, len, nd) | stop, __float_as_uint(minz));
+    s_tab[code] = m;
+  }
+  const int ty = (int)blockIdx.x / tiles_x, tx = (int)blockIdx.x - ty * tiles_x;
+  const int y0 = ty * 64 - w.halo, x0 = tx * 64 - w.halo;  // the tile's first cell (rank coordinates)
+  const int wy0 = y0 - LT_M, wx0 = x0 - LT_M;
+  // (LT_WIN^2 = 25 * 256: every lane stages 25 cells, all loads in flight before the first is used)
+  static_assert(LT_WIN * LT_WIN % 256 == 0, "the staging loops are unrolled");
+  constexpr int LT_CPT = LT_WIN * LT_WIN / 256;
+  float zs[LT_CPT];
+  uint8_t cs[LT_CPT];
+  // the whole window in memory, inside the raster, and (a rank's) clear of the code-less last ring of the halo
+  const int ring = RANKED ? 1 : 0;
+  const bool inside = wy0 >= -w.halo + ring && wy0 + LT_WIN <= w.H + w.halo - ring && wx0 >= -w.halo + ring &&
+                      wx0 + LT_WIN <= w.W + w.halo - ring && w.gy0 + wy0 >= 0 && w.gy0 + wy0 + LT_WIN <= w.Hg &&
+                      w.gx0 + wx0 >= 0 && w.gx0 + wx0 + LT_WIN <= w.Wg;
+  if (inside) {
+    const float *__restrict__ d0 = dem + ((long long)wy0 * w.ld + wx0);
+    const uint8_t *__restrict__ f0 = fdr + ((long long)wy0 * w.ld + wx0);
+    const int ld = (int)w.ld;
+#pragma unroll
+    for (int j = 0; j < LT_CPT; j++) {
+      const int i = (int)threadIdx.x + 256 * j;
+      const int r = i / LT_WIN, c = i - r * LT_WIN;
+      zs[j] = d0[r * ld + c];
+      cs[j] = f0[r * ld + c];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < LT_CPT; j++) {
+      const int i = (int)threadIdx.x + 256 * j;
+      const int r = i / LT_WIN, c = i - r * LT_WIN;
+      const int y = wy0 + r, x = wx0 + c;
+      zs[j] = dt_readable(w, y, x) ? dem[(long long)y * w.ld + x] : DT_NODATA;
+      cs[j] = (RANKED ? dt_has_code(w, y, x) : dt_readable(w, y, x)) ? fdr[(long long)y * w.ld + x] : (uint8_t)0;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < LT_CPT; j++) {
+    const int i = (int)threadIdx.x + 256 * j;
+    const int r = i / LT_WIN, c = i - r * LT_WIN;
+    s_c[r * LT_LD + c].x = __float_as_uint(ds_lift_z(zs[j]));
+  }
+  __syncthreads();
+  const char *__restrict__ base = (const char *)s_c;
+#pragma unroll
+  for (int j = 0; j < LT_CPT; j++) {
+    const int i = (int)threadIdx.x + 256 * j;
+    const int r = i / LT_WIN, c = i - r * LT_WIN;
+    // (no walk of 8 moves from the tile leaves from the window's ring: its successors may lie outside the window)
+    const bool edge = r == 0 || r == LT_WIN - 1 || c == 0 || c == LT_WIN - 1;
+    uint32_t m = edge ? 0u : s_tab[cs[j]];
+    const int q = (r * LT_LD + c) * 8;
+    // (a successor that is not in memory was staged as nodata)
+    if (__uint_as_float(*(const uint32_t *)(base + q + (int)(short)m)) == DT_NODATA) m = 0u;
+    s_c[r * LT_LD + c].y = m;
+  }
+  __syncthreads();
+  const int rows = w.H + w.halo, cols = w.W + w.halo;  // (exclusive ends of the memory, rank coordinates)
+#pragma unroll 1
+  for (int jb = 0; jb < 16; jb += 4) {
+    int p[4], p0[4];
+    uint32_t m[4], acc[4];
+    float mz[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int c = (int)threadIdx.x + 256 * (jb + k);
+      p0[k] = p[k] = (((c >> 6) + LT_M) * LT_LD + (c & 63) + LT_M) * 8;
+      m[k] = (*(const uint2 *)(base + p[k])).y;
+      acc[k] = 0u;
+      mz[k] = __builtin_inff();
+    }
+#pragma unroll
+    for (int step = 0; step < 8; step++) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        p[k] += (int)(short)m[k];
+        acc[k] += m[k] >> 16;
+        const uint2 e = *(const uint2 *)(base + p[k]);
+        mz[k] = fminf(mz[k], __uint_as_float(e.x));
+        m[k] = e.y;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int c = (int)threadIdx.x + 256 * (jb + k);
+      const int y = y0 + (c >> 6), x = x0 + (c & 63);
+      if (y >= rows || x >= cols) continue;
+      const uint32_t len = acc[k] & 0xFFu, nd = acc[k] >> 8;
+      const int dp = (p[k] - p0[k]) / 8;  // dy * LT_LD + dx with |dx| <= 8
+      const int dy = (dp + 8 * LT_LD + LT_LD / 2) / LT_LD - 8, dx = dp - dy * LT_LD;
+      // (a walk that made no move only ever read the cell it stands on: its skip has no lowest height)
+      T[ds_mem_index(w, y, x)] = make_uint2(ds_lift_pack(dy, dx, len, nd) | (len < 8u ? DS_LIFT_STOP : 0u),
+                                            len ? __float_as_uint(mz[k]) : __float_as_uint(__builtin_inff()));
+    }
   }
 }
-// skips of 2 L moves from skips of L; rows x cols cells of row stride ld
-__global__ __launch_bounds__(256) void k_ds_lift_double(const uint2 *__restrict__ A, uint2 *__restrict__ B, int rows,
-                                                       int cols, int ld, const uint32_t *__restrict__ qcount,
-                                                       uint32_t lift_min) {
-  if (*qcount < lift_min) return;
-  const int x = (int)(blockIdx.x * 256u + threadIdx.x);
-  if (x >= cols) return;
-  for (int y = (int)blockIdx.y; y < rows; y += (int)gridDim.y) {
-    const long long i = (long long)y * ld + x;
-    uint2 a = A[i];
+// SPARSE upper levels (round 4).  A walk that passes through a cell ends no later than that cell's OWN walk does
+// wherever the heights do not rise along the way, so skips of 16 .. 64 moves are worth having only at cells whose own
+// walk is long: the queued ones -- 13 % of the valid cells of the tiled Example, where a doubling pass over all 214 M
+// cells took 0.79 ms per level.  The tables stay dense arrays (a lookup is an index), but above the 8-move level only
+// the entries of the QUEUED cells are computed, and a byte per cell (`dom`, cleared by the launcher, set by the first
+// round) says which exist; where there is none a walk uses the 8-move table, which every cell has.  (With the 8-move
+// entries sparse as well a few walks of the Example -- out of a pit and across steep ground, where no cell's own walk
+// is long -- made a thousand single moves and the kernel waited 0.6 ms for them.)
+// skips of up to 2 L moves from skips of L, for the queued cells; a skip whose end has no entry stays as it is.
+// FIRST: from the 8-move table (every cell has an entry); marks the queued cells in `dom`
+template <bool FIRST>
+__global__ __launch_bounds__(256) void k_ds_tab_double(DsQueue queue, const uint2 *__restrict__ A,
+                                                      uint2 *__restrict__ B, uint8_t *__restrict__ dom, int ld,
+                                                      uint32_t lift_min) {
+  if (*queue.count < lift_min) return;
+  const uint32_t total = min(*queue.count, queue.capacity);
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const uint32_t cell = queue.entries[i].x;
+    uint2 a = A[cell];
     if (!(a.x & DS_LIFT_STOP)) {
-      const uint2 b = A[(long long)(y + ds_lift_dy(a.x)) * ld + (x + ds_lift_dx(a.x))];
-      // the four fields add without carries (offsets within +-64 of the start, <= 64 moves): one addition, less the
-      // second entry's two biases; the stop bit is the second entry's
-      a.x += b.x - DS_LIFT_BIAS2;
-      a.y = __float_as_uint(fminf(__uint_as_float(a.y), __uint_as_float(b.y)));
+      const uint32_t t = (uint32_t)((int)cell + ds_lift_dy(a.x) * ld + ds_lift_dx(a.x));
+      if (FIRST || dom[t]) {
+        const uint2 b = A[t];
+        // the four fields add without carries (offsets within +-64 of the start, <= 64 moves): one addition, less the
+        // second entry's two biases; the stop bit is the second entry's
+        a.x += b.x - DS_LIFT_BIAS2;
+        a.y = __float_as_uint(fminf(__uint_as_float(a.y), __uint_as_float(b.y)));
+      }
     }
-    B[i] = a;
+    B[cell] = a;
+    if (FIRST) dom[cell] = (uint8_t)1;
   }
 }
 // the queued walks: skips while no cell of a skip can end the walk, then the moves that remain, one by one
@@ -1130,8 +1235,8 @@ template <bool RANKED>
 __global__ __launch_bounds__(256, 8) void k_ds_finish(const float *__restrict__ dem, const uint8_t *__restrict__ fdr, DtWin w,
                                                   double px, double dz, float dzf, int raw, float *__restrict__ out,
                                                   DsQueue queue, const uint2 *__restrict__ T,
-                                                  const uint2 *__restrict__ T8, int *__restrict__ n_unresolved,
-                                                  uint32_t lift_min, DsWalkOut wo) {
+                                                  const uint2 *__restrict__ T8, const uint8_t *__restrict__ dom,
+                                                  int *__restrict__ n_unresolved, uint32_t lift_min, DsWalkOut wo) {
   const uint32_t total = min(*queue.count, queue.capacity);
   const bool lifted = T != nullptr && *queue.count >= lift_min;
   const double dcard = px, ddiag = px * sqrt(2.0);
@@ -1150,8 +1255,11 @@ __global__ __launch_bounds__(256, 8) void k_ds_finish(const float *__restrict__ 
       for (int level = 0; level < 2; level++) {
         const uint2 *__restrict__ tab = level ? T8 : T;
         for (;;) {
-          const uint2 t = tab[ds_mem_index(w, y, x)];
-          const uint32_t len = ds_lift_len(t.x);
+          const uint32_t at = ds_mem_index(w, y, x);
+          // (the long skips exist for the queued cells only -- `dom`, fetched with the entry; the 8-move table is dense)
+          const uint32_t have = level ? 1u : (uint32_t)dom[at];
+          const uint2 t = tab[at];
+          const uint32_t len = have ? ds_lift_len(t.x) : 0u;
           // every cell of the skip leaves the drop below dz (the lowest one does), and the cap is beyond it
           if (len == 0u || !(z0 - __uint_as_float(t.y) < dzf) || loop + len > 4999u) break;
           y += ds_lift_dy(t.x);
@@ -1180,7 +1288,8 @@ __global__ __launch_bounds__(256, 8) void k_ds_finish(const float *__restrict__ 
 __global__ __launch_bounds__(256) void k_ds_walk(const float *__restrict__ dem, const uint8_t *__restrict__ fdr, DtWin w,
                                                 double px, double dz, float dzf, int64_t n, uint4 *__restrict__ rec,
                                                 const uint2 *__restrict__ T, const uint2 *__restrict__ T8,
-                                                const uint32_t *__restrict__ qcount, uint32_t lift_min) {
+                                                const uint8_t *__restrict__ dom, const uint32_t *__restrict__ qcount,
+                                                uint32_t lift_min) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   uint4 r0 = rec[3 * i], r1 = rec[3 * i + 1];
@@ -1198,8 +1307,10 @@ __global__ __launch_bounds__(256) void k_ds_walk(const float *__restrict__ dem, 
       for (int level = 0; level < 2; level++) {
         const uint2 *__restrict__ tab = level ? T8 : T;
         for (;;) {
-          const uint2 t = tab[ds_mem_index(w, y, x)];
-          const uint32_t len = ds_lift_len(t.x);
+          const uint32_t at = ds_mem_index(w, y, x);
+          const uint32_t have = level ? 1u : (uint32_t)dom[at];
+          const uint2 t = tab[at];
+          const uint32_t len = have ? ds_lift_len(t.x) : 0u;
           if (len == 0u || !(z0 - __uint_as_float(t.y) < dzf) || loop + len > 4999u) break;
           y += ds_lift_dy(t.x);
           x += ds_lift_dx(t.x);
@@ -1291,6 +1402,7 @@ int dt_launch_ds_walk(hipStream_t s, const DtWin &w, const float *dem, const uin
   float dzf = (float)dz;
   if ((double)dzf < dz) dzf = nextafterf(dzf, INFINITY);
   const uint2 *T = nullptr, *T8 = nullptr;
+  const uint8_t *dom = nullptr;
   const uint32_t *qc = nullptr;
   if (work) {
     const size_t cells = (size_t)(w.H + 2 * (int64_t)w.halo) * (size_t)w.ld;
@@ -1298,9 +1410,10 @@ int dt_launch_ds_walk(hipStream_t s, const DtWin &w, const float *dem, const uin
     qc = (const uint32_t *)work;
     T = (const uint2 *)t0;
     T8 = (const uint2 *)(t0 + 2 * dt_align256(cells * 8));
+    dom = (const uint8_t *)(t0 + 3 * dt_align256(cells * 8));
   }
   hipLaunchKernelGGL(k_ds_walk, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dem, fdr, w, px, dz, dzf, n, (uint4 *)rec,
-                     T, T8, qc, dt_downslope_lift_min(w.H, w.W));
+                     T, T8, dom, qc, dt_downslope_lift_min(w.H, w.W));
   return DT_OK;
 }
 // start records for cells marked -50 (the fallback when the emission buffer was too small, or a tile without one):
@@ -1326,14 +1439,18 @@ int dt_launch_ds_walk_seed(hipStream_t s, const DtWin &w, const float *dem, int6
 // TABLES (two ping-pong skip tables and the 8-move table that is kept); dt_downslope_lift_bytes = both, back to back
 static size_t ds_queue_capacity(int64_t H, int64_t W) { return (size_t)((H * W + 1) / 2); }
 size_t dt_downslope_queue_bytes(int64_t H, int64_t W) { return 256 + dt_align256(ds_queue_capacity(H, W) * 16); }
-size_t dt_downslope_tables_bytes(int64_t H, int64_t W) { return 3 * dt_align256((size_t)H * W * 8); }
+size_t dt_downslope_tables_bytes(int64_t H, int64_t W) {
+  return 3 * dt_align256((size_t)H * W * 8) + dt_align256((size_t)H * W);  // three tables | which entries exist
+}
 size_t dt_downslope_lift_bytes(int64_t H, int64_t W) {
   return dt_downslope_queue_bytes(H, W) + dt_downslope_tables_bytes(H, W);
 }
 uint32_t dt_downslope_lift_min(int64_t H, int64_t W) { return (uint32_t)std::max<int64_t>(DS_LIFT_MIN, H * W / 256); }
 // ... of a window: the queue holds core cells, the tables cover the window's memory (core + halo, row stride ld)
 static size_t ds_mem_cells(const DtWin &w) { return (size_t)(w.H + 2 * (int64_t)w.halo) * (size_t)w.ld; }
-size_t dt_downslope_tables_bytes_w(const DtWin &w) { return 3 * dt_align256(ds_mem_cells(w) * 8); }
+size_t dt_downslope_tables_bytes_w(const DtWin &w) {
+  return 3 * dt_align256(ds_mem_cells(w) * 8) + dt_align256(ds_mem_cells(w));
+}
 size_t dt_downslope_lift_bytes_w(const DtWin &w) {
   return dt_downslope_queue_bytes(w.H, w.W) + dt_downslope_tables_bytes_w(w);
 }
@@ -1403,26 +1520,30 @@ int dt_launch_downslope(hipStream_t s, const DtWin &w, const float *dem, const u
     const dim3 b(256);
     const uint32_t lift_min = dt_downslope_lift_min(H, W);
     uint2 *src = nullptr;
+    uint8_t *dom = nullptr;
+    const unsigned fin_blocks = (unsigned)std::min<size_t>((q.capacity + 255) / 256, 8192);
     if (tab[0]) {
       // every kernel of the tables returns at once when fewer than lift_min walks were queued
-      // 8 moves per skip (tab[2], kept) -> 16 -> 32 -> 64
+      // 8 moves per skip for every cell (tab[2], kept) -> 16 -> 32 -> 64 for the queued cells (`dom`)
+      dom = (uint8_t *)tab[2] + dt_align256(ds_mem_cells(w) * 8);
+      DT_HIP(hipMemsetAsync(dom, 0, ds_mem_cells(w), s));
       const int rows = (int)(H + 2 * w.halo), cols = (int)(W + 2 * w.halo);
-      const dim3 g2((unsigned)((cols + 255) / 256), (unsigned)std::min(rows, 65535));
+      const int ltx = (cols + 63) / 64, lty = (rows + 63) / 64;
+      const dim3 gt((unsigned)(ltx * lty));
       const uint32_t *qc = (const uint32_t *)q.count;
-      if (ranked) hipLaunchKernelGGL(k_ds_lift_init<true>, g2, b, 0, s, dem, fdr, w, tab[2], qc, lift_min);
-      else hipLaunchKernelGGL(k_ds_lift_init<false>, g2, b, 0, s, dem, fdr, w, tab[2], qc, lift_min);
-      hipLaunchKernelGGL(k_ds_lift_double, g2, b, 0, s, (const uint2 *)tab[2], tab[0], rows, cols, w.ld, qc, lift_min);
-      hipLaunchKernelGGL(k_ds_lift_double, g2, b, 0, s, (const uint2 *)tab[0], tab[1], rows, cols, w.ld, qc, lift_min);
-      hipLaunchKernelGGL(k_ds_lift_double, g2, b, 0, s, (const uint2 *)tab[1], tab[0], rows, cols, w.ld, qc, lift_min);
+      if (ranked) hipLaunchKernelGGL(k_ds_lift_init<true>, gt, b, 0, s, dem, fdr, w, tab[2], qc, lift_min, ltx);
+      else hipLaunchKernelGGL(k_ds_lift_init<false>, gt, b, 0, s, dem, fdr, w, tab[2], qc, lift_min, ltx);
+      hipLaunchKernelGGL(k_ds_tab_double<true>, dim3(fin_blocks), b, 0, s, q, (const uint2 *)tab[2], tab[0], dom, (int)w.ld, lift_min);
+      hipLaunchKernelGGL(k_ds_tab_double<false>, dim3(fin_blocks), b, 0, s, q, (const uint2 *)tab[0], tab[1], dom, (int)w.ld, lift_min);
+      hipLaunchKernelGGL(k_ds_tab_double<false>, dim3(fin_blocks), b, 0, s, q, (const uint2 *)tab[1], tab[0], dom, (int)w.ld, lift_min);
       src = tab[0];
     }
-    const unsigned fin_blocks = (unsigned)std::min<size_t>((q.capacity + 255) / 256, 8192);
     if (ranked)
       hipLaunchKernelGGL(k_ds_finish<true>, dim3(fin_blocks), b, 0, s, dem, fdr, w, px, dz, dzf, raw, out, q,
-                         (const uint2 *)src, (const uint2 *)tab[2], n_unresolved, lift_min, wo);
+                         (const uint2 *)src, (const uint2 *)tab[2], (const uint8_t *)dom, n_unresolved, lift_min, wo);
     else
       hipLaunchKernelGGL(k_ds_finish<false>, dim3(fin_blocks), b, 0, s, dem, fdr, w, px, dz, dzf, raw, out, q,
-                         (const uint2 *)src, (const uint2 *)tab[2], n_unresolved, lift_min, DsWalkOut());
+                         (const uint2 *)src, (const uint2 *)tab[2], (const uint8_t *)dom, n_unresolved, lift_min, DsWalkOut());
   }
   return DT_OK;
 }
