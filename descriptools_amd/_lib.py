@@ -100,6 +100,7 @@ _SIGS = {
     "dt_dev_downslope_lift_w": (ci, [vp, vp, vp, vp, f64, f64, ci, vp, vp, vp, i64]),
     "dt_dev_downslope_emit_w": (ci, [vp, vp, vp, vp, f64, f64, ci, vp, vp, vp, i64, vp, i64]),
     "dt_dev_downslope_walk_w": (ci, [vp, vp, vp, vp, f64, f64, i64, vp, vp, i64]),
+    "dt_dev_downslope_walk_route_w": (ci, [vp, vp, vp, vp, f64, f64, i64, vp, vp, i64, vp, vp, C.c_int32, vp, C.c_int32, vp, vp, vp]),
     "dt_dev_downslope_walk_seed_w": (ci, [vp, vp, vp, i64, vp, vp, vp]),
     "dt_dev_flowacc_local_w": (ci, [vp, vp, vp, vp, vp, vp, vp]),
     "dt_dev_flowacc_finish_w": (ci, [vp, vp, vp, vp, vp, i64, vp, vp]),

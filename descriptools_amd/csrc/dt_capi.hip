@@ -902,6 +902,30 @@ extern "C" int dt_dev_downslope_walk_w(dt_ctx *c, const dt_window *win, const fl
   DT_HIP(hipGetLastError());
   return DT_OK;
 }
+// One iteration of the walkers' journey, prepared on the device (tiling.finish_downslope): the records that arrived
+// finished are home -- their value goes into `out` (this rank's downslope raster, core origin) -- the others advance like
+// dt_dev_downslope_walk_w; then every record that is still wanted somewhere is copied into `send`, grouped by destination
+// rank (a walker that has just finished: the owner of its start cell; the others: the owner of the cell they stand on),
+// and counts[d] = records for rank d, counts[n_ranks] = how many of them are still on their way.  row_starts /
+// col_starts: device arrays of ty + 1 / tx + 1 global rows / columns (the layout's bands and the raster's end);
+// counts: int32[ty * tx + 1]; scratch: int32[n + ty * tx]; send: room for n records.
+extern "C" int dt_dev_downslope_walk_route_w(dt_ctx *c, const dt_window *win, const float *dem, const uint8_t *fdr,
+                                             double px, double dz, int64_t n, void *rec, void *work, int64_t work_bytes,
+                                             float *out, const int32_t *row_starts, int32_t ty,
+                                             const int32_t *col_starts, int32_t tx, void *send, int32_t *counts,
+                                             int32_t *scratch) {
+  DT_CTX(c);
+  DtWin w;
+  DT_TRY(dt_convert_window(win, &w));
+  DT_REQUIRE(n >= 0, "negative count");
+  DT_REQUIRE(ty >= 1 && tx >= 1 && row_starts && col_starts && counts, "layout / counts missing");
+  DT_REQUIRE(n == 0 || (dem && fdr && rec && out && send && scratch), "NULL pointer");
+  DT_REQUIRE(work == nullptr || work_bytes >= (int64_t)dt_downslope_lift_bytes_w(w), "downslope workspace too small");
+  DT_TRY(dt_launch_ds_walk(c->stream, w, dem, fdr, px, dz, n, rec, work, out));
+  DT_TRY(dt_launch_ds_route(c->stream, n, rec, row_starts, ty, col_starts, tx, send, counts, scratch));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
 // records of walkers at their start cells (core coordinates ys / xs of n cells), no move made: for cells that are
 // marked -50 without a record (emission buffer too small, or a tile without one)
 extern "C" int dt_dev_downslope_walk_seed_w(dt_ctx *c, const dt_window *win, const float *dem, int64_t n,

@@ -40,7 +40,9 @@ int dt_launch_downslope(hipStream_t s, const DtWin &w, const float *dem, const u
                         double dz, int raw, float *out, int *n_unresolved, void *qwork = nullptr,
                         void *twork = nullptr, int phase = 0, void *walkers = nullptr, size_t walkers_bytes = 0);
 int dt_launch_ds_walk(hipStream_t s, const DtWin &w, const float *dem, const uint8_t *fdr, double px, double dz,
-                      int64_t n, void *rec, void *work);
+                      int64_t n, void *rec, void *work, float *out = nullptr);
+int dt_launch_ds_route(hipStream_t s, int64_t n, const void *rec, const int32_t *row_starts, int ty,
+                       const int32_t *col_starts, int tx, void *send, int32_t *counts, int32_t *scratch);
 int dt_launch_ds_walk_seed(hipStream_t s, const DtWin &w, const float *dem, int64_t n, const int32_t *ys,
                            const int32_t *xs, void *rec);
 int dt_launch_downslope_v1(hipStream_t s, const float *dem, const uint8_t *fdr, int64_t H, int64_t W,

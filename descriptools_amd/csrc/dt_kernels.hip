@@ -555,6 +555,7 @@ __device__ __forceinline__ uint32_t ds_lift_nd(uint32_t e) { return (e >> 23) & 
 // tiling.finish_downslope sends the records on as device buffers (all-to-all); k_ds_walk advances them.
 #define DSW_SEQ 1u
 #define DSW_DONE 2u
+#define DSW_HOME 4u /* a finished walker whose value has been written at its start cell (k_ds_walk with `out`) */
 #define DSW_WORDS 12 /* 32-bit words per record */
 struct DsWalkOut {
   uint32_t *count;  // records emitted (may exceed capacity: the excess cells are only marked -50, as before)
@@ -1289,11 +1290,23 @@ __global__ __launch_bounds__(256) void k_ds_walk(const float *__restrict__ dem, 
                                                 double px, double dz, float dzf, int64_t n, uint4 *__restrict__ rec,
                                                 const uint2 *__restrict__ T, const uint2 *__restrict__ T8,
                                                 const uint8_t *__restrict__ dom, const uint32_t *__restrict__ qcount,
-                                                uint32_t lift_min) {
+                                                uint32_t lift_min, float *__restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   uint4 r0 = rec[3 * i], r1 = rec[3 * i + 1];
-  if (r1.w & DSW_DONE) return;
+  if (r1.w & DSW_DONE) {
+    // a finished walker is sent to the owner of its start cell: with `out` (the route form) its value is written here
+    // and the record marked DSW_HOME, which drops it from the next exchange
+    if (out && !(r1.w & DSW_HOME)) {
+      const int ys = (int)r0.x - w.gy0, xs = (int)r0.y - w.gx0;
+      if (dt_in_core(w, ys, xs)) {
+        out[(long long)ys * w.ld + xs] = __uint_as_float(rec[3 * i + 2].z);
+        r1.w |= DSW_HOME;
+        rec[3 * i + 1] = r1;
+      }
+    }
+    return;
+  }
   int y = (int)r0.z - w.gy0, x = (int)r0.w - w.gx0;
   if (!dt_has_code(w, y, x)) return;  // not mine: somebody else's walker
   const double dcard = px, ddiag = px * sqrt(2.0);
@@ -1397,7 +1410,7 @@ __global__ __launch_bounds__(256) void k_ds_walk(const float *__restrict__ dem, 
 }
 // work (optional): the rank's long-walk workspace as dt_dev_downslope_lift_w left it (queue | tables)
 int dt_launch_ds_walk(hipStream_t s, const DtWin &w, const float *dem, const uint8_t *fdr, double px, double dz,
-                      int64_t n, void *rec, void *work) {
+                      int64_t n, void *rec, void *work, float *out) {
   if (n <= 0) return DT_OK;
   float dzf = (float)dz;
   if ((double)dzf < dz) dzf = nextafterf(dzf, INFINITY);
@@ -1413,7 +1426,86 @@ int dt_launch_ds_walk(hipStream_t s, const DtWin &w, const float *dem, const uin
     dom = (const uint8_t *)(t0 + 3 * dt_align256(cells * 8));
   }
   hipLaunchKernelGGL(k_ds_walk, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dem, fdr, w, px, dz, dzf, n, (uint4 *)rec,
-                     T, T8, dom, qc, dt_downslope_lift_min(w.H, w.W));
+                     T, T8, dom, qc, dt_downslope_lift_min(w.H, w.W), out);
+  return DT_OK;
+}
+// ---- where the walker records go next (tiling.finish_downslope's exchange, prepared on the device) -------------------
+// The layout of the ranks: row_starts[0 .. ty] / col_starts[0 .. tx] = first global row / column of every rank row /
+// column and the raster's end; rank = rank row * tx + rank column.
+#define DSW_MAX_RANKS 1024
+__device__ __forceinline__ int dsw_band(const int32_t *__restrict__ starts, int n, int v) {
+  int k = 0;
+  for (int j = 1; j < n; j++) k += (v >= starts[j]) ? 1 : 0;  // (a handful of bands: a scan, no search)
+  return k;
+}
+// dest[i] = the rank record i goes to (-1: it stays -- a finished walker that is home, DSW_HOME): the owner of its start
+// cell when it has finished, the owner of the cell it stands on otherwise; counts[d] += records for rank d,
+// counts[n_ranks] += the ones still on their way
+__global__ __launch_bounds__(256) void k_dsw_classify(const uint4 *__restrict__ rec, int64_t n,
+                                                     const int32_t *__restrict__ row_starts, int ty,
+                                                     const int32_t *__restrict__ col_starts, int tx,
+                                                     int32_t *__restrict__ dest, int32_t *__restrict__ counts) {
+  __shared__ int s_cnt[DSW_MAX_RANKS + 1];
+  const int nr = ty * tx;
+  for (int j = threadIdx.x; j <= nr; j += 256) s_cnt[j] = 0;
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const uint4 r0 = rec[3 * i], r1 = rec[3 * i + 1];
+    int d = -1;
+    if (!(r1.w & DSW_HOME)) {
+      const bool done = (r1.w & DSW_DONE) != 0u;
+      const int gy = (int)(done ? r0.x : r0.z), gx = (int)(done ? r0.y : r0.w);
+      d = dsw_band(row_starts, ty, gy) * tx + dsw_band(col_starts, tx, gx);
+      atomicAdd(&s_cnt[d], 1);
+      if (!done) atomicAdd(&s_cnt[nr], 1);
+    }
+    dest[i] = d;
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j <= nr; j += 256)
+    if (s_cnt[j]) atomicAdd(&counts[j], s_cnt[j]);
+}
+// send = the records grouped by destination rank (the order inside a group is whatever the atomics give: records are
+// independent of one another); cursor[d]: zeroed by the launcher
+__global__ __launch_bounds__(256) void k_dsw_scatter(const uint4 *__restrict__ rec, int64_t n,
+                                                    const int32_t *__restrict__ dest,
+                                                    const int32_t *__restrict__ counts, int nr,
+                                                    int32_t *__restrict__ cursor, uint4 *__restrict__ send) {
+  __shared__ int s_cnt[DSW_MAX_RANKS], s_base[DSW_MAX_RANKS];
+  for (int j = threadIdx.x; j < nr; j += 256) s_cnt[j] = 0;
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int d = i < n ? dest[i] : -1;
+  int r = 0;
+  if (d >= 0) r = atomicAdd(&s_cnt[d], 1);
+  __syncthreads();
+  for (int j = threadIdx.x; j < nr; j += 256) {
+    int off = 0;  // first slot of rank j's group
+    for (int k = 0; k < j; k++) off += counts[k];
+    s_base[j] = off + (s_cnt[j] ? atomicAdd(&cursor[j], s_cnt[j]) : 0);
+  }
+  __syncthreads();
+  if (d >= 0) {
+    const int64_t slot = (int64_t)s_base[d] + r;
+    send[3 * slot] = rec[3 * i];
+    send[3 * slot + 1] = rec[3 * i + 1];
+    send[3 * slot + 2] = rec[3 * i + 2];
+  }
+}
+// scratch: int32[n + n_ranks]; counts: int32[n_ranks + 1]
+int dt_launch_ds_route(hipStream_t s, int64_t n, const void *rec, const int32_t *row_starts, int ty,
+                       const int32_t *col_starts, int tx, void *send, int32_t *counts, int32_t *scratch) {
+  const int nr = ty * tx;
+  DT_REQUIRE(nr >= 1 && nr <= DSW_MAX_RANKS, "1 .. 1024 ranks");
+  DT_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)(nr + 1), s));
+  if (n <= 0) return DT_OK;
+  int32_t *dest = scratch, *cursor = scratch + n;
+  DT_HIP(hipMemsetAsync(cursor, 0, sizeof(int32_t) * (size_t)nr, s));
+  const dim3 g((unsigned)((n + 255) / 256)), b(256);
+  hipLaunchKernelGGL(k_dsw_classify, g, b, 0, s, (const uint4 *)rec, n, row_starts, ty, col_starts, tx, dest, counts);
+  hipLaunchKernelGGL(k_dsw_scatter, g, b, 0, s, (const uint4 *)rec, n, (const int32_t *)dest, (const int32_t *)counts, nr,
+                     cursor, (uint4 *)send);
   return DT_OK;
 }
 // start records for cells marked -50 (the fallback when the emission buffer was too small, or a tile without one):

@@ -1050,6 +1050,12 @@ class DistComm:
         self.dist.all_gather_into_tensor(out, v.contiguous(), group=self.group)
         return out.cpu().numpy().reshape(self.size, -1)
 
+    def all_gather_host_ints(self, values):
+        """values: a few host integers -> host numpy [size, k]"""
+        import torch
+        dev = "cpu" if self.cpu else torch.device("cuda", torch.cuda.current_device())
+        return self.all_gather_ints(torch.tensor([int(v) for v in values], dtype=torch.int64, device=dev))
+
     def exchange_rows(self, rows, send_counts, recv_counts):
         """rows: [n, w] int32 device tensor sorted by destination rank; send_counts / recv_counts: rows per peer (host
         ints).  Returns the rows the peers sent here, a device tensor [sum(recv_counts), w]."""
@@ -1071,10 +1077,13 @@ class LocalComm:
     class _Shared:
         def __init__(self, n):
             import threading
-            self.n, self.slots, self.barrier = n, [None] * n, threading.Barrier(n)
+            # two sets of slots, used in turn: every exchange has a barrier, so no thread is more than one exchange
+            # ahead of another, and the slots of exchange k are not written again before exchange k + 2 -- after the
+            # barrier of k + 1, which every reader of k has passed.  One barrier per exchange instead of two.
+            self.n, self.slots, self.barrier = n, [[None] * n, [None] * n], threading.Barrier(n)
 
     def __init__(self, shared, rank):
-        self.sh, self.rank, self.size = shared, rank, shared.n
+        self.sh, self.rank, self.size, self._turn = shared, rank, shared.n, 0
 
     @staticmethod
     def create(n):
@@ -1082,11 +1091,11 @@ class LocalComm:
         return [LocalComm(sh, r) for r in range(n)]
 
     def _swap(self, mine):
-        self.sh.slots[self.rank] = mine
+        slots = self.sh.slots[self._turn]
+        self._turn ^= 1
+        slots[self.rank] = mine
         self.sh.barrier.wait()
-        out = list(self.sh.slots)
-        self.sh.barrier.wait()  # everybody has read before the next exchange overwrites
-        return out
+        return list(slots)
 
     def all_gather(self, value):
         return self._swap(np.asarray(value).copy())
@@ -1094,19 +1103,24 @@ class LocalComm:
     def all_gather_ints(self, vec):
         return np.stack(self._swap(vec.cpu().numpy().astype(np.int64)))
 
+    def all_gather_host_ints(self, values):
+        return np.stack(self._swap(np.asarray([int(v) for v in values], np.int64)))
+
     def exchange_rows(self, rows, send_counts, recv_counts):
         import torch
         offs = np.concatenate([[0], np.cumsum(send_counts)]).astype(np.int64)
-        torch.cuda.current_stream().synchronize()  # the other threads' streams read these rows
-        self.sh.slots[self.rank] = [rows[int(offs[d]):int(offs[d + 1])] for d in range(self.size)]
-        self.sh.barrier.wait()
-        out = torch.cat([self.sh.slots[s][self.rank] for s in range(self.size)])
-        torch.cuda.current_stream().synchronize()  # copied before the senders may let go of their rows
-        self.sh.barrier.wait()
+        st = torch.cuda.current_stream()
+        st.synchronize()  # the other threads' streams read these rows
+        pieces = [s[self.rank] for s in self._swap([rows[int(offs[d]):int(offs[d + 1])] for d in range(self.size)])]
+        out = torch.cat(pieces)
+        # copied before this thread reaches the next barrier: the senders' rows stay referenced by the slots until the
+        # exchange after next overwrites them, and that one starts behind that barrier.  (Not record_stream: the tiles'
+        # streams are destroyed with the tiles, and the allocator would still hold them.)
+        st.synchronize()
         return out
 
 
-def finish_downslope(tile, comm, max_iters=200):
+def finish_downslope(tile, comm, max_iters=200, stats=None):
     """Downslope walks that left a rank's memory (none on the synthetic benchmark terrain, thousands along every border
     on real terrain, whose walks run for kilometres through flats and along valley floors; the reference's analogue is
     the CPU repair downslope.py:373-374).  Every rank calls this after its step.  Such a walk travels on as a WALKER
@@ -1120,12 +1134,16 @@ def finish_downslope(tile, comm, max_iters=200):
     iteration's only synchronisation with the host.  The result is the reference's float32 whatever the route: counts
     give it through the rounding-safety test of the count form, and the rare walk that fails the test starts again
     carrying the reference's own sequential float64 sum.  Returns the number of cells resolved (over all ranks); 0
-    without any exchange of records when no rank had any."""
+    without any exchange of records when no rank had any.  stats (a dict, optional): filled with the number of
+    iterations and this rank's wall-clock seconds per phase."""
+    import time
     tc, L, layout = tile.torch, tile.L, tile.layout
+    t_begin = time.perf_counter()
+    phase = {"setup": 0.0, "kernels": 0.0, "counts": 0.0, "exchange": 0.0}
     n_local = tile.unresolved_downslope()
     i32 = tc.int32
     with tile.on_stream():
-        total = int(comm.all_gather_ints(tc.tensor([n_local], dtype=tc.int64, device=tile.dev)).sum())
+        total = int(np.sum(comm.all_gather_host_ints([n_local])))
     if total == 0:
         return 0
     with tile.on_stream():
@@ -1133,49 +1151,54 @@ def finish_downslope(tile, comm, max_iters=200):
         if tile._walkers is not None:
             emitted = int(tile._walkers[:4].view(i32).item())
             if emitted == n_local and n_local <= (tile._walkers.numel() - 256) // WALKER_BYTES:
-                rec = tile._walkers[256:256 + WALKER_BYTES * n_local].view(i32).reshape(n_local, WALKER_WORDS).clone()
+                # (advanced in place: the buffer is the next step's to overwrite)
+                rec = tile._walkers[256:256 + WALKER_BYTES * n_local].view(i32).reshape(n_local, WALKER_WORDS)
         if rec is None:  # no records (or more walks than the buffer holds): from the -50 marks, at the start cells
             ys, xs = (tile.core("down") == -50.0).nonzero(as_tuple=True)
             ys, xs = ys.to(i32).contiguous(), xs.to(i32).contiguous()
             rec = tc.empty((int(ys.numel()), WALKER_WORDS), dtype=i32, device=tile.dev)
             tile._chk(L.dt_dev_downslope_walk_seed_w(tile.ctx.h, C.byref(tile.win), tile.p("dem"), int(ys.numel()),
                                                      ys.data_ptr(), xs.data_ptr(), rec.data_ptr()))
-        ys_t, xs_t = tc.as_tensor(layout.ys, device=tile.dev).to(i32), tc.as_tensor(layout.xs, device=tile.dev).to(i32)
-
-    def owner(y, x):  # Layout.owner on the device
-        return ((tc.bucketize(y.contiguous(), ys_t, right=True) - 1) * layout.tx +
-                (tc.bucketize(x.contiguous(), xs_t, right=True) - 1))
+        if getattr(tile, "_route", None) is None:  # the layout's bands on the device, once per tile
+            tile._route = (tc.as_tensor(np.asarray(layout.ys, np.int32), device=tile.dev),
+                           tc.as_tensor(np.asarray(layout.xs, np.int32), device=tile.dev),
+                           tc.zeros(comm.size + 1, dtype=i32, device=tile.dev))
+        ys_t, xs_t, counts = tile._route
     work = tile._lift_work
+    phase["setup"] = time.perf_counter() - t_begin
+    iters = 0
     for _ in range(max_iters):
+        iters += 1
+        t0 = time.perf_counter()
         with tile.on_stream():
             n = int(rec.shape[0])
-            if n:
-                rec = rec.contiguous()
-                tile._chk(L.dt_dev_downslope_walk_w(tile.ctx.h, C.byref(tile.win), tile.p("dem"), tile.p("fdr"), tile.px,
-                                                    tile.dz, n, rec.data_ptr(),
-                                                    work.data_ptr() if work is not None else None,
-                                                    work.numel() if work is not None else 0))
-            done = (rec[:, 7] & W_DONE) != 0
-            dest = tc.where(done, owner(rec[:, 0], rec[:, 1]), owner(rec[:, 2], rec[:, 3]))
-            order = tc.argsort(dest, stable=True)
-            rec = rec[order]
-            meta = tc.cat([tc.bincount(dest, minlength=comm.size)[:comm.size], (~done).sum().reshape(1)])
-            m = comm.all_gather_ints(meta)                      # [size, size + 1] on the host: the one synchronisation
-            active = int(m[:, comm.size].sum())                 # walkers still on their way, over all ranks
-            got = comm.exchange_rows(rec, m[comm.rank, :comm.size], m[:, comm.rank])
-            fin = (got[:, 7] & W_DONE) != 0
-            home = got[fin]                                     # finished, and their start cell is mine
-            if home.shape[0]:
-                tile.core("down")[home[:, 0].long() - tile.gy0, home[:, 1].long() - tile.gx0] = \
-                    home[:, 10].contiguous().view(tc.float32)
-            rec = got[~fin]
-        if active == 0:
-            break
+            rec = rec.contiguous()
+            send = tc.empty_like(rec)
+            scratch = tc.empty(n + comm.size, dtype=i32, device=tile.dev)
+            # arrivals that are finished are written home, the others advance; then the records are grouped by where
+            # they go next and counted -- all on the device (dt_dev_downslope_walk_route_w)
+            tile._chk(L.dt_dev_downslope_walk_route_w(
+                tile.ctx.h, C.byref(tile.win), tile.p("dem"), tile.p("fdr"), tile.px, tile.dz, n, rec.data_ptr(),
+                work.data_ptr() if work is not None else None, work.numel() if work is not None else 0,
+                tile.p("down"), ys_t.data_ptr(), layout.ty, xs_t.data_ptr(), layout.tx, send.data_ptr(),
+                counts.data_ptr(), scratch.data_ptr()))
+            t1 = time.perf_counter()
+            m = comm.all_gather_ints(counts)                    # [size, size + 1] on the host: the one synchronisation
+            t2 = time.perf_counter()
+            phase["kernels"] += t1 - t0
+            phase["counts"] += t2 - t1
+            if int(m[:, :comm.size].sum()) == 0:                # nobody sends anything: every walker is home
+                break
+            rec = comm.exchange_rows(send[:int(m[comm.rank, :comm.size].sum())], m[comm.rank, :comm.size],
+                                     m[:, comm.rank])
+            phase["exchange"] += time.perf_counter() - t2
     else:
         raise RuntimeError("finish_downslope: walkers still on their way after %d exchanges" % max_iters)
     with tile.on_stream():
         tile.n_unres.zero_()
     tile.ctx.sync()
+    if stats is not None:
+        stats.update(iterations=iters, seconds=time.perf_counter() - t_begin, **{"s_" + k: v for k, v in phase.items()})
     return total
 
 

@@ -359,6 +359,19 @@ int dt_dev_downslope_emit_w(dt_ctx *ctx, const dt_window *win, const float *dem,
                             int64_t work_bytes, void *walkers, int64_t walkers_bytes);
 int dt_dev_downslope_walk_w(dt_ctx *ctx, const dt_window *win, const float *dem, const uint8_t *fdr, double px,
                             double elevation_difference, int64_t n, void *records, void *work, int64_t work_bytes);
+/* One iteration of the walkers' journey prepared on the device: records that arrived finished (flag 2) are home -- their
+ * value is written into `out` (this rank's downslope raster, core origin) and they are marked (flag 4) -- the others
+ * advance like dt_dev_downslope_walk_w; every record still wanted somewhere is then copied into `send` grouped by
+ * destination rank (a walker that has just finished: the owner of its start cell; otherwise the owner of the cell it
+ * stands on), counts[d] = records for rank d and counts[ty * tx] = how many of them are still on their way.  The host
+ * reads `counts` (its one synchronisation), exchanges them and the groups (all-to-all), and calls again with what it
+ * received until no rank sends anything.  row_starts[ty + 1] / col_starts[tx + 1]: first global row / column of every
+ * rank row / column and the raster's end (device arrays; rank = rank row * tx + rank column, at most 1024 ranks);
+ * counts: int32[ty * tx + 1]; scratch: int32[n + ty * tx]; send: room for n records. */
+int dt_dev_downslope_walk_route_w(dt_ctx *ctx, const dt_window *win, const float *dem, const uint8_t *fdr, double px,
+                                  double elevation_difference, int64_t n, void *records, void *work, int64_t work_bytes,
+                                  float *out, const int32_t *row_starts, int32_t ty, const int32_t *col_starts,
+                                  int32_t tx, void *send, int32_t *counts, int32_t *scratch);
 int dt_dev_downslope_walk_seed_w(dt_ctx *ctx, const dt_window *win, const float *dem, int64_t n, const int32_t *ys,
                                  const int32_t *xs, void *records);
 /* phase 1: in-rank accumulation; per ring cell: A = cells of this rank draining OUT through it (0 unless

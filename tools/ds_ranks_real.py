@@ -61,8 +61,9 @@ if tiles:  # the walks that left their rank travel on as walkers (one thread pla
     import threading
     comms = tiling.LocalComm.create(layout.size)
     done = [None] * layout.size
+    stats = [dict() for _ in range(layout.size)]
     def work(r):
-        done[r] = tiling.finish_downslope(tiles[r], comms[r])
+        done[r] = tiling.finish_downslope(tiles[r], comms[r], stats=stats[r])
     for rnd in ("first call (torch loads its kernels, its allocator asks the driver for every block)", "second call",
                 "third call"):
         t0 = time.perf_counter()
@@ -72,7 +73,9 @@ if tiles:  # the walks that left their rank travel on as walkers (one thread pla
         for th in threads:
             th.join()
         print("finish_downslope, %s: %d walkers in %.1f ms (four threads play the ranks; walker records emitted by the "
-              "downslope kernel, exchanged as device buffers)" % (rnd, done[0], (time.perf_counter() - t0) * 1e3), flush=True)
+              "downslope kernel, advanced / routed / grouped on the device, exchanged as device buffers)" % (rnd, done[0], (time.perf_counter() - t0) * 1e3), flush=True)
+        print("   rank 0: %d iterations; ms: " % stats[0]["iterations"] +
+              ", ".join("%s %.2f" % (k[2:], v * 1e3) for k, v in stats[0].items() if k.startswith("s_")), flush=True)
         if rnd != "third call":
             for tile in tiles:  # the same step again
                 tile.downslope()
