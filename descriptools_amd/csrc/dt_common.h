@@ -37,7 +37,7 @@ void dt_set_error(const char *fmt, ...);
   } while (0)
 
 // ---- test / experiment knobs (dt_debug_set in the C ABI; all 0 by default) -------------------------
-enum { DT_DBG_TWI_FLAG_ALL = 0, DT_DBG_TWI_PLAIN = 1, DT_DBG_TWI_WX = 2, DT_DBG_TWI_MAP = 3, DT_DBG_DS_MARGIN = 4, DT_DBG_NO_FUSED_FA_FH = 5, DT_DBG_HY_FILL_SWEEPS = 6, DT_DBG_HY_FLAT_SWEEPS = 7, DT_DBG_COUNT = 8 };
+enum { DT_DBG_TWI_FLAG_ALL = 0, DT_DBG_TWI_PLAIN = 1, DT_DBG_TWI_WX = 2, DT_DBG_TWI_MAP = 3, DT_DBG_DS_MARGIN = 4, DT_DBG_NO_FUSED_FA_FH = 5, DT_DBG_HY_FILL_SWEEPS = 6, DT_DBG_HY_FLAT_SWEEPS = 7, DT_DBG_HY_COLOUR_MIN = 8 /* tiles from which the conditioning rounds are coloured (0: the default; tests) */, DT_DBG_COUNT = 9 };
 #define DT_TWI_WX_DEFAULT 1 /* tile geometry of the fused slope + TI + MTI stencil: see k_slope_twi */
 int dt_debug_get(int key);
 

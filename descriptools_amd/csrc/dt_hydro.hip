@@ -110,6 +110,30 @@ __device__ __forceinline__ void hy_stage(T *s, const T *__restrict__ src, const 
 // fixed point, so sweeping a tile to that point only repeats work the next visit does anyway.
 #define HY_FILL_SWEEPS 1
 #define HY_FLAT_SWEEPS 1
+// COLOURED rounds (round 4).  A round that visits all tiles at once reads, in every tile, what the neighbours held
+// BEFORE the round: a front moves one tile per round.  The tiles are coloured 2 x 2 (colour = 2 * (row & 1) + (column &
+// 1): all eight neighbours of a tile have other colours) and a round is four launches, one colour each: a tile sees what
+// the colours before it did in this very round, and a front that crosses tile borders moves two tiles per round for the
+// same number of tile visits -- rough 16384^2 terrain: 16 -> 9 fill rounds, 12 -> 7 flat rounds.  The activity flags
+// live in ONE array used in place: when a tile of colour c is visited, every neighbour's latest visit lies after the
+// tile's own previous one, so the flags it reads are exactly the changes it has not seen yet, and nobody writes them
+// during this launch.  colour < 0: every tile (the first round of the fill, which initialises the surface).
+__device__ __forceinline__ void hy_tile_of_block(int colour, int tiles_x, int &ty, int &tx) {
+  if (colour < 0) {
+    ty = (int)blockIdx.x / tiles_x;
+    tx = (int)blockIdx.x - ty * tiles_x;
+  } else {
+    const int cx = (tiles_x - (colour & 1) + 1) >> 1;  // tiles of this colour in a row of tiles
+    const int i = (int)blockIdx.x / cx, j = (int)blockIdx.x - i * cx;
+    ty = 2 * i + (colour >> 1);
+    tx = 2 * j + (colour & 1);
+  }
+}
+// workgroups of a launch over the tiles of one colour
+static unsigned hy_colour_blocks(int colour, int tiles_x, int tiles_y) {
+  if (colour < 0) return (unsigned)(tiles_x * tiles_y);
+  return (unsigned)(((tiles_x - (colour & 1) + 1) >> 1) * ((tiles_y - (colour >> 1) + 1) >> 1));
+}
 __device__ __forceinline__ bool hy_tile_active(const uint8_t *__restrict__ act_prev, int ty, int tx, int tiles_x,
                                                int tiles_y) {
   if (!act_prev) return true;
@@ -133,7 +157,8 @@ __global__ __launch_bounds__(256) void k_fill_relax(const float *__restrict__ de
                                                    int tiles_x, int *__restrict__ changed,
                                                    const int *__restrict__ prev,
                                                    const uint8_t *__restrict__ act_prev,
-                                                   uint8_t *__restrict__ act_cur, int tiles_y, int sweeps) {
+                                                   uint8_t *__restrict__ act_cur, int tiles_y, int sweeps,
+                                                   int colour) {
   const int H = w.H, W = w.W;
   __shared__ float s_w[HLD * HLS];
   __shared__ float s_z[HT * HZS];  // the tile's own heights (nodata beyond the raster)
@@ -141,10 +166,12 @@ __global__ __launch_bounds__(256) void k_fill_relax(const float *__restrict__ de
   // a device-scope atomic load in every thread -- 260 K wave-level requests on one address at 16384^2, served one
   // after the other by the memory system: the rounds that had a `prev` took 3.9-4.4 ms, the ones without 1.5)
   if (prev && *prev == 0) return;
-  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  int ty, tx;
+  hy_tile_of_block(colour, tiles_x, ty, tx);
+  const int tile = ty * tiles_x + tx;
   const int y0 = ty * HT, x0 = tx * HT;
   if (!hy_tile_active(act_prev, ty, tx, tiles_x, tiles_y)) {
-    if (act_cur && threadIdx.x == 0) act_cur[blockIdx.x] = 0;
+    if (act_cur && threadIdx.x == 0) act_cur[tile] = 0;
     return;
   }
   // outside the raster and nodata both read as +inf: they never lower a minimum (cells next to them are outlets
@@ -255,7 +282,7 @@ __global__ __launch_bounds__(256) void k_fill_relax(const float *__restrict__ de
     any = 1;
   }
   if (INIT) any = 1;  // every cell is written, and the neighbours have yet to see this tile
-  if (act_cur && threadIdx.x == 0) act_cur[blockIdx.x] = (uint8_t)((any ? HY_CHANGED : 0) | (open ? HY_OPEN : 0));
+  if (act_cur && threadIdx.x == 0) act_cur[tile] = (uint8_t)((any ? HY_CHANGED : 0) | (open ? HY_OPEN : 0));
   if (!any) return;
 #pragma unroll
   for (int j = 0; j < H_CPT; j++) {
@@ -342,15 +369,18 @@ __global__ __launch_bounds__(256) void k_flat_relax(const float *__restrict__ ws
                                                    int tiles_x, int *__restrict__ changed,
                                                    const int *__restrict__ prev,
                                                    const uint8_t *__restrict__ act_prev,
-                                                   uint8_t *__restrict__ act_cur, int tiles_y, int sweeps) {
+                                                   uint8_t *__restrict__ act_cur, int tiles_y, int sweeps,
+                                                   int colour) {
   const int H = w.H, W = w.W;
   __shared__ float s_w[HLD * HLS];
   __shared__ uint32_t s_d[HLD * HLS];
   if (prev && *prev == 0) return;  // (a plain scalar load: see k_fill_relax)
-  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  int ty, tx;
+  hy_tile_of_block(colour, tiles_x, ty, tx);  // (coloured rounds: see hy_tile_of_block)
+  const int tile = ty * tiles_x + tx;
   const int y0 = ty * HT, x0 = tx * HT;
   if (!hy_tile_active(act_prev, ty, tx, tiles_x, tiles_y)) {
-    if (act_cur && threadIdx.x == 0) act_cur[blockIdx.x] = 0;
+    if (act_cur && threadIdx.x == 0) act_cur[tile] = 0;
     return;
   }
   hy_stage<float>(s_w, wsurf, w, y0, x0, DT_NODATA);
@@ -416,7 +446,7 @@ __global__ __launch_bounds__(256) void k_flat_relax(const float *__restrict__ ws
     any = 1;
   }
 #undef HY_M
-  if (act_cur && threadIdx.x == 0) act_cur[blockIdx.x] = (uint8_t)((any ? HY_CHANGED : 0) | (open ? HY_OPEN : 0));
+  if (act_cur && threadIdx.x == 0) act_cur[tile] = (uint8_t)((any ? HY_CHANGED : 0) | (open ? HY_OPEN : 0));
   if (!any) return;
 #pragma unroll
   for (int j = 0; j < H_CPT; j++) {
@@ -525,6 +555,49 @@ static DtWin hy_full_window(int64_t H, int64_t W) {
   return w;
 }
 
+// One relaxation round of a single raster.  Rasters of at least HY_COLOUR_MIN_TILES tiles run COLOURED rounds (four
+// launches, activity flags in place in act0: hy_tile_of_block); smaller ones keep one launch per round over every tile
+// with the flags alternating between act0 and act1 -- a colour of the Example's 840 tiles does not fill a quarter of
+// the chip, and four launches in a row cost it 1.9 ms where one costs 1.07 (16 + 12 rounds instead of 28 + 18 or not).
+#define HY_COLOUR_MIN_TILES 16384
+static size_t hy_colour_min() {
+  const int v = dt_debug_get(DT_DBG_HY_COLOUR_MIN);  // (tests run the coloured form on small rasters)
+  return v > 0 ? (size_t)v : (size_t)HY_COLOUR_MIN_TILES;
+}
+static void hy_fill_round(hipStream_t s, bool coloured, int64_t r, const float *dem, float *filled, const DtWin &w,
+                          int tiles_x, int tiles_y, int *f, const int *prev, uint8_t *act0, uint8_t *act1, int sweeps) {
+  const dim3 b(256);
+  if (r == 0) {  // the first round initialises the surface itself (no k_fill_init pass): every tile at once
+    hipLaunchKernelGGL(k_fill_relax<true>, dim3((unsigned)(tiles_x * tiles_y)), b, 0, s, dem, filled, w, tiles_x, f, prev,
+                       (const uint8_t *)nullptr, act0, tiles_y, sweeps, -1);
+  } else if (coloured) {
+    for (int c = 0; c < 4; c++)
+      if (hy_colour_blocks(c, tiles_x, tiles_y))
+        hipLaunchKernelGGL(k_fill_relax<false>, dim3(hy_colour_blocks(c, tiles_x, tiles_y)), b, 0, s, dem, filled, w,
+                           tiles_x, f, prev, (const uint8_t *)act0, act0, tiles_y, sweeps, c);
+  } else {
+    hipLaunchKernelGGL(k_fill_relax<false>, dim3((unsigned)(tiles_x * tiles_y)), b, 0, s, dem, filled, w, tiles_x, f, prev,
+                       (const uint8_t *)((r - 1) & 1 ? act1 : act0), (r & 1) ? act1 : act0, tiles_y, sweeps, -1);
+  }
+}
+// ... of the flat distances; has_flat: k_flat_init's per-tile flags, the activity the first round starts from (the
+// coloured form has them copied into act0 beforehand)
+static void hy_flat_round(hipStream_t s, bool coloured, int64_t r, const float *filled, uint32_t *dist, const DtWin &w,
+                          int tiles_x, int tiles_y, int *f, const int *prev, uint8_t *act0, uint8_t *act1,
+                          const uint8_t *has_flat, int sweeps) {
+  const dim3 b(256);
+  if (coloured) {
+    for (int c = 0; c < 4; c++)
+      if (hy_colour_blocks(c, tiles_x, tiles_y))
+        hipLaunchKernelGGL(k_flat_relax, dim3(hy_colour_blocks(c, tiles_x, tiles_y)), b, 0, s, filled, dist, w, tiles_x, f,
+                           prev, (const uint8_t *)act0, act0, tiles_y, sweeps, c);
+  } else {
+    hipLaunchKernelGGL(k_flat_relax, dim3((unsigned)(tiles_x * tiles_y)), b, 0, s, filled, dist, w, tiles_x, f, prev,
+                       r ? (const uint8_t *)((r - 1) & 1 ? act1 : act0) : has_flat, (r & 1) ? act1 : act0, tiles_y,
+                       sweeps, -1);
+  }
+}
+
 // dem -> filled surface (may alias nothing), D8 codes with flats resolved.  *unresolved_host = flat cells left
 // without a code (0 on any raster: every flat of a filled surface reaches a coded cell).  Synchronous.
 int dt_launch_condition(hipStream_t s, const float *dem, int64_t H, int64_t W, double px, float *filled, uint8_t *fdr,
@@ -542,25 +615,20 @@ int dt_launch_condition(hipStream_t s, const float *dem, int64_t H, int64_t W, d
   dim3 gc((unsigned)((n + 255) / 256)), gt((unsigned)(tiles_x * tiles_y)), b(256);
   int r1 = 0, r2 = 0;
   const int64_t max_rounds = n + 8;
-  uint8_t *act[2];
-  act[0] = (uint8_t *)scratch + DT_HYDRO_FLAG_BYTES + dt_align256((size_t)n * 4);
-  act[1] = act[0] + dt_align256(hy_tiles(H, W));
-  uint8_t *has_flat = act[1] + dt_align256(hy_tiles(H, W));
+  uint8_t *act = (uint8_t *)scratch + DT_HYDRO_FLAG_BYTES + dt_align256((size_t)n * 4);
+  uint8_t *act1 = act + dt_align256(hy_tiles(H, W));
+  uint8_t *has_flat = act + 2 * dt_align256(hy_tiles(H, W));
+  const bool coloured = hy_tiles(H, W) >= hy_colour_min();
   DT_TRY(hy_iterate(s, flag, max_rounds, [&](int *f, const int *prev, int64_t r) {
-    if (r == 0)  // the first round initialises the surface itself (no k_fill_init pass)
-      hipLaunchKernelGGL(k_fill_relax<true>, gt, b, 0, s, dem, filled, w, tiles_x, f, prev, (const uint8_t *)nullptr,
-                         act[0], tiles_y, fill_sweeps);
-    else
-      hipLaunchKernelGGL(k_fill_relax<false>, gt, b, 0, s, dem, filled, w, tiles_x, f, prev,
-                         (const uint8_t *)act[(r - 1) & 1], act[r & 1], tiles_y, fill_sweeps);
+    hy_fill_round(s, coloured, r, dem, filled, w, tiles_x, tiles_y, f, prev, act, act1, fill_sweeps);
   }, &r1));
   if (fdr) {
     DT_TRY(dt_launch_stencil(s, w, filled, px, nullptr, fdr, nullptr, nullptr, 0, 0.0, nullptr, nullptr));
     hipLaunchKernelGGL(k_flat_init, gt, b, 0, s, filled, fdr, w, dist, tiles_x, has_flat);
-    // the first round visits the tiles that have flat cells (and their neighbours), not every tile
+    // the rounds start from the tiles that have flat cells (and their neighbours), not from every tile
+    if (coloured) DT_HIP(hipMemcpyAsync(act, has_flat, hy_tiles(H, W), hipMemcpyDeviceToDevice, s));
     DT_TRY(hy_iterate(s, flag, max_rounds, [&](int *f, const int *prev, int64_t r) {
-      hipLaunchKernelGGL(k_flat_relax, gt, b, 0, s, filled, dist, w, tiles_x, f, prev,
-                         r ? (const uint8_t *)act[(r - 1) & 1] : (const uint8_t *)has_flat, act[r & 1], tiles_y, flat_sweeps);
+      hy_flat_round(s, coloured, r, filled, dist, w, tiles_x, tiles_y, f, prev, act, act1, has_flat, flat_sweeps);
     }, &r2));
     DT_HIP(hipMemsetAsync(flag + 64, 0, sizeof(int), s));
     hipLaunchKernelGGL(k_flat_assign, gt, b, 0, s, filled, dist, w, fdr, flag + 64, tiles_x, (const uint8_t *)has_flat);
@@ -598,22 +666,20 @@ int dt_launch_condition_async(hipStream_t s, const float *dem, int64_t H, int64_
   const int tiles_x = (int)((W + HT - 1) / HT), tiles_y = (int)((H + HT - 1) / HT);
   dim3 gc((unsigned)((n + 255) / 256)), gt((unsigned)(tiles_x * tiles_y)), b(256);
   DT_HIP(hipMemsetAsync(flags, 0, DT_HYDRO_FLAG_BYTES, s));
-  uint8_t *act[2];
-  act[0] = (uint8_t *)scratch + DT_HYDRO_FLAG_BYTES + dt_align256((size_t)n * 4);
-  act[1] = act[0] + dt_align256(hy_tiles(H, W));
-  uint8_t *has_flat = act[1] + dt_align256(hy_tiles(H, W));
-  hipLaunchKernelGGL(k_fill_relax<true>, gt, b, 0, s, dem, filled, w, tiles_x, flags, (const int *)nullptr,
-                     (const uint8_t *)nullptr, act[0], tiles_y, fill_sweeps);
-  for (int r = 1; r < rounds; r++)
-    hipLaunchKernelGGL(k_fill_relax<false>, gt, b, 0, s, dem, filled, w, tiles_x, flags + r, (const int *)(flags + r - 1),
-                       (const uint8_t *)act[(r - 1) & 1], act[r & 1], tiles_y, fill_sweeps);
+  uint8_t *act = (uint8_t *)scratch + DT_HYDRO_FLAG_BYTES + dt_align256((size_t)n * 4);
+  uint8_t *act1 = act + dt_align256(hy_tiles(H, W));
+  uint8_t *has_flat = act + 2 * dt_align256(hy_tiles(H, W));
+  const bool coloured = hy_tiles(H, W) >= hy_colour_min();
+  for (int r = 0; r < rounds; r++)
+    hy_fill_round(s, coloured, r, dem, filled, w, tiles_x, tiles_y, flags + r, r ? (const int *)(flags + r - 1) : nullptr,
+                  act, act1, fill_sweeps);
   DT_TRY(dt_launch_stencil(s, w, filled, px, nullptr, fdr, nullptr, nullptr, 0, 0.0, nullptr, nullptr));
   hipLaunchKernelGGL(k_flat_init, gt, b, 0, s, filled, fdr, w, dist, tiles_x, has_flat);
+  if (coloured) DT_HIP(hipMemcpyAsync(act, has_flat, hy_tiles(H, W), hipMemcpyDeviceToDevice, s));
   int *fl2 = flags + rounds;
   for (int r = 0; r < rounds; r++)
-    hipLaunchKernelGGL(k_flat_relax, gt, b, 0, s, filled, dist, w, tiles_x, fl2 + r,
-                       r ? (const int *)(fl2 + r - 1) : (const int *)nullptr,
-                       r ? (const uint8_t *)act[(r - 1) & 1] : (const uint8_t *)has_flat, act[r & 1], tiles_y, flat_sweeps);
+    hy_flat_round(s, coloured, r, filled, dist, w, tiles_x, tiles_y, fl2 + r, r ? (const int *)(fl2 + r - 1) : nullptr, act,
+                  act1, has_flat, flat_sweeps);
   hipLaunchKernelGGL(k_flat_assign, gt, b, 0, s, filled, dist, w, fdr, flags + 2 * rounds, tiles_x,
                      (const uint8_t *)has_flat);
   hipLaunchKernelGGL(k_hydro_verdict, dim3(1), dim3(1), 0, s, (const int *)(flags + rounds - 1),
@@ -637,6 +703,7 @@ int dt_launch_condition_stage(hipStream_t s, const DtWin &w, int stage, int roun
   const int tiles_x = (w.W + HT - 1) / HT, tiles_y = (w.H + HT - 1) / HT;
   dim3 gc((unsigned)((n + 255) / 256)), gt((unsigned)(tiles_x * tiles_y)), b(256);
   DT_REQUIRE(rounds >= 1 || (stage != 1 && stage != 3), "rounds < 1");
+  const bool coloured = (size_t)tiles_x * tiles_y >= hy_colour_min();  // (hy_fill_round)
   switch (stage) {
     case 0:
       DT_REQUIRE(dem && filled, "NULL raster");
@@ -645,8 +712,11 @@ int dt_launch_condition_stage(hipStream_t s, const DtWin &w, int stage, int roun
     case 1:
       DT_REQUIRE(dem && filled && flag_dev, "NULL pointer");
       for (int r = 0; r < rounds; r++)
-        hipLaunchKernelGGL(k_fill_relax<false>, gt, b, 0, s, dem, filled, w, tiles_x, flag_dev, (const int *)nullptr,
-                           (const uint8_t *)nullptr, (uint8_t *)nullptr, tiles_y, fill_sweeps);
+        for (int c = coloured ? 0 : -1; c < (coloured ? 4 : 0); c++)
+          if (hy_colour_blocks(c, tiles_x, tiles_y))
+            hipLaunchKernelGGL(k_fill_relax<false>, dim3(hy_colour_blocks(c, tiles_x, tiles_y)), b, 0, s, dem, filled, w,
+                               tiles_x, flag_dev, (const int *)nullptr, (const uint8_t *)nullptr, (uint8_t *)nullptr,
+                               tiles_y, fill_sweeps, c);
       break;
     case 2:
       DT_REQUIRE(filled && fdr && dist, "NULL pointer");
@@ -655,8 +725,11 @@ int dt_launch_condition_stage(hipStream_t s, const DtWin &w, int stage, int roun
     case 3:
       DT_REQUIRE(filled && dist && flag_dev, "NULL pointer");
       for (int r = 0; r < rounds; r++)
-        hipLaunchKernelGGL(k_flat_relax, gt, b, 0, s, filled, dist, w, tiles_x, flag_dev, (const int *)nullptr,
-                           (const uint8_t *)nullptr, (uint8_t *)nullptr, tiles_y, flat_sweeps);
+        for (int c = coloured ? 0 : -1; c < (coloured ? 4 : 0); c++)
+          if (hy_colour_blocks(c, tiles_x, tiles_y))
+            hipLaunchKernelGGL(k_flat_relax, dim3(hy_colour_blocks(c, tiles_x, tiles_y)), b, 0, s, filled, dist, w,
+                               tiles_x, flag_dev, (const int *)nullptr, (const uint8_t *)nullptr, (uint8_t *)nullptr,
+                               tiles_y, flat_sweeps, c);
       break;
     case 4:
       DT_REQUIRE(filled && dist && fdr && flag_dev, "NULL pointer");

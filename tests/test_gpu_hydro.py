@@ -89,6 +89,55 @@ def _serpentine(H, W, walls=1):
     return chan, order
 
 
+@pytest.fixture
+def coloured_rounds():
+    """the coloured form of the relaxation rounds (four launches per round, a 2 x 2 colouring of the tiles, activity
+    flags in place: dt_hydro.hip hy_tile_of_block) is the default from 16384 tiles on; debug key 8 lowers the bar so that
+    the small rasters of these tests run it"""
+    from descriptools_amd import _lib
+    L = _lib.lib()
+    _lib.check(L.dt_debug_set(8, 1))
+    yield
+    _lib.check(L.dt_debug_set(8, 0))
+
+
+@pytest.mark.parametrize("H,W,seed", [(300, 417, 1), (64, 64, 2), (129, 1000, 3), (1, 77, 4), (50, 1, 5), (700, 900, 6)])
+def test_coloured_rounds_on_rough_terrain(coloured_rounds, H, W, seed):
+    """the coloured rounds reach the same fixed points: rasters of one tile, one row / column of tiles (two of the four
+    colours have no tile), odd and even tile counts; synchronous and asynchronous form"""
+    import ctypes as C
+    from descriptools_amd import _lib
+    from descriptools_amd.device import Context
+    rng = np.random.default_rng(seed)
+    dem = oracle.synth_dem(seed, 2048, 2048, 11, 17, H, W, 3)
+    nod = dem == -100
+    dem = np.floor(dem + rng.normal(0, 6.0, dem.shape)).astype(np.float32)
+    dem[rng.random(dem.shape) < 0.02] -= 40
+    if H > 40 and W > 40:
+        dem[10:30, 5:35] = dem[10:30, 5:35].min()
+    dem[nod] = -100
+    fdr, filled, _ = _check(dem, 10.0)
+    L = _lib.lib()
+    ctx = Context()
+    d, f, c = ctx.to_device(dem), ctx.empty((H, W), np.float32), ctx.empty((H, W), np.uint8)
+    _lib.check(L.dt_dev_condition_d8_async(ctx.h, d.ptr, H, W, 10.0, f.ptr, c.ptr, 60))
+    assert ctx.status() == 0
+    assert np.array_equal(f.to_host(), filled) and np.array_equal(c.to_host(), fdr)
+    for b in (d, f, c):
+        b.free()
+    ctx.close()
+
+
+def test_coloured_rounds_on_the_serpentine_and_the_spiral(coloured_rounds):
+    test_conditioning_serpentine_depression_across_many_tiles()
+    test_conditioning_spiral_flat_across_many_tiles()
+
+
+@pytest.mark.parametrize("heights,widths", [([192, 130], [128, 250]), ([320], [128, 64, 130])])
+def test_coloured_rounds_over_ranks(coloured_rounds, heights, widths):
+    test_conditioning_tiled_over_ranks_equals_untiled(heights, widths)
+
+
 def test_conditioning_serpentine_depression_across_many_tiles():
     """the spill path of a depression may cross tile borders far more often than the raster has tiles.
     A closed basin whose floor is a serpentine channel between high 1-cell walls (192 x 192 = 9 tiles; the channel
