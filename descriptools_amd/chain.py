@@ -65,7 +65,7 @@ class Chain:
         # long_walks: for real, conditioned terrain, whose flats and valley floors make downslope walks thousands of
         # moves long (the bundled Example: 9.6 -> 1.0 ms).  True: the whole long-walk workspace up front
         # (dt_dev_downslope_lift, 56 B/cell), nothing synchronises.  "auto": the walks are queued (8 B/cell) and
-        # finish_long_walks() -- a synchronisation point -- finishes them, with skip tables (24 B/cell more) only when
+        # finish_long_walks() -- a synchronisation point -- finishes them, with skip tables (25 B/cell more) only when
         # the raster has enough of them; run_host does this.  False: the plain kernel (the synthetic benchmark terrain
         # has no long walks).
         assert long_walks in (False, True, "auto")
@@ -182,7 +182,7 @@ class Chain:
             return 0
         tables, tb = None, 0
         if n.value >= int(L.dt_downslope_tables_threshold(self.H, self.W)):
-            # the skip tables (24 bytes per cell) are kept once a step needed them: a raster that has long walks has
+            # the skip tables (25 bytes per cell) are kept once a step needed them: a raster that has long walks has
             # them in every step, and allocating 5 GB per step is not free
             tb = int(L.dt_downslope_tables_workspace(self.H, self.W))
             if self._lift_tables is None:

@@ -288,14 +288,15 @@ int dt_dev_gfi_lnhlh(dt_ctx *ctx, const float *hand, const int32_t *a_river, con
 int dt_dev_downslope(dt_ctx *ctx, const float *dem, const uint8_t *fdr, int64_t H, int64_t W,
                      double px, double elevation_difference, int raw, float *out);
 /* The same with the long-walk acceleration: walks that leave the kernel's window and are still short of the elevation
- * difference after 32 further moves are queued and finished with a skip table (64 moves per skip, built on the device
- * when at least 256 walks were queued) -- on real, conditioned terrain, where flats and valley floors make walks
- * thousands of moves long, an order of magnitude faster; same results.  `work`: dt_downslope_lift_workspace(H, W)
- * bytes of device memory (32 bytes per cell), the library's for the duration of the call's kernels. */
+ * difference after 32 further moves are queued and finished with skip tables (8 moves per skip for every cell, 16 / 32 /
+ * 64 for the queued cells, built on the device when at least 256 walks were queued) -- on real, conditioned terrain,
+ * where flats and valley floors make walks thousands of moves long, an order of magnitude faster; same results.
+ * `work`: dt_downslope_lift_workspace(H, W) bytes of device memory (33 bytes per cell), the library's for the duration
+ * of the call's kernels. */
 int64_t dt_downslope_lift_workspace(int64_t H, int64_t W);
 int dt_dev_downslope_lift(dt_ctx *ctx, const float *dem, const uint8_t *fdr, int64_t H, int64_t W, double px,
                           double dz, int raw, float *out, void *work, int64_t work_bytes);
-/* The same in two steps, for callers that may synchronise in between and want the tables' 24 bytes per cell only for
+/* The same in two steps, for callers that may synchronise in between and want the tables' 25 bytes per cell only for
  * rasters that need them: dt_dev_downslope_queue runs the window kernel and queues the long walks (qwork:
  * dt_downslope_queue_workspace bytes, 8 per cell); dt_dev_downslope_queued waits for it and returns their number;
  * dt_dev_downslope_finish finishes them -- with skip tables when twork (dt_downslope_tables_workspace bytes) is given
