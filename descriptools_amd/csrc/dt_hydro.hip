@@ -43,6 +43,71 @@ __device__ __forceinline__ float hy_from_next_lane(float edge, float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), 0x130, 0xF, 0xF, false));
 }
 
+// min / max as the bare instructions.  fminf / fmaxf cost a canonicalising `v_max x, x, x` per operand (IEEE mode: a
+// signalling NaN must come out quiet) -- seven of them in a step of the fill sweep, which is bound by vector issue.
+// The surface never holds a NaN (heights are staged through comparisons, +inf stands for "unknown"), and for a quiet
+// NaN height the instructions return the other operand, as fminf / fmaxf do.
+__device__ __forceinline__ float hy_min2(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float hy_min3(float a, float b, float c) {
+  float r;
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float hy_max2(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// One directional in-place sweep of the fill over the tile in LDS (see k_fill_relax): BY_ROWS: a lane per column, the
+// sweep walks rows; DIR: +1 from the first line to the last, -1 back.  Direction and strides are template parameters
+// so that every LDS address of a step is the running position plus an immediate offset (with run-time strides a step
+// spent five instructions on address arithmetic).  Returns whether the sweep lowered anything.
+template <bool BY_ROWS, int DIR>
+__device__ __forceinline__ int hy_fill_sweep(float *__restrict__ s_w, const float *__restrict__ s_z, int lane) {
+  constexpr int SA = BY_ROWS ? DIR * HLS : DIR;  // one step along the sweep
+  constexpr int SC = BY_ROWS ? 1 : HLS;          // one lane across it
+  constexpr int ZA = BY_ROWS ? DIR * HZS : DIR;
+  constexpr int K0 = DIR < 0 ? HT - 1 : 0;
+  int p = BY_ROWS ? (K0 + 1) * HLS + lane + 1 : (lane + 1) * HLS + K0 + 1;
+  int zi = BY_ROWS ? K0 * HZS + lane : lane * HZS + K0;
+  float up = s_w[p - SA];                              // the line before the tile (halo: nobody writes it)
+  float hl = s_w[p - SA - SC], hr = s_w[p - SA + SC];  // its cells beside lanes 0 / 63
+  float cur = s_w[p], lf = s_w[p - SC], rt = s_w[p + SC];
+  int ch = 0;
+#pragma unroll 4
+  for (int step = 0; step < HT; step++) {
+    // (through an index the compiler cannot see through: another wave may have lowered the cell since this lane
+    // fetched it as the line ahead, and with compile-time strides the compiler would reuse that value -- a store
+    // could then RAISE the cell)
+    int pf = p;
+    asm volatile("" : "+v"(pf));
+    const float fresh = s_w[pf];
+    const float d0 = s_w[p + SA - SC], d1 = s_w[p + SA], d2 = s_w[p + SA + SC];
+    const float zc = s_z[zi];
+    const float upm = hy_from_prev_lane(hl, up), upp = hy_from_next_lane(hr, up);
+    const float m = hy_min2(hy_min3(hy_min3(upm, up, upp), lf, rt), hy_min3(d0, d1, d2));
+    const float nw = hy_max2(zc, m);
+    const bool valid = !hy_nodata(zc);
+    if (valid && nw < fresh) {  // (a value equal to its height cannot get lower: nw >= zc)
+      s_w[p] = nw;
+      ch = 1;
+    }
+    up = (valid && nw < cur) ? nw : cur;  // what this lane leaves behind, without waiting for `fresh`
+    hl = lf;   // the next step's line before is this line: beside lanes 0 / 63 lie its halo cells
+    hr = rt;
+    cur = d1;
+    lf = d0;
+    rt = d2;
+    p += SA;
+    zi += ZA;
+  }
+  return ch;
+}
+
 // W = z on outlets (edge of the GLOBAL raster / next to nodata), +inf on the other valid cells, nodata stays nodata.
 // Windowed like every tile kernel: the core of `w`, neighbours read from the halo where the core ends inside the raster.
 __global__ __launch_bounds__(256) void k_fill_init(const float *__restrict__ dem, DtWin w, float *__restrict__ wout) {
@@ -239,44 +304,15 @@ __global__ __launch_bounds__(256) void k_fill_relax(const float *__restrict__ de
   // line ahead were fetched a step earlier (the line ahead of this step IS the next step's line), and the one fresh
   // read of the cell itself -- another wave may have lowered it since -- only gates the store.  ~15 vector
   // instructions per step instead of two LDS round trips.
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const bool by_rows = !(wave & 2);                 // waves 0 / 1 walk rows (a lane per column), 2 / 3 columns
-  const int dir = (wave & 1) ? -1 : 1;
-  const int SA = by_rows ? dir * HLS : dir;         // one step along the sweep
-  const int SC = by_rows ? 1 : HLS;                 // one lane across it
-  const int ZA = by_rows ? dir * HZS : dir;
-  const int k0 = (wave & 1) ? HT - 1 : 0;
-  const int p0 = by_rows ? (k0 + 1) * HLS + lane + 1 : (lane + 1) * HLS + k0 + 1;
-  const int zi0 = by_rows ? k0 * HZS + lane : lane * HZS + k0;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   int any = 0, open = 0;
-  // rounds of four sweeps until one of them lowers nothing (round 4; one round per visit before)
+  // rounds of four sweeps until one of them lowers nothing (round 4; `sweeps` = 1: one round per visit)
   for (int it = 0; it < sweeps; it++) {
-    int p = p0, zi = zi0;
-    float up = s_w[p - SA];                              // the line before the tile (halo: nobody writes it)
-    float hl = s_w[p - SA - SC], hr = s_w[p - SA + SC];  // its cells beside lanes 0 / 63
-    float cur = s_w[p], lf = s_w[p - SC], rt = s_w[p + SC];
-    int ch = 0;
-    for (int step = 0; step < HT; step++) {
-      const float fresh = s_w[p];
-      const float d0 = s_w[p + SA - SC], d1 = s_w[p + SA], d2 = s_w[p + SA + SC];
-      const float zc = s_z[zi];
-      const float upm = hy_from_prev_lane(hl, up), upp = hy_from_next_lane(hr, up);
-      const float m = fminf(fminf(fminf(upm, up), fminf(upp, lf)), fminf(fminf(rt, d0), fminf(d1, d2)));
-      const float nw = fmaxf(zc, m);
-      const bool valid = !hy_nodata(zc);
-      if (valid && nw < fresh) {  // (a value equal to its height cannot get lower: nw >= zc)
-        s_w[p] = nw;
-        ch = 1;
-      }
-      up = (valid && nw < cur) ? nw : cur;  // what this lane leaves behind, without waiting for `fresh`
-      hl = lf;   // the next step's line before is this line: beside lanes 0 / 63 lie its halo cells
-      hr = rt;
-      cur = d1;
-      lf = d0;
-      rt = d2;
-      p += SA;
-      zi += ZA;
-    }
+    int ch;
+    if (wave == 0) ch = hy_fill_sweep<true, 1>(s_w, s_z, lane);         // top to bottom
+    else if (wave == 1) ch = hy_fill_sweep<true, -1>(s_w, s_z, lane);   // bottom to top
+    else if (wave == 2) ch = hy_fill_sweep<false, 1>(s_w, s_z, lane);   // left to right (a lane per row)
+    else ch = hy_fill_sweep<false, -1>(s_w, s_z, lane);                 // right to left
     open = __syncthreads_or(ch);
     if (!open) break;
     any = 1;
@@ -364,6 +400,62 @@ __global__ __launch_bounds__(256) void k_flat_init(const float *__restrict__ wsu
   if (has_flat && threadIdx.x == 0) has_flat[blockIdx.x] = (uint8_t)(any ? (HY_CHANGED | HY_OPEN) : 0);
 }
 
+// One directional in-place sweep of the flat distances over the tile in LDS (see k_flat_relax; direction and strides
+// are template parameters as in hy_fill_sweep).  Returns whether the sweep lowered anything.
+template <bool BY_ROWS, int DIR>
+__device__ __forceinline__ int hy_flat_sweep(const float *__restrict__ s_w, uint32_t *__restrict__ s_d, int lane) {
+  constexpr int SA = BY_ROWS ? DIR * HLS : DIR, SC = BY_ROWS ? 1 : HLS;
+  constexpr int K0 = DIR < 0 ? HT - 1 : 0;
+  auto dpp_prev = [](uint32_t edge, uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x138, 0xF, 0xF, false);
+  };
+  auto dpp_next = [](uint32_t edge, uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x130, 0xF, 0xF, false);
+  };
+#define HY_M(wn, dn) m = min(m, (wn) == wc ? (dn) : H_INF_DIST);
+  int p = BY_ROWS ? (K0 + 1) * HLS + lane + 1 : (lane + 1) * HLS + K0 + 1;
+  float wu = s_w[p - SA], whl = s_w[p - SA - SC], whr = s_w[p - SA + SC];   // heights: line before, its edge cells
+  uint32_t du = s_d[p - SA], dhl = s_d[p - SA - SC], dhr = s_d[p - SA + SC];
+  float wcur = s_w[p], wlf = s_w[p - SC], wrt = s_w[p + SC];
+  uint32_t dcur = s_d[p], dlf = s_d[p - SC], drt = s_d[p + SC];
+  int ch = 0;
+#pragma unroll 4
+  for (int step = 0; step < HT; step++) {
+    int pf = p;  // (see hy_fill_sweep: the fresh read must not be merged with the value fetched a step earlier)
+    asm volatile("" : "+v"(pf));
+    const uint32_t fresh = s_d[pf];
+    const float w0 = s_w[p + SA - SC], w1 = s_w[p + SA], w2 = s_w[p + SA + SC];
+    const uint32_t d0 = s_d[p + SA - SC], d1 = s_d[p + SA], d2 = s_d[p + SA + SC];
+    const float wc = wcur;
+    const float wum = hy_from_prev_lane(whl, wu), wup = hy_from_next_lane(whr, wu);
+    const uint32_t dum = dpp_prev(dhl, du), dup = dpp_next(dhr, du);
+    uint32_t m = H_INF_DIST;
+    HY_M(wum, dum) HY_M(wu, du) HY_M(wup, dup) HY_M(wlf, dlf) HY_M(wrt, drt) HY_M(w0, d0) HY_M(w1, d1) HY_M(w2, d2)
+    // coded cells (0) and cells next to one (1) are final; positions beyond the raster edge are staged as nodata
+    const bool lower = dcur > 1u && !hy_nodata(wc) && m != H_INF_DIST;
+    const uint32_t nd = m + 1u;
+    if (lower && nd < fresh) {
+      s_d[p] = nd;
+      ch = 1;
+    }
+    du = (lower && nd < dcur) ? nd : dcur;  // what this lane leaves behind
+    wu = wc;
+    whl = wlf;
+    whr = wrt;
+    dhl = dlf;
+    dhr = drt;
+    wcur = w1;
+    wlf = w0;
+    wrt = w2;
+    dcur = d1;
+    dlf = d0;
+    drt = d2;
+    p += SA;
+  }
+#undef HY_M
+  return ch;
+}
+
 // one round of the flat distances: d(c) = 1 + min d(n) over neighbours of the same filled height
 __global__ __launch_bounds__(256) void k_flat_relax(const float *__restrict__ wsurf, uint32_t *__restrict__ dist, DtWin w,
                                                    int tiles_x, int *__restrict__ changed,
@@ -390,62 +482,18 @@ __global__ __launch_bounds__(256) void k_flat_relax(const float *__restrict__ ws
   // sweeps until one changes nothing.  The heights never change, and the line a sweep comes from is in registers
   // (heights and distances: the lane's own, its neighbours' through DPP), the line it stands on and the line ahead were
   // fetched a step earlier: 7 LDS reads per step where round 3 made 17.
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const bool by_rows = !(wave & 2);
-  const int dir = (wave & 1) ? -1 : 1;
-  const int SA = by_rows ? dir * HLS : dir, SC = by_rows ? 1 : HLS;
-  const int k0 = (wave & 1) ? HT - 1 : 0;
-  const int p0 = by_rows ? (k0 + 1) * HLS + lane + 1 : (lane + 1) * HLS + k0 + 1;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   int any = 0, open = 0;
-  auto dpp_prev = [](uint32_t edge, uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x138, 0xF, 0xF, false);
-  };
-  auto dpp_next = [](uint32_t edge, uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x130, 0xF, 0xF, false);
-  };
-#define HY_M(wn, dn) m = min(m, (wn) == wc ? (dn) : H_INF_DIST);
   for (int it = 0; it < sweeps; it++) {
-    int p = p0;
-    float wu = s_w[p - SA], whl = s_w[p - SA - SC], whr = s_w[p - SA + SC];   // heights: line before, its edge cells
-    uint32_t du = s_d[p - SA], dhl = s_d[p - SA - SC], dhr = s_d[p - SA + SC];
-    float wcur = s_w[p], wlf = s_w[p - SC], wrt = s_w[p + SC];
-    uint32_t dcur = s_d[p], dlf = s_d[p - SC], drt = s_d[p + SC];
-    int ch = 0;
-    for (int step = 0; step < HT; step++) {
-      const uint32_t fresh = s_d[p];
-      const float w0 = s_w[p + SA - SC], w1 = s_w[p + SA], w2 = s_w[p + SA + SC];
-      const uint32_t d0 = s_d[p + SA - SC], d1 = s_d[p + SA], d2 = s_d[p + SA + SC];
-      const float wc = wcur;
-      const float wum = hy_from_prev_lane(whl, wu), wup = hy_from_next_lane(whr, wu);
-      const uint32_t dum = dpp_prev(dhl, du), dup = dpp_next(dhr, du);
-      uint32_t m = H_INF_DIST;
-      HY_M(wum, dum) HY_M(wu, du) HY_M(wup, dup) HY_M(wlf, dlf) HY_M(wrt, drt) HY_M(w0, d0) HY_M(w1, d1) HY_M(w2, d2)
-      // coded cells (0) and cells next to one (1) are final; positions beyond the raster edge are staged as nodata
-      const bool lower = dcur > 1u && !hy_nodata(wc) && m != H_INF_DIST;
-      const uint32_t nd = m + 1u;
-      if (lower && nd < fresh) {
-        s_d[p] = nd;
-        ch = 1;
-      }
-      du = (lower && nd < dcur) ? nd : dcur;  // what this lane leaves behind
-      wu = wc;
-      whl = wlf;
-      whr = wrt;
-      dhl = dlf;
-      dhr = drt;
-      wcur = w1;
-      wlf = w0;
-      wrt = w2;
-      dcur = d1;
-      dlf = d0;
-      drt = d2;
-      p += SA;
-    }
+    int ch;
+    if (wave == 0) ch = hy_flat_sweep<true, 1>(s_w, s_d, lane);
+    else if (wave == 1) ch = hy_flat_sweep<true, -1>(s_w, s_d, lane);
+    else if (wave == 2) ch = hy_flat_sweep<false, 1>(s_w, s_d, lane);
+    else ch = hy_flat_sweep<false, -1>(s_w, s_d, lane);
     open = __syncthreads_or(ch);
     if (!open) break;
     any = 1;
   }
-#undef HY_M
   if (act_cur && threadIdx.x == 0) act_cur[tile] = (uint8_t)((any ? HY_CHANGED : 0) | (open ? HY_OPEN : 0));
   if (!any) return;
 #pragma unroll
