@@ -1138,6 +1138,16 @@ __global__ __launch_bounds__(256) void k_ds_lift_init(const float *__restrict__ 
       cs[j] = (RANKED ? dt_has_code(w, y, x) : dt_readable(w, y, x)) ? fdr[(long long)y * w.ld + x] : (uint8_t)0;
     }
   }
+  // a tile without a single valid cell (real rasters are basins inside a rectangle of nodata: half of the tiled
+  // Example) has no entry anybody reads -- a walk never stands on nodata -- and is left as it is
+  int valid = 0;
+#pragma unroll
+  for (int j = 0; j < LT_CPT; j++) {
+    const int i = (int)threadIdx.x + 256 * j;
+    const int r = i / LT_WIN, c = i - r * LT_WIN;
+    valid |= (r >= LT_M && r < LT_M + 64 && c >= LT_M && c < LT_M + 64 && zs[j] != DT_NODATA) ? 1 : 0;
+  }
+  if (!__syncthreads_or(valid)) return;
 #pragma unroll
   for (int j = 0; j < LT_CPT; j++) {
     const int i = (int)threadIdx.x + 256 * j;
