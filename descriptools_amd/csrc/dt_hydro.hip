@@ -65,7 +65,8 @@ __device__ __forceinline__ float hy_max2(float a, float b) {
 // One directional in-place sweep of the fill over the tile in LDS (see k_fill_relax): BY_ROWS: a lane per column, the
 // sweep walks rows; DIR: +1 from the first line to the last, -1 back.  Direction and strides are template parameters
 // so that every LDS address of a step is the running position plus an immediate offset (with run-time strides a step
-// spent five instructions on address arithmetic).  Returns whether the sweep lowered anything.
+// spent five instructions on address arithmetic).  Returns bit 0: the sweep lowered something; bit 1: on the tile's
+// outer ring -- the cells the neighbouring tiles read as their halo.
 template <bool BY_ROWS, int DIR>
 __device__ __forceinline__ int hy_fill_sweep(float *__restrict__ s_w, const float *__restrict__ s_z, int lane) {
   constexpr int SA = BY_ROWS ? DIR * HLS : DIR;  // one step along the sweep
@@ -77,6 +78,7 @@ __device__ __forceinline__ int hy_fill_sweep(float *__restrict__ s_w, const floa
   float up = s_w[p - SA];                              // the line before the tile (halo: nobody writes it)
   float hl = s_w[p - SA - SC], hr = s_w[p - SA + SC];  // its cells beside lanes 0 / 63
   float cur = s_w[p], lf = s_w[p - SC], rt = s_w[p + SC];
+  const bool on_side = lane == 0 || lane == HT - 1;
   int ch = 0;
 #pragma unroll 4
   for (int step = 0; step < HT; step++) {
@@ -94,7 +96,7 @@ __device__ __forceinline__ int hy_fill_sweep(float *__restrict__ s_w, const floa
     const bool valid = !hy_nodata(zc);
     if (valid && nw < fresh) {  // (a value equal to its height cannot get lower: nw >= zc)
       s_w[p] = nw;
-      ch = 1;
+      ch |= (on_side || step == 0 || step == HT - 1) ? 3 : 1;  // bit 1: a cell of the tile's outer ring
     }
     up = (valid && nw < cur) ? nw : cur;  // what this lane leaves behind, without waiting for `fresh`
     hl = lf;   // the next step's line before is this line: beside lanes 0 / 63 lie its halo cells
@@ -166,7 +168,7 @@ __device__ __forceinline__ void hy_stage(T *s, const T *__restrict__ src, const 
 // do.  A round visits the tiles that have a changed NEIGHBOUR or are open themselves; a tile at its local fixed point
 // rests until its halo changes.  (With one round of sweeps per visit -- the measured optimum, HY_FILL_SWEEPS -- a
 // tile that changed is open: round 3's rule.)  act_prev == NULL: the first round of a phase, every tile is visited.
-#define HY_CHANGED 1
+#define HY_CHANGED 1 /* (round 4, late: only when a cell of the tile's OUTER RING changed -- what its neighbours read) */
 #define HY_OPEN 2
 // rounds of sweeps per visit at most (dt_debug_set(6 / 7, n) overrides: tools/condition_bench.py N sweeps).  Measured,
 // round 4 (profiles/r4/conditioning_sweeps.txt): ONE is best for both relaxations on rough 8192^2 terrain and on the
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(256) void k_fill_relax(const float *__restrict__ de
   // read of the cell itself -- another wave may have lowered it since -- only gates the store.  ~15 vector
   // instructions per step instead of two LDS round trips.
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-  int any = 0, open = 0;
+  int any = 0, open = 0, ring = 0;
   // rounds of four sweeps until one of them lowers nothing (round 4; `sweeps` = 1: one round per visit)
   for (int it = 0; it < sweeps; it++) {
     int ch;
@@ -316,9 +318,10 @@ __global__ __launch_bounds__(256) void k_fill_relax(const float *__restrict__ de
     open = __syncthreads_or(ch);
     if (!open) break;
     any = 1;
+    ring |= __syncthreads_or(ch & 2);
   }
-  if (INIT) any = 1;  // every cell is written, and the neighbours have yet to see this tile
-  if (act_cur && threadIdx.x == 0) act_cur[tile] = (uint8_t)((any ? HY_CHANGED : 0) | (open ? HY_OPEN : 0));
+  if (INIT) any = ring = 1;  // every cell is written, and the neighbours have yet to see this tile
+  if (act_cur && threadIdx.x == 0) act_cur[tile] = (uint8_t)((ring ? HY_CHANGED : 0) | (open ? HY_OPEN : 0));
   if (!any) return;
 #pragma unroll
   for (int j = 0; j < H_CPT; j++) {
@@ -401,7 +404,7 @@ __global__ __launch_bounds__(256) void k_flat_init(const float *__restrict__ wsu
 }
 
 // One directional in-place sweep of the flat distances over the tile in LDS (see k_flat_relax; direction and strides
-// are template parameters as in hy_fill_sweep).  Returns whether the sweep lowered anything.
+// are template parameters as in hy_fill_sweep).  Returns hy_fill_sweep's two bits.
 template <bool BY_ROWS, int DIR>
 __device__ __forceinline__ int hy_flat_sweep(const float *__restrict__ s_w, uint32_t *__restrict__ s_d, int lane) {
   constexpr int SA = BY_ROWS ? DIR * HLS : DIR, SC = BY_ROWS ? 1 : HLS;
@@ -418,6 +421,7 @@ __device__ __forceinline__ int hy_flat_sweep(const float *__restrict__ s_w, uint
   uint32_t du = s_d[p - SA], dhl = s_d[p - SA - SC], dhr = s_d[p - SA + SC];
   float wcur = s_w[p], wlf = s_w[p - SC], wrt = s_w[p + SC];
   uint32_t dcur = s_d[p], dlf = s_d[p - SC], drt = s_d[p + SC];
+  const bool on_side = lane == 0 || lane == HT - 1;
   int ch = 0;
 #pragma unroll 4
   for (int step = 0; step < HT; step++) {
@@ -436,7 +440,7 @@ __device__ __forceinline__ int hy_flat_sweep(const float *__restrict__ s_w, uint
     const uint32_t nd = m + 1u;
     if (lower && nd < fresh) {
       s_d[p] = nd;
-      ch = 1;
+      ch |= (on_side || step == 0 || step == HT - 1) ? 3 : 1;  // bit 1: a cell of the tile's outer ring
     }
     du = (lower && nd < dcur) ? nd : dcur;  // what this lane leaves behind
     wu = wc;
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(256) void k_flat_relax(const float *__restrict__ ws
   // (heights and distances: the lane's own, its neighbours' through DPP), the line it stands on and the line ahead were
   // fetched a step earlier: 7 LDS reads per step where round 3 made 17.
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-  int any = 0, open = 0;
+  int any = 0, open = 0, ring = 0;
   for (int it = 0; it < sweeps; it++) {
     int ch;
     if (wave == 0) ch = hy_flat_sweep<true, 1>(s_w, s_d, lane);
@@ -493,8 +497,9 @@ __global__ __launch_bounds__(256) void k_flat_relax(const float *__restrict__ ws
     open = __syncthreads_or(ch);
     if (!open) break;
     any = 1;
+    ring |= __syncthreads_or(ch & 2);
   }
-  if (act_cur && threadIdx.x == 0) act_cur[tile] = (uint8_t)((any ? HY_CHANGED : 0) | (open ? HY_OPEN : 0));
+  if (act_cur && threadIdx.x == 0) act_cur[tile] = (uint8_t)((ring ? HY_CHANGED : 0) | (open ? HY_OPEN : 0));
   if (!any) return;
 #pragma unroll
   for (int j = 0; j < H_CPT; j++) {
