@@ -1050,10 +1050,14 @@ class DistComm:
         self.dist.all_gather_into_tensor(out, v.contiguous(), group=self.group)
         return out.cpu().numpy().reshape(self.size, -1)
 
-    def all_gather_host_ints(self, values):
-        """values: a few host integers -> host numpy [size, k]"""
+    def all_gather_host_ints(self, values, device=None):
+        """values: a few host integers -> host numpy [size, k] (device: where the collective's buffer lives on RCCL --
+        the caller's GPU; default: torch's current device)"""
         import torch
-        dev = "cpu" if self.cpu else torch.device("cuda", torch.cuda.current_device())
+        if self.cpu:
+            dev = "cpu"
+        else:
+            dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         return self.all_gather_ints(torch.tensor([int(v) for v in values], dtype=torch.int64, device=dev))
 
     def exchange_rows(self, rows, send_counts, recv_counts):
@@ -1103,7 +1107,7 @@ class LocalComm:
     def all_gather_ints(self, vec):
         return np.stack(self._swap(vec.cpu().numpy().astype(np.int64)))
 
-    def all_gather_host_ints(self, values):
+    def all_gather_host_ints(self, values, device=None):
         return np.stack(self._swap(np.asarray([int(v) for v in values], np.int64)))
 
     def exchange_rows(self, rows, send_counts, recv_counts):
@@ -1143,7 +1147,7 @@ def finish_downslope(tile, comm, max_iters=200, stats=None):
     n_local = tile.unresolved_downslope()
     i32 = tc.int32
     with tile.on_stream():
-        total = int(np.sum(comm.all_gather_host_ints([n_local])))
+        total = int(np.sum(comm.all_gather_host_ints([n_local], device=tile.dev)))
     if total == 0:
         return 0
     with tile.on_stream():
