@@ -134,14 +134,71 @@ __global__ __launch_bounds__(256) void k_fill_init(const float *__restrict__ dem
   wout[o] = outlet ? z : __builtin_inff();
 }
 
-// stage the tile's 66 x 66 window of `src` into LDS; cells outside the raster read as `outside`
+// ---- staging a tile's 66 x 66 window into LDS ---------------------------------------------------------------------
+// The common case -- a tile inside the raster, rows aligned to 16 bytes -- takes the 64 x 64 core as 16-byte loads (four
+// per thread) and the ring around it as one or two 4-byte loads: six load instructions per thread where the 66-wide
+// rows, which start one cell before a 256-byte boundary, took eighteen (bare reads: 6.3 instead of 3.8 TB/s,
+// profiles/r4/micro_tile_read.txt).  Loads and LDS stores are separate functions so that a kernel that stages two
+// rasters (or a raster and the tile's heights) has ALL its loads in flight before it waits for the first.
+typedef uint32_t hy_v4u __attribute__((ext_vector_type(4)));
+struct HyTileRegs {
+  hy_v4u c[4];
+  uint32_t r1, r2;
+};
+__device__ __forceinline__ void hy_ring_cell(int j, int &r, int &c) {  // 66 above, 66 below, 64 left, 64 right
+  if (j < HLD) { r = 0; c = j; }
+  else if (j < 2 * HLD) { r = HLD - 1; c = j - HLD; }
+  else if (j < 2 * HLD + HT) { r = j - 2 * HLD + 1; c = 0; }
+  else { r = j - 2 * HLD - HT + 1; c = HLD - 1; }
+}
+// block-uniform: the whole window is readable and the core's rows can be read 16 bytes at a time
+__device__ __forceinline__ bool hy_tile_fast(const void *src, const DtWin &w, int y0, int x0) {
+  return dt_readable(w, y0 - 1, x0 - 1) && dt_readable(w, y0 + HT, x0 + HT) && (w.ld & 3) == 0 && (x0 & 3) == 0 &&
+         ((uintptr_t)src & 15) == 0;
+}
+__device__ __forceinline__ void hy_tile_load(HyTileRegs &t, const void *src, const DtWin &w, int y0, int x0) {
+  const uint32_t *__restrict__ p32 = reinterpret_cast<const uint32_t *>(src);
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int i = (int)threadIdx.x + 256 * k;  // 16 groups of four cells per row
+    t.c[k] = *reinterpret_cast<const hy_v4u *>(p32 + (long long)(y0 + (i >> 4)) * w.ld + x0 + (i & 15) * 4);
+  }
+  int r, c;
+  hy_ring_cell((int)threadIdx.x, r, c);
+  t.r1 = p32[(long long)(y0 - 1 + r) * w.ld + x0 - 1 + c];
+  t.r2 = 0u;
+  if ((int)threadIdx.x + 256 < 2 * HLD + 2 * HT) {
+    hy_ring_cell((int)threadIdx.x + 256, r, c);
+    t.r2 = p32[(long long)(y0 - 1 + r) * w.ld + x0 - 1 + c];
+  }
+}
+__device__ __forceinline__ void hy_tile_store(const HyTileRegs &t, void *s) {
+  uint32_t *s32 = reinterpret_cast<uint32_t *>(s);
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int i = (int)threadIdx.x + 256 * k;
+    uint32_t *d = s32 + ((i >> 4) + 1) * HLS + 1 + (i & 15) * 4;
+    d[0] = t.c[k].x;
+    d[1] = t.c[k].y;
+    d[2] = t.c[k].z;
+    d[3] = t.c[k].w;
+  }
+  int r, c;
+  hy_ring_cell((int)threadIdx.x, r, c);
+  s32[r * HLS + c] = t.r1;
+  if ((int)threadIdx.x + 256 < 2 * HLD + 2 * HT) {
+    hy_ring_cell((int)threadIdx.x + 256, r, c);
+    s32[r * HLS + c] = t.r2;
+  }
+}
+// the general form: cells outside the raster (or the rank's memory) read as `outside`
 template <typename T>
-__device__ __forceinline__ void hy_stage(T *s, const T *__restrict__ src, const DtWin &w, int y0, int x0, T outside) {
+__device__ __forceinline__ void hy_stage_slow(T *s, const T *__restrict__ src, const DtWin &w, int y0, int x0, T outside) {
   // all of a thread's (up to 18) loads are issued before the first is used: one memory round trip per staging, not
   // eighteen (the loop form waited for each load before it computed the next address)
   constexpr int N = (HLD * HLD + 255) / 256;
   T v[N];
-  // block-uniform: the whole 66 x 66 window is readable (inside the global raster and in this rank's memory)
+  // block-uniform: the whole 66 x 66 window is readable (rows that are not 16-byte aligned bring a tile here too)
   const bool all_in = dt_readable(w, y0 - 1, x0 - 1) && dt_readable(w, y0 + HT, x0 + HT);
 #pragma unroll
   for (int k = 0; k < N; k++) {
@@ -159,6 +216,33 @@ __device__ __forceinline__ void hy_stage(T *s, const T *__restrict__ src, const 
   for (int k = 0; k < N; k++) {
     const int i = threadIdx.x + 256 * k;
     if (i < HLD * HLD) s[(i / HLD) * HLS + (i - (i / HLD) * HLD)] = v[k];
+  }
+}
+// stage the tile's 66 x 66 window of `src` into LDS; cells outside the raster read as `outside`
+template <typename T>
+__device__ __forceinline__ void hy_stage(T *s, const T *__restrict__ src, const DtWin &w, int y0, int x0, T outside) {
+  static_assert(sizeof(T) == 4, "32-bit rasters");
+  if (hy_tile_fast(src, w, y0, x0)) {
+    HyTileRegs t;
+    hy_tile_load(t, src, w, y0, x0);
+    hy_tile_store(t, s);
+  } else {
+    hy_stage_slow<T>(s, src, w, y0, x0, outside);
+  }
+}
+// ... of two rasters: both windows' loads are in flight before the first store waits
+template <typename TA, typename TB>
+__device__ __forceinline__ void hy_stage2(TA *sa, const TA *__restrict__ a, TA outside_a, TB *sb,
+                                          const TB *__restrict__ b, TB outside_b, const DtWin &w, int y0, int x0) {
+  if (hy_tile_fast(a, w, y0, x0) && hy_tile_fast(b, w, y0, x0)) {
+    HyTileRegs ta, tb;
+    hy_tile_load(ta, a, w, y0, x0);
+    hy_tile_load(tb, b, w, y0, x0);
+    hy_tile_store(ta, sa);
+    hy_tile_store(tb, sb);
+  } else {
+    hy_stage_slow<TA>(sa, a, w, y0, x0, outside_a);
+    hy_stage_slow<TB>(sb, b, w, y0, x0, outside_b);
   }
 }
 
@@ -244,6 +328,9 @@ __global__ __launch_bounds__(256) void k_fill_relax(const float *__restrict__ de
   // outside the raster and nodata both read as +inf: they never lower a minimum (cells next to them are outlets
   // and already hold their final value)
   float z[H_CPT];
+  // block-uniform: a whole tile of 16-byte aligned rows -- heights in and surface out go 16 bytes at a time
+  const bool fastio = y0 + HT <= H && x0 + HT <= W && (w.ld & 3) == 0 && ((uintptr_t)dem & 15) == 0 &&
+                      ((uintptr_t)wsurf & 15) == 0;
   if (INIT) {
     // the HEIGHTS of the window: a cell is an outlet when it lies on the raster's edge or has a nodata neighbour
     // (cells beyond the raster are staged as +inf: not nodata)
@@ -273,22 +360,47 @@ __global__ __launch_bounds__(256) void k_fill_relax(const float *__restrict__ de
       s_w[(c / HT + 1) * HLS + (c % HT) + 1] = w0[j];
     }
   } else {
+    // the tile's heights first: their loads are in flight while the surface is staged (they were issued after its
+    // barrier before: a second memory round trip on every visit)
+    hy_v4u z4[4];
+    if (fastio) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int i = (int)threadIdx.x + 256 * k;
+        z4[k] = *reinterpret_cast<const hy_v4u *>(dem + (long long)(y0 + (i >> 4)) * w.ld + x0 + (i & 15) * 4);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < H_CPT; j++) {
+        int c = threadIdx.x + 256 * j;
+        int ly = c / HT, lx = c % HT;
+        int y = y0 + ly, x = x0 + lx;
+        z[j] = (y < H && x < W) ? dem[(long long)y * w.ld + x] : DT_NODATA;
+      }
+    }
     hy_stage<float>(s_w, wsurf, w, y0, x0, __builtin_inff());
+    if (fastio) {
+      uint32_t *sz32 = reinterpret_cast<uint32_t *>(s_z);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int i = (int)threadIdx.x + 256 * k;
+        uint32_t *d = sz32 + (i >> 4) * HZS + (i & 15) * 4;
+        d[0] = z4[k].x;
+        d[1] = z4[k].y;
+        d[2] = z4[k].z;
+        d[3] = z4[k].w;
+      }
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < HLD * HLS; i += 256)
       if (hy_nodata(s_w[i])) s_w[i] = __builtin_inff();  // (the pad column holds garbage nobody reads)
+  }
+  if (INIT || !fastio) {
 #pragma unroll
     for (int j = 0; j < H_CPT; j++) {
-      int c = threadIdx.x + 256 * j;
-      int ly = c / HT, lx = c % HT;
-      int y = y0 + ly, x = x0 + lx;
-      z[j] = (y < H && x < W) ? dem[(long long)y * w.ld + x] : DT_NODATA;
+      const int c = threadIdx.x + 256 * j;
+      s_z[(c / HT) * HZS + (c % HT)] = z[j];
     }
-  }
-#pragma unroll
-  for (int j = 0; j < H_CPT; j++) {
-    const int c = threadIdx.x + 256 * j;
-    s_z[(c / HT) * HZS + (c % HT)] = z[j];
   }
   __syncthreads();
   // DIRECTIONAL in-place sweeps (round 3; Jacobi sweeps to the tile's local fixed point before: one cell of progress
@@ -323,13 +435,29 @@ __global__ __launch_bounds__(256) void k_fill_relax(const float *__restrict__ de
   if (INIT) any = ring = 1;  // every cell is written, and the neighbours have yet to see this tile
   if (act_cur && threadIdx.x == 0) act_cur[tile] = (uint8_t)((ring ? HY_CHANGED : 0) | (open ? HY_OPEN : 0));
   if (!any) return;
+  if (fastio) {
+    // (a nodata cell holds DT_NODATA since the first round: writing it again changes nothing)
 #pragma unroll
-  for (int j = 0; j < H_CPT; j++) {
-    int c = threadIdx.x + 256 * j;
-    int y = y0 + c / HT, x = x0 + c % HT;
-    if (y < H && x < W) {
-      if (!hy_nodata(z[j])) wsurf[(long long)y * w.ld + x] = s_w[(c / HT + 1) * HLS + (c % HT) + 1];
-      else if (INIT) wsurf[(long long)y * w.ld + x] = DT_NODATA;
+    for (int k = 0; k < 4; k++) {
+      const int i = (int)threadIdx.x + 256 * k;
+      const int r = i >> 4, c4 = (i & 15) * 4;
+      const float *sw = s_w + (r + 1) * HLS + 1 + c4, *sz = s_z + r * HZS + c4;
+      float4 v;
+      v.x = hy_nodata(sz[0]) ? DT_NODATA : sw[0];
+      v.y = hy_nodata(sz[1]) ? DT_NODATA : sw[1];
+      v.z = hy_nodata(sz[2]) ? DT_NODATA : sw[2];
+      v.w = hy_nodata(sz[3]) ? DT_NODATA : sw[3];
+      *reinterpret_cast<float4 *>(wsurf + (long long)(y0 + r) * w.ld + x0 + c4) = v;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < H_CPT; j++) {
+      int c = threadIdx.x + 256 * j;
+      int y = y0 + c / HT, x = x0 + c % HT;
+      if (y < H && x < W) {
+        if (!hy_nodata(z[j])) wsurf[(long long)y * w.ld + x] = s_w[(c / HT + 1) * HLS + (c % HT) + 1];
+        else if (INIT) wsurf[(long long)y * w.ld + x] = DT_NODATA;
+      }
     }
   }
   if (threadIdx.x == 0) atomicOr(changed, 1);
@@ -479,8 +607,7 @@ __global__ __launch_bounds__(256) void k_flat_relax(const float *__restrict__ ws
     if (act_cur && threadIdx.x == 0) act_cur[tile] = 0;
     return;
   }
-  hy_stage<float>(s_w, wsurf, w, y0, x0, DT_NODATA);
-  hy_stage<uint32_t>(s_d, dist, w, y0, x0, H_INF_DIST);
+  hy_stage2<float, uint32_t>(s_w, wsurf, DT_NODATA, s_d, dist, H_INF_DIST, w, y0, x0);
   __syncthreads();
   // directional in-place sweeps, as k_fill_relax: distances only decrease, towards the same fixed point; rounds of four
   // sweeps until one changes nothing.  The heights never change, and the line a sweep comes from is in registers
@@ -501,11 +628,22 @@ __global__ __launch_bounds__(256) void k_flat_relax(const float *__restrict__ ws
   }
   if (act_cur && threadIdx.x == 0) act_cur[tile] = (uint8_t)((ring ? HY_CHANGED : 0) | (open ? HY_OPEN : 0));
   if (!any) return;
+  if (y0 + HT <= H && x0 + HT <= W && (w.ld & 3) == 0 && ((uintptr_t)dist & 15) == 0) {  // 16 bytes at a time
 #pragma unroll
-  for (int j = 0; j < H_CPT; j++) {
-    int c = threadIdx.x + 256 * j;
-    int y = y0 + c / HT, x = x0 + c % HT;
-    if (y < H && x < W) dist[(long long)y * w.ld + x] = s_d[(c / HT + 1) * HLS + (c % HT) + 1];
+    for (int k = 0; k < 4; k++) {
+      const int i = (int)threadIdx.x + 256 * k;
+      const int r = i >> 4, c4 = (i & 15) * 4;
+      const uint32_t *sd = s_d + (r + 1) * HLS + 1 + c4;
+      hy_v4u v = {sd[0], sd[1], sd[2], sd[3]};
+      *reinterpret_cast<hy_v4u *>(dist + (long long)(y0 + r) * w.ld + x0 + c4) = v;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < H_CPT; j++) {
+      int c = threadIdx.x + 256 * j;
+      int y = y0 + c / HT, x = x0 + c % HT;
+      if (y < H && x < W) dist[(long long)y * w.ld + x] = s_d[(c / HT + 1) * HLS + (c % HT) + 1];
+    }
   }
   if (threadIdx.x == 0) atomicOr(changed, 1);
 }
@@ -522,8 +660,8 @@ __global__ __launch_bounds__(256) void k_flat_assign(const float *__restrict__ w
   if (has_flat && has_flat[blockIdx.x] == 0) return;
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
   const int y0 = ty * HT, x0 = tx * HT;
-  hy_stage<float>(s_w, wsurf, w, y0, x0, DT_NODATA);       // beyond the raster: equal to no valid height
-  hy_stage<uint32_t>(s_d, dist, w, y0, x0, H_INF_DIST);
+  // (beyond the raster: equal to no valid height)
+  hy_stage2<float, uint32_t>(s_w, wsurf, DT_NODATA, s_d, dist, H_INF_DIST, w, y0, x0);
   __syncthreads();
   int bad = 0;
 #pragma unroll
