@@ -172,23 +172,27 @@ __device__ __forceinline__ void hy_tile_load(HyTileRegs &t, const void *src, con
     t.r2 = p32[(long long)(y0 - 1 + r) * w.ld + x0 - 1 + c];
   }
 }
+// NODATA_INF: a nodata height is stored as +inf (the fill's surface: nodata never lowers a minimum)
+template <bool NODATA_INF = false>
 __device__ __forceinline__ void hy_tile_store(const HyTileRegs &t, void *s) {
   uint32_t *s32 = reinterpret_cast<uint32_t *>(s);
+  const uint32_t nod = __float_as_uint(DT_NODATA), inf = __float_as_uint(__builtin_inff());
+  auto f = [&](uint32_t v) { return (NODATA_INF && v == nod) ? inf : v; };  // (-100.0f has one bit pattern)
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const int i = (int)threadIdx.x + 256 * k;
     uint32_t *d = s32 + ((i >> 4) + 1) * HLS + 1 + (i & 15) * 4;
-    d[0] = t.c[k].x;
-    d[1] = t.c[k].y;
-    d[2] = t.c[k].z;
-    d[3] = t.c[k].w;
+    d[0] = f(t.c[k].x);
+    d[1] = f(t.c[k].y);
+    d[2] = f(t.c[k].z);
+    d[3] = f(t.c[k].w);
   }
   int r, c;
   hy_ring_cell((int)threadIdx.x, r, c);
-  s32[r * HLS + c] = t.r1;
+  s32[r * HLS + c] = f(t.r1);
   if ((int)threadIdx.x + 256 < 2 * HLD + 2 * HT) {
     hy_ring_cell((int)threadIdx.x + 256, r, c);
-    s32[r * HLS + c] = t.r2;
+    s32[r * HLS + c] = f(t.r2);
   }
 }
 // the general form: cells outside the raster (or the rank's memory) read as `outside`
@@ -378,7 +382,14 @@ __global__ __launch_bounds__(256) void k_fill_relax(const float *__restrict__ de
         z[j] = (y < H && x < W) ? dem[(long long)y * w.ld + x] : DT_NODATA;
       }
     }
-    hy_stage<float>(s_w, wsurf, w, y0, x0, __builtin_inff());
+    const bool fast_w = hy_tile_fast(wsurf, w, y0, x0);
+    if (fast_w) {  // nodata -> +inf on the way into LDS: no pass over the LDS image and no barrier for it
+      HyTileRegs t;
+      hy_tile_load(t, wsurf, w, y0, x0);
+      hy_tile_store<true>(t, s_w);
+    } else {
+      hy_stage_slow<float>(s_w, wsurf, w, y0, x0, __builtin_inff());
+    }
     if (fastio) {
       uint32_t *sz32 = reinterpret_cast<uint32_t *>(s_z);
 #pragma unroll
@@ -391,9 +402,11 @@ __global__ __launch_bounds__(256) void k_fill_relax(const float *__restrict__ de
         d[3] = z4[k].w;
       }
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < HLD * HLS; i += 256)
-      if (hy_nodata(s_w[i])) s_w[i] = __builtin_inff();  // (the pad column holds garbage nobody reads)
+    if (!fast_w) {
+      __syncthreads();
+      for (int i = threadIdx.x; i < HLD * HLS; i += 256)
+        if (hy_nodata(s_w[i])) s_w[i] = __builtin_inff();  // (the pad column holds garbage nobody reads)
+    }
   }
   if (INIT || !fastio) {
 #pragma unroll
@@ -485,45 +498,77 @@ __global__ __launch_bounds__(256) void k_flat_init(const float *__restrict__ wsu
   __shared__ float s_w[HLD * HLS];
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
   const int y0 = ty * HT, x0 = tx * HT;
-  uint8_t f[H_CPT];  // the tile's codes, all loads in flight with the staging's
-#pragma unroll
-  for (int j = 0; j < H_CPT; j++) {
-    const int c = threadIdx.x + 256 * j;
-    const int y = y0 + c / HT, x = x0 + c % HT;
-    f[j] = (y < w.H && x < w.W) ? fdr[(long long)y * w.ld + x] : (uint8_t)1;
-  }
-  hy_stage<float>(s_w, wsurf, w, y0, x0, __builtin_inff());  // beyond the raster: not nodata (those cells got their
-  __syncthreads();                                           // outward code from the stencil), never equal to anything
+  // a code-less valid cell: distance "infinite", unless it lies next to nodata -- then it drains there right away
+  // (returns the cell's distance; *code != 0: the cell's new D8 code)
+  auto init_cell = [&](int p, uint32_t f, uint32_t *code) -> uint32_t {
+    *code = 0u;
+    if (hy_nodata(s_w[p]) || f != 0u) return 0u;
+    // scan order NW N NE W E SW S SE
+    uint32_t c = 0u;
+    if (hy_nodata(s_w[p - HLS - 1])) c = 32u;
+    else if (hy_nodata(s_w[p - HLS])) c = 64u;
+    else if (hy_nodata(s_w[p - HLS + 1])) c = 128u;
+    else if (hy_nodata(s_w[p - 1])) c = 16u;
+    else if (hy_nodata(s_w[p + 1])) c = 1u;
+    else if (hy_nodata(s_w[p + HLS - 1])) c = 8u;
+    else if (hy_nodata(s_w[p + HLS])) c = 4u;
+    else if (hy_nodata(s_w[p + HLS + 1])) c = 2u;
+    *code = c;
+    return c ? 0u : H_INF_DIST;
+  };
   int any = 0;
+  // block-uniform: a whole tile of aligned rows -- four codes per 32-bit load, four distances per 16-byte store
+  const bool fast = y0 + HT <= w.H && x0 + HT <= w.W && (w.ld & 3) == 0 && ((uintptr_t)fdr & 3) == 0 &&
+                    ((uintptr_t)dist & 15) == 0;
+  if (fast) {
+    uint32_t f4[4];  // the tile's codes, all loads in flight with the staging's
 #pragma unroll
-  for (int j = 0; j < H_CPT; j++) {
-    const int c = threadIdx.x + 256 * j;
-    const int ly = c / HT, lx = c % HT;
-    const int y = y0 + ly, x = x0 + lx;
-    if (y >= w.H || x >= w.W) continue;
-    const long long o = (long long)y * w.ld + x;
-    const int p = (ly + 1) * HLS + lx + 1;
-    uint32_t d = 0u;
-    if (!hy_nodata(s_w[p]) && f[j] == 0) {
-      d = H_INF_DIST;
-      // scan order NW N NE W E SW S SE
-      uint32_t code = 0u;
-      if (hy_nodata(s_w[p - HLS - 1])) code = 32u;
-      else if (hy_nodata(s_w[p - HLS])) code = 64u;
-      else if (hy_nodata(s_w[p - HLS + 1])) code = 128u;
-      else if (hy_nodata(s_w[p - 1])) code = 16u;
-      else if (hy_nodata(s_w[p + 1])) code = 1u;
-      else if (hy_nodata(s_w[p + HLS - 1])) code = 8u;
-      else if (hy_nodata(s_w[p + HLS])) code = 4u;
-      else if (hy_nodata(s_w[p + HLS + 1])) code = 2u;
-      if (code) {
-        fdr[o] = (uint8_t)code;
-        d = 0u;
-      } else {
-        any = 1;
-      }
+    for (int k = 0; k < 4; k++) {
+      const int i = (int)threadIdx.x + 256 * k;
+      f4[k] = *reinterpret_cast<const uint32_t *>(fdr + (long long)(y0 + (i >> 4)) * w.ld + x0 + (i & 15) * 4);
     }
-    dist[o] = d;
+    hy_stage<float>(s_w, wsurf, w, y0, x0, __builtin_inff());
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int i = (int)threadIdx.x + 256 * k;
+      const int r = i >> 4, c4 = (i & 15) * 4;
+      const long long o = (long long)(y0 + r) * w.ld + x0 + c4;
+      uint32_t d[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        uint32_t code;
+        d[q] = init_cell((r + 1) * HLS + 1 + c4 + q, (f4[k] >> (8 * q)) & 0xFFu, &code);
+        if (code) fdr[o + q] = (uint8_t)code;
+        any |= d[q] == H_INF_DIST ? 1 : 0;
+      }
+      hy_v4u v = {d[0], d[1], d[2], d[3]};
+      *reinterpret_cast<hy_v4u *>(dist + o) = v;
+    }
+  } else {
+    uint8_t f[H_CPT];
+#pragma unroll
+    for (int j = 0; j < H_CPT; j++) {
+      const int c = threadIdx.x + 256 * j;
+      const int y = y0 + c / HT, x = x0 + c % HT;
+      f[j] = (y < w.H && x < w.W) ? fdr[(long long)y * w.ld + x] : (uint8_t)1;
+    }
+    // (beyond the raster: not nodata -- those cells got their outward code from the stencil --, never equal to anything)
+    hy_stage<float>(s_w, wsurf, w, y0, x0, __builtin_inff());
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < H_CPT; j++) {
+      const int c = threadIdx.x + 256 * j;
+      const int ly = c / HT, lx = c % HT;
+      const int y = y0 + ly, x = x0 + lx;
+      if (y >= w.H || x >= w.W) continue;
+      const long long o = (long long)y * w.ld + x;
+      uint32_t code;
+      const uint32_t d = init_cell((ly + 1) * HLS + lx + 1, f[j], &code);
+      if (code) fdr[o] = (uint8_t)code;
+      any |= d == H_INF_DIST ? 1 : 0;
+      dist[o] = d;
+    }
   }
   any = __syncthreads_or(any);
   // (read as the activity byte of "round -1" by the first relaxation round: the tile itself is open, its neighbours
