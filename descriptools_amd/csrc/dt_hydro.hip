@@ -135,12 +135,16 @@ __global__ __launch_bounds__(256) void k_fill_init(const float *__restrict__ dem
 }
 
 // ---- staging a tile's 66 x 66 window into LDS ---------------------------------------------------------------------
-// The common case -- a tile inside the raster, rows aligned to 16 bytes -- takes the 64 x 64 core as 16-byte loads (four
+// The common case -- a tile whose window lies inside the raster -- takes the 64 x 64 core as 16-byte loads (four
 // per thread) and the ring around it as one or two 4-byte loads: six load instructions per thread where the 66-wide
 // rows, which start one cell before a 256-byte boundary, took eighteen (bare reads: 6.3 instead of 3.8 TB/s,
 // profiles/r4/micro_tile_read.txt).  Loads and LDS stores are separate functions so that a kernel that stages two
 // rasters (or a raster and the tile's heights) has ALL its loads in flight before it waits for the first.
 typedef uint32_t hy_v4u __attribute__((ext_vector_type(4)));
+// the same for rows that are only 4-byte aligned (a raster whose width is not a multiple of 4: the Example's 1534):
+// global memory takes a 16-byte access at any 4-byte address
+typedef uint32_t hy_v4u_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef float hy_v4f_a4 __attribute__((ext_vector_type(4), aligned(4)));
 struct HyTileRegs {
   hy_v4u c[4];
   uint32_t r1, r2;
@@ -151,17 +155,16 @@ __device__ __forceinline__ void hy_ring_cell(int j, int &r, int &c) {  // 66 abo
   else if (j < 2 * HLD + HT) { r = j - 2 * HLD + 1; c = 0; }
   else { r = j - 2 * HLD - HT + 1; c = HLD - 1; }
 }
-// block-uniform: the whole window is readable and the core's rows can be read 16 bytes at a time
+// block-uniform: the whole window is readable (the core's rows are then read 16 bytes at a time)
 __device__ __forceinline__ bool hy_tile_fast(const void *src, const DtWin &w, int y0, int x0) {
-  return dt_readable(w, y0 - 1, x0 - 1) && dt_readable(w, y0 + HT, x0 + HT) && (w.ld & 3) == 0 && (x0 & 3) == 0 &&
-         ((uintptr_t)src & 15) == 0;
+  return dt_readable(w, y0 - 1, x0 - 1) && dt_readable(w, y0 + HT, x0 + HT) && ((uintptr_t)src & 3) == 0;
 }
 __device__ __forceinline__ void hy_tile_load(HyTileRegs &t, const void *src, const DtWin &w, int y0, int x0) {
   const uint32_t *__restrict__ p32 = reinterpret_cast<const uint32_t *>(src);
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const int i = (int)threadIdx.x + 256 * k;  // 16 groups of four cells per row
-    t.c[k] = *reinterpret_cast<const hy_v4u *>(p32 + (long long)(y0 + (i >> 4)) * w.ld + x0 + (i & 15) * 4);
+    t.c[k] = *reinterpret_cast<const hy_v4u_a4 *>(p32 + (long long)(y0 + (i >> 4)) * w.ld + x0 + (i & 15) * 4);
   }
   int r, c;
   hy_ring_cell((int)threadIdx.x, r, c);
@@ -332,9 +335,8 @@ __global__ __launch_bounds__(256) void k_fill_relax(const float *__restrict__ de
   // outside the raster and nodata both read as +inf: they never lower a minimum (cells next to them are outlets
   // and already hold their final value)
   float z[H_CPT];
-  // block-uniform: a whole tile of 16-byte aligned rows -- heights in and surface out go 16 bytes at a time
-  const bool fastio = y0 + HT <= H && x0 + HT <= W && (w.ld & 3) == 0 && ((uintptr_t)dem & 15) == 0 &&
-                      ((uintptr_t)wsurf & 15) == 0;
+  // block-uniform: a whole tile -- heights in and surface out go 16 bytes at a time
+  const bool fastio = y0 + HT <= H && x0 + HT <= W;
   if (INIT) {
     // the HEIGHTS of the window: a cell is an outlet when it lies on the raster's edge or has a nodata neighbour
     // (cells beyond the raster are staged as +inf: not nodata)
@@ -371,7 +373,7 @@ __global__ __launch_bounds__(256) void k_fill_relax(const float *__restrict__ de
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         const int i = (int)threadIdx.x + 256 * k;
-        z4[k] = *reinterpret_cast<const hy_v4u *>(dem + (long long)(y0 + (i >> 4)) * w.ld + x0 + (i & 15) * 4);
+        z4[k] = *reinterpret_cast<const hy_v4u_a4 *>(dem + (long long)(y0 + (i >> 4)) * w.ld + x0 + (i & 15) * 4);
       }
     } else {
 #pragma unroll
@@ -455,12 +457,12 @@ __global__ __launch_bounds__(256) void k_fill_relax(const float *__restrict__ de
       const int i = (int)threadIdx.x + 256 * k;
       const int r = i >> 4, c4 = (i & 15) * 4;
       const float *sw = s_w + (r + 1) * HLS + 1 + c4, *sz = s_z + r * HZS + c4;
-      float4 v;
+      hy_v4f_a4 v;
       v.x = hy_nodata(sz[0]) ? DT_NODATA : sw[0];
       v.y = hy_nodata(sz[1]) ? DT_NODATA : sw[1];
       v.z = hy_nodata(sz[2]) ? DT_NODATA : sw[2];
       v.w = hy_nodata(sz[3]) ? DT_NODATA : sw[3];
-      *reinterpret_cast<float4 *>(wsurf + (long long)(y0 + r) * w.ld + x0 + c4) = v;
+      *reinterpret_cast<hy_v4f_a4 *>(wsurf + (long long)(y0 + r) * w.ld + x0 + c4) = v;
     }
   } else {
 #pragma unroll
@@ -518,8 +520,7 @@ __global__ __launch_bounds__(256) void k_flat_init(const float *__restrict__ wsu
   };
   int any = 0;
   // block-uniform: a whole tile of aligned rows -- four codes per 32-bit load, four distances per 16-byte store
-  const bool fast = y0 + HT <= w.H && x0 + HT <= w.W && (w.ld & 3) == 0 && ((uintptr_t)fdr & 3) == 0 &&
-                    ((uintptr_t)dist & 15) == 0;
+  const bool fast = y0 + HT <= w.H && x0 + HT <= w.W && (w.ld & 3) == 0 && ((uintptr_t)fdr & 3) == 0;
   if (fast) {
     uint32_t f4[4];  // the tile's codes, all loads in flight with the staging's
 #pragma unroll
@@ -542,8 +543,8 @@ __global__ __launch_bounds__(256) void k_flat_init(const float *__restrict__ wsu
         if (code) fdr[o + q] = (uint8_t)code;
         any |= d[q] == H_INF_DIST ? 1 : 0;
       }
-      hy_v4u v = {d[0], d[1], d[2], d[3]};
-      *reinterpret_cast<hy_v4u *>(dist + o) = v;
+      hy_v4u_a4 v = {d[0], d[1], d[2], d[3]};
+      *reinterpret_cast<hy_v4u_a4 *>(dist + o) = v;
     }
   } else {
     uint8_t f[H_CPT];
@@ -673,14 +674,14 @@ __global__ __launch_bounds__(256) void k_flat_relax(const float *__restrict__ ws
   }
   if (act_cur && threadIdx.x == 0) act_cur[tile] = (uint8_t)((ring ? HY_CHANGED : 0) | (open ? HY_OPEN : 0));
   if (!any) return;
-  if (y0 + HT <= H && x0 + HT <= W && (w.ld & 3) == 0 && ((uintptr_t)dist & 15) == 0) {  // 16 bytes at a time
+  if (y0 + HT <= H && x0 + HT <= W) {  // 16 bytes at a time
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int i = (int)threadIdx.x + 256 * k;
       const int r = i >> 4, c4 = (i & 15) * 4;
       const uint32_t *sd = s_d + (r + 1) * HLS + 1 + c4;
-      hy_v4u v = {sd[0], sd[1], sd[2], sd[3]};
-      *reinterpret_cast<hy_v4u *>(dist + (long long)(y0 + r) * w.ld + x0 + c4) = v;
+      hy_v4u_a4 v = {sd[0], sd[1], sd[2], sd[3]};
+      *reinterpret_cast<hy_v4u_a4 *>(dist + (long long)(y0 + r) * w.ld + x0 + c4) = v;
     }
   } else {
 #pragma unroll
