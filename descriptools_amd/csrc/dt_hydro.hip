@@ -494,9 +494,11 @@ __device__ __forceinline__ void hy_scan_delta(int k, int &dy, int &dx) {
 // 64 x 64 tile with the surface staged in LDS (round 4; one thread per cell on global memory before: 2.4 ms at
 // 16384^2, up to 9 scattered loads per code-less cell); has_flat[tile] (may be NULL) = the tile has cells that need a
 // distance: the relaxation rounds and the assignment never look at the others.
+// nsame (may be NULL; single rasters): one byte per cell, bit k (scan order NW N NE W E SW S SE) SET when neighbour k
+// does NOT have the cell's height (0xFF for nodata) -- all the relaxation rounds need of the surface: k_flat_relax_m
 __global__ __launch_bounds__(256) void k_flat_init(const float *__restrict__ wsurf, uint8_t *__restrict__ fdr, DtWin w,
                                                   uint32_t *__restrict__ dist, int tiles_x,
-                                                  uint8_t *__restrict__ has_flat) {
+                                                  uint8_t *__restrict__ has_flat, uint8_t *__restrict__ nsame) {
   __shared__ float s_w[HLD * HLS];
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
   const int y0 = ty * HT, x0 = tx * HT;
@@ -517,6 +519,13 @@ __global__ __launch_bounds__(256) void k_flat_init(const float *__restrict__ wsu
     else if (hy_nodata(s_w[p + HLS + 1])) c = 2u;
     *code = c;
     return c ? 0u : H_INF_DIST;
+  };
+  auto nsame_of = [&](int p) -> uint32_t {
+    const float wc = s_w[p];
+    if (hy_nodata(wc)) return 0xFFu;
+    return (s_w[p - HLS - 1] == wc ? 0u : 1u) | (s_w[p - HLS] == wc ? 0u : 2u) | (s_w[p - HLS + 1] == wc ? 0u : 4u) |
+           (s_w[p - 1] == wc ? 0u : 8u) | (s_w[p + 1] == wc ? 0u : 16u) | (s_w[p + HLS - 1] == wc ? 0u : 32u) |
+           (s_w[p + HLS] == wc ? 0u : 64u) | (s_w[p + HLS + 1] == wc ? 0u : 128u);
   };
   int any = 0;
   // block-uniform: a whole tile of aligned rows -- four codes per 32-bit load, four distances per 16-byte store
@@ -545,6 +554,11 @@ __global__ __launch_bounds__(256) void k_flat_init(const float *__restrict__ wsu
       }
       hy_v4u_a4 v = {d[0], d[1], d[2], d[3]};
       *reinterpret_cast<hy_v4u_a4 *>(dist + o) = v;
+      if (nsame) {
+        const int p = (r + 1) * HLS + 1 + c4;
+        *reinterpret_cast<uint32_t *>(nsame + o) = nsame_of(p) | (nsame_of(p + 1) << 8) | (nsame_of(p + 2) << 16) |
+                                                   (nsame_of(p + 3) << 24);
+      }
     }
   } else {
     uint8_t f[H_CPT];
@@ -569,6 +583,7 @@ __global__ __launch_bounds__(256) void k_flat_init(const float *__restrict__ wsu
       if (code) fdr[o] = (uint8_t)code;
       any |= d == H_INF_DIST ? 1 : 0;
       dist[o] = d;
+      if (nsame) nsame[o] = (uint8_t)nsame_of((ly + 1) * HLS + lx + 1);
     }
   }
   any = __syncthreads_or(any);
@@ -694,6 +709,159 @@ __global__ __launch_bounds__(256) void k_flat_relax(const float *__restrict__ ws
   if (threadIdx.x == 0) atomicOr(changed, 1);
 }
 
+// ---- the flat rounds of a single raster: k_flat_relax without the surface -----------------------------------------
+// The heights never change during the flat rounds, and a step uses them only to ask which neighbours have the cell's
+// height: k_flat_init leaves that as one byte per cell (`nsame`), and a visit stages the distances (with their halo)
+// and the tile's 4 KiB of bytes instead of two 17 KiB windows -- 9 instead of 12 bytes of traffic per cell, and 21.5
+// instead of 34.5 KiB of LDS: seven workgroups per CU where the two windows allowed four (a visit is a chain of memory
+// round trips: what hides it is workgroups in flight).
+#define HMS (HT + 1) /* row stride of the byte tile: odd, so that a sweep with a lane per row spreads over the banks */
+template <bool BY_ROWS, int DIR>
+__device__ __forceinline__ int hy_flat_sweep_m(const uint8_t *__restrict__ s_m, uint32_t *__restrict__ s_d, int lane) {
+  constexpr int SA = BY_ROWS ? DIR * HLS : DIR, SC = BY_ROWS ? 1 : HLS;
+  constexpr int MA = BY_ROWS ? DIR * HMS : DIR;
+  constexpr int K0 = DIR < 0 ? HT - 1 : 0;
+  // which bit of the byte (NW N NE W E SW S SE) speaks of the cell before me in the lane before mine, before me, ...
+  constexpr int B_UM = BY_ROWS ? (DIR > 0 ? 0 : 5) : (DIR > 0 ? 0 : 2), B_U = BY_ROWS ? (DIR > 0 ? 1 : 6) : (DIR > 0 ? 3 : 4),
+                B_UP = BY_ROWS ? (DIR > 0 ? 2 : 7) : (DIR > 0 ? 5 : 7), B_LF = BY_ROWS ? 3 : 1, B_RT = BY_ROWS ? 4 : 6,
+                B_D0 = BY_ROWS ? (DIR > 0 ? 5 : 0) : (DIR > 0 ? 2 : 0), B_D1 = BY_ROWS ? (DIR > 0 ? 6 : 1) : (DIR > 0 ? 4 : 3),
+                B_D2 = BY_ROWS ? (DIR > 0 ? 7 : 2) : (DIR > 0 ? 7 : 5);
+  auto dpp_prev = [](uint32_t edge, uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x138, 0xF, 0xF, false);
+  };
+  auto dpp_next = [](uint32_t edge, uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x130, 0xF, 0xF, false);
+  };
+  // a neighbour of another height counts as infinitely far: its distance OR H_INF_DIST (all the bits a distance has)
+  static_assert(H_INF_DIST == 0x7FFFFFFFu, "the masking below");
+  auto far = [](uint32_t mk, int bit, uint32_t d) {
+    return d | ((uint32_t)__builtin_amdgcn_sbfe((int)mk, bit, 1) & H_INF_DIST);  // (one v_bfe_i32, one v_and_or_b32)
+  };
+  int p = BY_ROWS ? (K0 + 1) * HLS + lane + 1 : (lane + 1) * HLS + K0 + 1;
+  int mi = BY_ROWS ? K0 * HMS + lane : lane * HMS + K0;
+  uint32_t du = s_d[p - SA], dhl = s_d[p - SA - SC], dhr = s_d[p - SA + SC];
+  uint32_t dcur = s_d[p], dlf = s_d[p - SC], drt = s_d[p + SC];
+  const bool on_side = lane == 0 || lane == HT - 1;
+  int ch = 0;
+#pragma unroll 4
+  for (int step = 0; step < HT; step++) {
+    int pf = p;  // (see hy_fill_sweep: the fresh read must not be merged with the value fetched a step earlier)
+    asm volatile("" : "+v"(pf));
+    const uint32_t fresh = s_d[pf];
+    const uint32_t d0 = s_d[p + SA - SC], d1 = s_d[p + SA], d2 = s_d[p + SA + SC];
+    const uint32_t mk = s_m[mi];
+    const uint32_t dum = dpp_prev(dhl, du), dup = dpp_next(dhr, du);
+    // The line the sweep comes from and the two cells beside this one: five of the eight neighbours.  The three of the
+    // line ahead hold values this sweep has not touched yet -- the sweep in the opposite direction relaxes against
+    // them -- and between them the four sweeps of a visit look at every neighbour (each diagonal twice), so a visit
+    // that changes nothing still proves the tile's fixed point.  The kernel is bound by vector issue: 45 -> 36
+    // instructions per step.
+    uint32_t m = min(min(far(mk, B_UM, dum), far(mk, B_U, du)), min(far(mk, B_UP, dup), far(mk, B_LF, dlf)));
+    m = min(m, far(mk, B_RT, drt));
+    (void)B_D0;
+    (void)B_D1;
+    (void)B_D2;
+    // coded cells (0) and cells next to one (1) are final; nodata and the cells beyond the raster have no neighbour of
+    // "their height" (all bits set)
+    const bool lower = dcur > 1u && m != H_INF_DIST;
+    const uint32_t nd = m + 1u;
+    if (lower && nd < fresh) {
+      s_d[p] = nd;
+      ch |= (on_side || step == 0 || step == HT - 1) ? 3 : 1;  // bit 1: a cell of the tile's outer ring
+    }
+    du = (lower && nd < dcur) ? nd : dcur;  // what this lane leaves behind
+    dhl = dlf;
+    dhr = drt;
+    dcur = d1;
+    dlf = d0;
+    drt = d2;
+    p += SA;
+    mi += MA;
+  }
+  return ch;
+}
+__global__ __launch_bounds__(256) void k_flat_relax_m(const uint8_t *__restrict__ nsame, uint32_t *__restrict__ dist,
+                                                     DtWin w, int tiles_x, int *__restrict__ changed,
+                                                     const int *__restrict__ prev,
+                                                     const uint8_t *__restrict__ act_prev,
+                                                     uint8_t *__restrict__ act_cur, int tiles_y, int sweeps, int colour) {
+  const int H = w.H, W = w.W;
+  __shared__ uint32_t s_d[HLD * HLS];
+  __shared__ uint8_t s_m[HT * HMS + 3];
+  if (prev && *prev == 0) return;  // (a plain scalar load: see k_fill_relax)
+  int ty, tx;
+  hy_tile_of_block(colour, tiles_x, ty, tx);  // (coloured rounds: see hy_tile_of_block)
+  const int tile = ty * tiles_x + tx;
+  const int y0 = ty * HT, x0 = tx * HT;
+  if (!hy_tile_active(act_prev, ty, tx, tiles_x, tiles_y)) {
+    if (act_cur && threadIdx.x == 0) act_cur[tile] = 0;
+    return;
+  }
+  // the tile's bytes: four cells per thread and load, all in flight with the distances'
+  const bool whole = y0 + HT <= H && x0 + HT <= W;
+  uint32_t mk4[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int i = (int)threadIdx.x + 256 * k;
+    const int r = i >> 4, c4 = (i & 15) * 4;
+    const uint8_t *src = nsame + (long long)(y0 + r) * w.ld + x0 + c4;
+    if (whole && (w.ld & 3) == 0 && ((uintptr_t)nsame & 3) == 0) {
+      mk4[k] = *reinterpret_cast<const uint32_t *>(src);
+    } else {
+      mk4[k] = 0xFFFFFFFFu;  // beyond the raster: no neighbour of "their height"
+      if (y0 + r < H) {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          if (x0 + c4 + q < W) mk4[k] = (mk4[k] & ~(0xFFu << (8 * q))) | ((uint32_t)src[q] << (8 * q));
+      }
+    }
+  }
+  hy_stage<uint32_t>(s_d, dist, w, y0, x0, H_INF_DIST);
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int i = (int)threadIdx.x + 256 * k;
+    uint8_t *d = s_m + (i >> 4) * HMS + (i & 15) * 4;
+    d[0] = (uint8_t)mk4[k];
+    d[1] = (uint8_t)(mk4[k] >> 8);
+    d[2] = (uint8_t)(mk4[k] >> 16);
+    d[3] = (uint8_t)(mk4[k] >> 24);
+  }
+  __syncthreads();
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  int any = 0, open = 0, ring = 0;
+  for (int it = 0; it < sweeps; it++) {
+    int ch;
+    if (wave == 0) ch = hy_flat_sweep_m<true, 1>(s_m, s_d, lane);
+    else if (wave == 1) ch = hy_flat_sweep_m<true, -1>(s_m, s_d, lane);
+    else if (wave == 2) ch = hy_flat_sweep_m<false, 1>(s_m, s_d, lane);
+    else ch = hy_flat_sweep_m<false, -1>(s_m, s_d, lane);
+    open = __syncthreads_or(ch);
+    if (!open) break;
+    any = 1;
+    ring |= __syncthreads_or(ch & 2);
+  }
+  if (act_cur && threadIdx.x == 0) act_cur[tile] = (uint8_t)((ring ? HY_CHANGED : 0) | (open ? HY_OPEN : 0));
+  if (!any) return;
+  if (whole) {  // 16 bytes at a time
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int i = (int)threadIdx.x + 256 * k;
+      const int r = i >> 4, c4 = (i & 15) * 4;
+      const uint32_t *sd = s_d + (r + 1) * HLS + 1 + c4;
+      hy_v4u_a4 v = {sd[0], sd[1], sd[2], sd[3]};
+      *reinterpret_cast<hy_v4u_a4 *>(dist + (long long)(y0 + r) * w.ld + x0 + c4) = v;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < H_CPT; j++) {
+      int c = threadIdx.x + 256 * j;
+      int y = y0 + c / HT, x = x0 + c % HT;
+      if (y < H && x < W) dist[(long long)y * w.ld + x] = s_d[(c / HT + 1) * HLS + (c % HT) + 1];
+    }
+  }
+  if (threadIdx.x == 0) atomicOr(changed, 1);
+}
+
 // flat cells point at a neighbour of the same filled height that is one hop closer: the first of N, W, E, S, else the
 // first of NW, NE, SW, SE.  One workgroup per tile that has flat cells, surface and distances staged in LDS (round 4;
 // one thread per cell with up to 16 scattered loads before: 5.3 ms at 16384^2).
@@ -743,8 +911,10 @@ __global__ __launch_bounds__(256) void k_flat_assign(const float *__restrict__ w
 #define DT_HYDRO_MAX_ASYNC_ROUNDS 500
 static size_t hy_tiles(int64_t H, int64_t W) { return (size_t)((W + HT - 1) / HT) * (size_t)((H + HT - 1) / HT); }
 // flags | distance raster | two per-tile activity arrays (the rounds alternate between them) | has_flat per tile
+// | one byte per cell: which neighbours have another height (k_flat_init -> k_flat_relax_m)
 size_t dt_hydro_scratch(int64_t H, int64_t W) {
-  return DT_HYDRO_FLAG_BYTES + dt_align256((size_t)H * W * 4) + 3 * dt_align256(hy_tiles(H, W));
+  return DT_HYDRO_FLAG_BYTES + dt_align256((size_t)H * W * 4) + 3 * dt_align256(hy_tiles(H, W)) +
+         dt_align256((size_t)H * W);
 }
 
 // raise the context's status when the budget of rounds did not reach the fixed point, or a flat cell got no code
@@ -819,17 +989,17 @@ static void hy_fill_round(hipStream_t s, bool coloured, int64_t r, const float *
 }
 // ... of the flat distances; has_flat: k_flat_init's per-tile flags, the activity the first round starts from (the
 // coloured form has them copied into act0 beforehand)
-static void hy_flat_round(hipStream_t s, bool coloured, int64_t r, const float *filled, uint32_t *dist, const DtWin &w,
+static void hy_flat_round(hipStream_t s, bool coloured, int64_t r, const uint8_t *nsame, uint32_t *dist, const DtWin &w,
                           int tiles_x, int tiles_y, int *f, const int *prev, uint8_t *act0, uint8_t *act1,
                           const uint8_t *has_flat, int sweeps) {
   const dim3 b(256);
   if (coloured) {
     for (int c = 0; c < 4; c++)
       if (hy_colour_blocks(c, tiles_x, tiles_y))
-        hipLaunchKernelGGL(k_flat_relax, dim3(hy_colour_blocks(c, tiles_x, tiles_y)), b, 0, s, filled, dist, w, tiles_x, f,
+        hipLaunchKernelGGL(k_flat_relax_m, dim3(hy_colour_blocks(c, tiles_x, tiles_y)), b, 0, s, nsame, dist, w, tiles_x, f,
                            prev, (const uint8_t *)act0, act0, tiles_y, sweeps, c);
   } else {
-    hipLaunchKernelGGL(k_flat_relax, dim3((unsigned)(tiles_x * tiles_y)), b, 0, s, filled, dist, w, tiles_x, f, prev,
+    hipLaunchKernelGGL(k_flat_relax_m, dim3((unsigned)(tiles_x * tiles_y)), b, 0, s, nsame, dist, w, tiles_x, f, prev,
                        r ? (const uint8_t *)((r - 1) & 1 ? act1 : act0) : has_flat, (r & 1) ? act1 : act0, tiles_y,
                        sweeps, -1);
   }
@@ -855,6 +1025,7 @@ int dt_launch_condition(hipStream_t s, const float *dem, int64_t H, int64_t W, d
   uint8_t *act = (uint8_t *)scratch + DT_HYDRO_FLAG_BYTES + dt_align256((size_t)n * 4);
   uint8_t *act1 = act + dt_align256(hy_tiles(H, W));
   uint8_t *has_flat = act + 2 * dt_align256(hy_tiles(H, W));
+  uint8_t *nsame = has_flat + dt_align256(hy_tiles(H, W));
   const bool coloured = hy_tiles(H, W) >= hy_colour_min();
   DT_TRY(hy_iterate(s, flag, max_rounds, [&](int *f, const int *prev, int64_t r) {
     hy_fill_round(s, coloured, r, dem, filled, w, tiles_x, tiles_y, f, prev, act, act1, fill_sweeps);
@@ -864,11 +1035,11 @@ int dt_launch_condition(hipStream_t s, const float *dem, int64_t H, int64_t W, d
     // of the chain's first op, 0.40 ms at 16384^2, instead of the generic stencil, 0.55)
     DT_TRY(dt_launch_stencil(s, w, filled, px, nullptr, fdr, nullptr, nullptr, 0, 0.0, nullptr, nullptr,
                              dt_stencil_aux_bytes(H, W) <= dt_align256((size_t)n * 4) ? (void *)dist : nullptr));
-    hipLaunchKernelGGL(k_flat_init, gt, b, 0, s, filled, fdr, w, dist, tiles_x, has_flat);
+    hipLaunchKernelGGL(k_flat_init, gt, b, 0, s, filled, fdr, w, dist, tiles_x, has_flat, nsame);
     // the rounds start from the tiles that have flat cells (and their neighbours), not from every tile
     if (coloured) DT_HIP(hipMemcpyAsync(act, has_flat, hy_tiles(H, W), hipMemcpyDeviceToDevice, s));
     DT_TRY(hy_iterate(s, flag, max_rounds, [&](int *f, const int *prev, int64_t r) {
-      hy_flat_round(s, coloured, r, filled, dist, w, tiles_x, tiles_y, f, prev, act, act1, has_flat, flat_sweeps);
+      hy_flat_round(s, coloured, r, nsame, dist, w, tiles_x, tiles_y, f, prev, act, act1, has_flat, flat_sweeps);
     }, &r2));
     DT_HIP(hipMemsetAsync(flag + 64, 0, sizeof(int), s));
     hipLaunchKernelGGL(k_flat_assign, gt, b, 0, s, filled, dist, w, fdr, flag + 64, tiles_x, (const uint8_t *)has_flat);
@@ -909,6 +1080,7 @@ int dt_launch_condition_async(hipStream_t s, const float *dem, int64_t H, int64_
   uint8_t *act = (uint8_t *)scratch + DT_HYDRO_FLAG_BYTES + dt_align256((size_t)n * 4);
   uint8_t *act1 = act + dt_align256(hy_tiles(H, W));
   uint8_t *has_flat = act + 2 * dt_align256(hy_tiles(H, W));
+  uint8_t *nsame = has_flat + dt_align256(hy_tiles(H, W));
   const bool coloured = hy_tiles(H, W) >= hy_colour_min();
   for (int r = 0; r < rounds; r++)
     hy_fill_round(s, coloured, r, dem, filled, w, tiles_x, tiles_y, flags + r, r ? (const int *)(flags + r - 1) : nullptr,
@@ -917,11 +1089,11 @@ int dt_launch_condition_async(hipStream_t s, const float *dem, int64_t H, int64_
     // of the chain's first op, 0.40 ms at 16384^2, instead of the generic stencil, 0.55)
     DT_TRY(dt_launch_stencil(s, w, filled, px, nullptr, fdr, nullptr, nullptr, 0, 0.0, nullptr, nullptr,
                              dt_stencil_aux_bytes(H, W) <= dt_align256((size_t)n * 4) ? (void *)dist : nullptr));
-  hipLaunchKernelGGL(k_flat_init, gt, b, 0, s, filled, fdr, w, dist, tiles_x, has_flat);
+  hipLaunchKernelGGL(k_flat_init, gt, b, 0, s, filled, fdr, w, dist, tiles_x, has_flat, nsame);
   if (coloured) DT_HIP(hipMemcpyAsync(act, has_flat, hy_tiles(H, W), hipMemcpyDeviceToDevice, s));
   int *fl2 = flags + rounds;
   for (int r = 0; r < rounds; r++)
-    hy_flat_round(s, coloured, r, filled, dist, w, tiles_x, tiles_y, fl2 + r, r ? (const int *)(fl2 + r - 1) : nullptr, act,
+    hy_flat_round(s, coloured, r, nsame, dist, w, tiles_x, tiles_y, fl2 + r, r ? (const int *)(fl2 + r - 1) : nullptr, act,
                   act1, has_flat, flat_sweeps);
   hipLaunchKernelGGL(k_flat_assign, gt, b, 0, s, filled, dist, w, fdr, flags + 2 * rounds, tiles_x,
                      (const uint8_t *)has_flat);
@@ -963,7 +1135,7 @@ int dt_launch_condition_stage(hipStream_t s, const DtWin &w, int stage, int roun
       break;
     case 2:
       DT_REQUIRE(filled && fdr && dist, "NULL pointer");
-      hipLaunchKernelGGL(k_flat_init, gt, b, 0, s, filled, fdr, w, dist, tiles_x, (uint8_t *)nullptr);
+      hipLaunchKernelGGL(k_flat_init, gt, b, 0, s, filled, fdr, w, dist, tiles_x, (uint8_t *)nullptr, (uint8_t *)nullptr);
       break;
     case 3:
       DT_REQUIRE(filled && dist && flag_dev, "NULL pointer");
