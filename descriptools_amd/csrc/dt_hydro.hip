@@ -904,6 +904,49 @@ __global__ __launch_bounds__(256) void k_flat_assign(const float *__restrict__ w
   if ((threadIdx.x & 63) == 0 && bad) atomicAdd(unresolved, bad);
 }
 
+// ... of a single raster: from the distances and k_flat_init's byte per cell (no surface: see k_flat_relax_m)
+__global__ __launch_bounds__(256) void k_flat_assign_m(const uint8_t *__restrict__ nsame, const uint32_t *__restrict__ dist,
+                                                      DtWin w, uint8_t *__restrict__ fdr, int *__restrict__ unresolved,
+                                                      int tiles_x, const uint8_t *__restrict__ has_flat) {
+  __shared__ uint32_t s_d[HLD * HLS];
+  if (has_flat && has_flat[blockIdx.x] == 0) return;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int y0 = ty * HT, x0 = tx * HT;
+  uint8_t mk[H_CPT];  // (the bytes of the thread's cells, in flight with the staging's loads)
+#pragma unroll
+  for (int j = 0; j < H_CPT; j++) {
+    const int c = threadIdx.x + 256 * j;
+    const int y = y0 + c / HT, x = x0 + c % HT;
+    mk[j] = (y < w.H && x < w.W) ? nsame[(long long)y * w.ld + x] : (uint8_t)0xFF;
+  }
+  hy_stage<uint32_t>(s_d, dist, w, y0, x0, H_INF_DIST);
+  __syncthreads();
+  int bad = 0;
+#pragma unroll
+  for (int j = 0; j < H_CPT; j++) {
+    const int c = threadIdx.x + 256 * j;
+    const int ly = c / HT, lx = c % HT;
+    const int y = y0 + ly, x = x0 + lx;
+    if (y >= w.H || x >= w.W) continue;
+    const int p = (ly + 1) * HLS + lx + 1;
+    const uint32_t d = s_d[p];
+    if (d == 0u) continue;
+    uint32_t code = 0u;
+    if (d != H_INF_DIST) {
+      const uint32_t want = d - 1u, m = mk[j];
+#define HY_A(bit, off, c_) \
+  if (!code && !((m >> (bit)) & 1u) && s_d[p + (off)] == want) code = (c_);
+      HY_A(1, -HLS, 64u) HY_A(3, -1, 16u) HY_A(4, 1, 1u) HY_A(6, HLS, 4u)
+      HY_A(0, -HLS - 1, 32u) HY_A(2, -HLS + 1, 128u) HY_A(5, HLS - 1, 8u) HY_A(7, HLS + 1, 2u)
+#undef HY_A
+    }
+    if (!code) bad++;
+    fdr[(long long)y * w.ld + x] = (uint8_t)code;
+  }
+  for (int o = 32; o; o >>= 1) bad += __shfl_xor(bad, o);
+  if ((threadIdx.x & 63) == 0 && bad) atomicAdd(unresolved, bad);
+}
+
 // scratch: flag words + the distance raster
 // asynchronous form: the round flags (2 x up to DT_HYDRO_MAX_ASYNC_ROUNDS + the unresolved count) live in the
 // first 4 KiB
@@ -1042,7 +1085,8 @@ int dt_launch_condition(hipStream_t s, const float *dem, int64_t H, int64_t W, d
       hy_flat_round(s, coloured, r, nsame, dist, w, tiles_x, tiles_y, f, prev, act, act1, has_flat, flat_sweeps);
     }, &r2));
     DT_HIP(hipMemsetAsync(flag + 64, 0, sizeof(int), s));
-    hipLaunchKernelGGL(k_flat_assign, gt, b, 0, s, filled, dist, w, fdr, flag + 64, tiles_x, (const uint8_t *)has_flat);
+    hipLaunchKernelGGL(k_flat_assign_m, gt, b, 0, s, (const uint8_t *)nsame, dist, w, fdr, flag + 64, tiles_x,
+                       (const uint8_t *)has_flat);
     int u = 0;
     DT_HIP(hipMemcpyAsync(&u, flag + 64, sizeof(int), hipMemcpyDeviceToHost, s));
     DT_HIP(hipStreamSynchronize(s));
@@ -1095,7 +1139,7 @@ int dt_launch_condition_async(hipStream_t s, const float *dem, int64_t H, int64_
   for (int r = 0; r < rounds; r++)
     hy_flat_round(s, coloured, r, nsame, dist, w, tiles_x, tiles_y, fl2 + r, r ? (const int *)(fl2 + r - 1) : nullptr, act,
                   act1, has_flat, flat_sweeps);
-  hipLaunchKernelGGL(k_flat_assign, gt, b, 0, s, filled, dist, w, fdr, flags + 2 * rounds, tiles_x,
+  hipLaunchKernelGGL(k_flat_assign_m, gt, b, 0, s, (const uint8_t *)nsame, dist, w, fdr, flags + 2 * rounds, tiles_x,
                      (const uint8_t *)has_flat);
   hipLaunchKernelGGL(k_hydro_verdict, dim3(1), dim3(1), 0, s, (const int *)(flags + rounds - 1),
                      (const int *)(fl2 + rounds - 1), (const int *)(flags + 2 * rounds), status);
