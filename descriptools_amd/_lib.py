@@ -50,6 +50,7 @@ _SIGS = {
     "dt_dev_condition_d8": (ci, [vp, vp, i64, i64, f64, vp, vp, c_i32p]),
     "dt_dev_condition_d8_async": (ci, [vp, vp, i64, i64, f64, vp, vp, ci]),
     "dt_dev_condition_stage_w": (ci, [vp, vp, ci, ci, vp, vp, vp, vp, vp]),
+    "dt_dev_condition_stage_m_w": (ci, [vp, vp, ci, ci, vp, vp, vp, vp, vp, vp]),
     "dt_flowhand": (ci, [c_f32p, c_u8p, c_i8p, i64, i64, f64, c_f32p, c_i64p, c_f32p]),
     "dt_hand_f32": (ci, [c_f32p, c_i64p, i64, c_f32p]),
     "dt_twi": (ci, [c_i64p, c_f32p, i64, f64, f64, c_f32p, c_f32p]),

@@ -466,6 +466,20 @@ extern "C" int dt_dev_condition_stage_w(dt_ctx *c, const dt_window *win, int sta
   return DT_OK;
 }
 
+// ... with a byte raster `nsame` (laid out like the others, the library's between stage 2 and stage 4): the flat stages
+// then work from one byte per cell instead of the surface -- less traffic and LDS per tile visit
+extern "C" int dt_dev_condition_stage_m_w(dt_ctx *c, const dt_window *win, int stage, int rounds, const float *dem,
+                                          float *filled, uint8_t *fdr, uint32_t *dist, int32_t *flag_dev,
+                                          uint8_t *nsame) {
+  DT_CTX(c);
+  DtWin w;
+  DT_TRY(dt_convert_window(win, &w));
+  DT_REQUIRE(nsame != nullptr || stage < 2, "the byte raster is missing");
+  DT_TRY(dt_launch_condition_stage(c->stream, w, stage, rounds, dem, filled, fdr, dist, (int *)flag_dev, nsame));
+  DT_HIP(hipGetLastError());
+  return DT_OK;
+}
+
 extern "C" int dt_dev_flowacc(dt_ctx *c, const uint8_t *fdr, const float *dem, int64_t H, int64_t W,
                               int32_t *acc32) {
   DT_CTX(c);

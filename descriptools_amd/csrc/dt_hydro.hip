@@ -1151,8 +1151,10 @@ int dt_launch_condition_async(hipStream_t s, const float *dem, int64_t H, int64_
 // stage 0 init of the surface, 1 `rounds` fill rounds, 2 init of the flat distances (after D8 on the surface),
 // 3 `rounds` flat rounds, 4 assignment of the flat cells' codes.  *flag_dev (device int, zeroed by the caller per
 // iteration) is raised by stages 1 / 3 when something changed, and counts the unresolved cells in stage 4.
+// nsame (optional; a uint8 raster laid out like the others): the flat stages run from the byte per cell that stage 2
+// leaves there instead of from the surface (k_flat_relax_m / k_flat_assign_m)
 int dt_launch_condition_stage(hipStream_t s, const DtWin &w, int stage, int rounds, const float *dem, float *filled,
-                              uint8_t *fdr, uint32_t *dist, int *flag_dev) {
+                              uint8_t *fdr, uint32_t *dist, int *flag_dev, uint8_t *nsame) {
   const int fill_sweeps = dt_debug_get(DT_DBG_HY_FILL_SWEEPS) > 0 ? dt_debug_get(DT_DBG_HY_FILL_SWEEPS) : HY_FILL_SWEEPS;
   const int flat_sweeps = dt_debug_get(DT_DBG_HY_FLAT_SWEEPS) > 0 ? dt_debug_get(DT_DBG_HY_FLAT_SWEEPS) : HY_FLAT_SWEEPS;
   (void)fill_sweeps;
@@ -1179,20 +1181,30 @@ int dt_launch_condition_stage(hipStream_t s, const DtWin &w, int stage, int roun
       break;
     case 2:
       DT_REQUIRE(filled && fdr && dist, "NULL pointer");
-      hipLaunchKernelGGL(k_flat_init, gt, b, 0, s, filled, fdr, w, dist, tiles_x, (uint8_t *)nullptr, (uint8_t *)nullptr);
+      hipLaunchKernelGGL(k_flat_init, gt, b, 0, s, filled, fdr, w, dist, tiles_x, (uint8_t *)nullptr, nsame);
       break;
     case 3:
       DT_REQUIRE(filled && dist && flag_dev, "NULL pointer");
       for (int r = 0; r < rounds; r++)
         for (int c = coloured ? 0 : -1; c < (coloured ? 4 : 0); c++)
-          if (hy_colour_blocks(c, tiles_x, tiles_y))
-            hipLaunchKernelGGL(k_flat_relax, dim3(hy_colour_blocks(c, tiles_x, tiles_y)), b, 0, s, filled, dist, w,
-                               tiles_x, flag_dev, (const int *)nullptr, (const uint8_t *)nullptr, (uint8_t *)nullptr,
-                               tiles_y, flat_sweeps, c);
+          if (hy_colour_blocks(c, tiles_x, tiles_y)) {
+            if (nsame)
+              hipLaunchKernelGGL(k_flat_relax_m, dim3(hy_colour_blocks(c, tiles_x, tiles_y)), b, 0, s,
+                                 (const uint8_t *)nsame, dist, w, tiles_x, flag_dev, (const int *)nullptr,
+                                 (const uint8_t *)nullptr, (uint8_t *)nullptr, tiles_y, flat_sweeps, c);
+            else
+              hipLaunchKernelGGL(k_flat_relax, dim3(hy_colour_blocks(c, tiles_x, tiles_y)), b, 0, s, filled, dist, w,
+                                 tiles_x, flag_dev, (const int *)nullptr, (const uint8_t *)nullptr, (uint8_t *)nullptr,
+                                 tiles_y, flat_sweeps, c);
+          }
       break;
     case 4:
       DT_REQUIRE(filled && dist && fdr && flag_dev, "NULL pointer");
-      hipLaunchKernelGGL(k_flat_assign, gt, b, 0, s, filled, dist, w, fdr, flag_dev, tiles_x, (const uint8_t *)nullptr);
+      if (nsame)
+        hipLaunchKernelGGL(k_flat_assign_m, gt, b, 0, s, (const uint8_t *)nsame, dist, w, fdr, flag_dev, tiles_x,
+                           (const uint8_t *)nullptr);
+      else
+        hipLaunchKernelGGL(k_flat_assign, gt, b, 0, s, filled, dist, w, fdr, flag_dev, tiles_x, (const uint8_t *)nullptr);
       break;
     default:
       DT_REQUIRE(false, "stage must be 0..4");

@@ -121,7 +121,7 @@ size_t dt_hydro_scratch(int64_t H, int64_t W);
 int dt_launch_condition(hipStream_t s, const float *dem, int64_t H, int64_t W, double px, float *filled, uint8_t *fdr,
                         void *scratch, int *unresolved_host, int *rounds_host);
 int dt_launch_condition_stage(hipStream_t s, const DtWin &w, int stage, int rounds, const float *dem, float *filled,
-                              uint8_t *fdr, uint32_t *dist, int *flag_dev);
+                              uint8_t *fdr, uint32_t *dist, int *flag_dev, uint8_t *nsame = nullptr);
 int dt_launch_condition_async(hipStream_t s, const float *dem, int64_t H, int64_t W, double px, float *filled,
                               uint8_t *fdr, void *scratch, int rounds, int *status);
 

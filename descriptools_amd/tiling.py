@@ -474,17 +474,20 @@ class RankTile:
             with self.on_stream():
                 self.t["filled"] = tc.zeros((self.He, self.We), dtype=tc.float32, device=self.dev)
                 self.t["dist"] = tc.zeros((self.He, self.We), dtype=tc.int32, device=self.dev)
+                # one byte per cell: which neighbours have another filled height (what the flat stages read instead of
+                # the surface: dt_dev_condition_stage_m_w)
+                self.t["nsame"] = tc.zeros((self.He, self.We), dtype=tc.uint8, device=self.dev)
                 self._cflag = tc.zeros(1, dtype=tc.int32, device=self.dev)
             self.ctx.sync()
 
     def cond_stage(self, stage, rounds=1):
-        """dt_dev_condition_stage_w on the core window; stages 1 / 3 / 4 start from a zeroed flag"""
+        """dt_dev_condition_stage_m_w on the core window; stages 1 / 3 / 4 start from a zeroed flag"""
         if stage in (1, 3, 4):
             with self.on_stream():
                 self._cflag.zero_()
-        self._chk(self.L.dt_dev_condition_stage_w(self.ctx.h, C.byref(self.win), stage, rounds, self.p("dem"),
-                                                  self.p("filled"), self.p("fdr"), self.p("dist"),
-                                                  self._cflag.data_ptr()))
+        self._chk(self.L.dt_dev_condition_stage_m_w(self.ctx.h, C.byref(self.win), stage, rounds, self.p("dem"),
+                                                    self.p("filled"), self.p("fdr"), self.p("dist"),
+                                                    self._cflag.data_ptr(), self.p("nsame")))
 
     def cond_flag(self):
         self.ctx.sync()

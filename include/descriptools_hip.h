@@ -327,6 +327,11 @@ int64_t dt_perim_cells(int64_t H, int64_t W);
  * number of cells left without a code after stage 4.  dist: uint32 raster laid out like the others. */
 int dt_dev_condition_stage_w(dt_ctx *ctx, const dt_window *win, int stage, int rounds, const float *dem, float *filled,
                              uint8_t *fdr, uint32_t *dist, int32_t *flag_dev);
+/* The same with a byte raster `nsame` (laid out like the others; the library's between stage 2 and stage 4): stage 2
+ * leaves one byte per cell there -- which neighbours have another filled height -- and stages 3 / 4 work from it instead
+ * of from the surface (less traffic and LDS per tile visit; same results). */
+int dt_dev_condition_stage_m_w(dt_ctx *ctx, const dt_window *win, int stage, int rounds, const float *dem, float *filled,
+                               uint8_t *fdr, uint32_t *dist, int32_t *flag_dev, uint8_t *nsame);
 int dt_dev_slope_d8_w(dt_ctx *ctx, const dt_window *win, const float *dem, double px, float *slope,
                       uint8_t *fdr, float *slope_rad);
 int dt_dev_slope_twi_w(dt_ctx *ctx, const dt_window *win, const float *dem, const int32_t *acc32, double px,
