@@ -1483,17 +1483,36 @@ __global__ __launch_bounds__(256) void k_dsw_scatter(const uint4 *__restrict__ r
                                                     const int32_t *__restrict__ counts, int nr,
                                                     int32_t *__restrict__ cursor, uint4 *__restrict__ send) {
   __shared__ int s_cnt[DSW_MAX_RANKS], s_base[DSW_MAX_RANKS];
-  for (int j = threadIdx.x; j < nr; j += 256) s_cnt[j] = 0;
+  for (int j = threadIdx.x; j < nr; j += 256) {
+    s_cnt[j] = 0;
+    s_base[j] = counts[j];
+  }
   __syncthreads();
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int d = i < n ? dest[i] : -1;
   int r = 0;
   if (d >= 0) r = atomicAdd(&s_cnt[d], 1);
-  __syncthreads();
+  // first slot of every rank's group: an exclusive scan of the counts (Hillis-Steele in LDS: log2(nr) steps, up to
+  // four entries per thread)
+  for (int step = 1; step < nr; step <<= 1) {
+    int t[DSW_MAX_RANKS / 256];
+#pragma unroll
+    for (int q = 0; q < DSW_MAX_RANKS / 256; q++) {
+      const int j = (int)threadIdx.x + 256 * q;
+      t[q] = (j < nr && j >= step) ? s_base[j - step] : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < DSW_MAX_RANKS / 256; q++) {
+      const int j = (int)threadIdx.x + 256 * q;
+      if (j < nr) s_base[j] += t[q];
+    }
+    __syncthreads();
+  }
+  // (inclusive -> exclusive, plus what the other workgroups have taken of the group)
   for (int j = threadIdx.x; j < nr; j += 256) {
-    int off = 0;  // first slot of rank j's group
-    for (int k = 0; k < j; k++) off += counts[k];
-    s_base[j] = off + (s_cnt[j] ? atomicAdd(&cursor[j], s_cnt[j]) : 0);
+    const int mine = s_cnt[j];
+    s_base[j] = s_base[j] - counts[j] + (mine ? atomicAdd(&cursor[j], mine) : 0);
   }
   __syncthreads();
   if (d >= 0) {

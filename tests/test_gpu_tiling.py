@@ -351,6 +351,73 @@ def test_two_phase_state_is_guarded():
     t.ctx.sync()
 
 
+def test_walker_records_are_routed_on_the_device_for_a_thousand_ranks():
+    """dt_dev_downslope_walk_route_w's classification and grouping alone, on a 32 x 31 layout (992 ranks; the scatter's
+    offsets are a scan over the counts): finished records whose start cell is this rank's are written into the raster
+    and dropped, finished ones of other ranks go to the owner of their start cell, walkers standing elsewhere to the
+    owner of the cell they stand on; counts and groups against numpy"""
+    import ctypes as C
+    import torch
+    from descriptools_amd import _lib
+    from descriptools_amd.device import Context
+    L = _lib.lib()
+    ty, tx, T = 32, 31, 64
+    Hg, Wg = ty * T, tx * T
+    rng = np.random.default_rng(8)
+    n = 60000
+    rec = np.zeros((n, 12), np.int32)
+    rec[:, 0], rec[:, 1] = rng.integers(T, Hg, n), rng.integers(0, Wg, n)        # start cells (not rank 0's)
+    rec[:, 2], rec[:, 3] = rng.integers(2 * T, Hg, n), rng.integers(0, Wg, n)    # standing far from rank 0's memory
+    done = rng.random(n) < 0.5
+    rec[:, 7] = np.where(done, 2, 0)
+    rec[:, 10] = rng.random(n).astype(np.float32).view(np.int32)
+    # a few finished records whose start cell is rank 0's own (distinct cells)
+    mine = rng.choice(T * T, 300, replace=False)
+    rec[:300, 0], rec[:300, 1], rec[:300, 7] = mine // T, mine % T, 2
+    done[:300] = True
+    ctx = Context()
+    dev = torch.device("cuda", 0)
+    ld = T + 2                                     # rank 0's window with a one-cell halo
+    win = _lib.Window(T, T, ld, 0, 0, Hg, Wg, 1)
+    dem = torch.zeros((ld, ld), dtype=torch.float32, device=dev)
+    fdr = torch.zeros((ld, ld), dtype=torch.uint8, device=dev)
+    out_ext = torch.full((ld, ld), -7.0, dtype=torch.float32, device=dev)
+    core = lambda t: t.data_ptr() + (ld + 1) * t.element_size()
+    out = out_ext[1:1 + T, 1:1 + T]
+    d_rec = torch.as_tensor(rec, device=dev).contiguous()
+    send = torch.zeros_like(d_rec)
+    rows = torch.as_tensor(np.arange(ty + 1, dtype=np.int32) * T, device=dev)
+    cols = torch.as_tensor(np.arange(tx + 1, dtype=np.int32) * T, device=dev)
+    counts = torch.zeros(ty * tx + 1, dtype=torch.int32, device=dev)
+    scratch = torch.zeros(n + ty * tx, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    _lib.check(L.dt_dev_downslope_walk_route_w(ctx.h, C.byref(win), core(dem), core(fdr), 10.0, 5.0, n,
+                                               d_rec.data_ptr(), None, 0, core(out_ext), rows.data_ptr(), ty,
+                                               cols.data_ptr(), tx, send.data_ptr(), counts.data_ptr(),
+                                               scratch.data_ptr()))
+    ctx.sync()
+    home = done & (rec[:, 0] < T) & (rec[:, 1] < T)
+    dest = np.where(done, (rec[:, 0] // T) * tx + rec[:, 1] // T, (rec[:, 2] // T) * tx + rec[:, 3] // T)
+    live = ~home
+    want_counts = np.bincount(dest[live], minlength=ty * tx)
+    got_counts = counts.cpu().numpy()
+    assert np.array_equal(got_counts[:-1], want_counts) and got_counts[-1] == int((~done).sum())
+    got_send = send.cpu().numpy()[:int(want_counts.sum())]
+    offs = np.concatenate([[0], np.cumsum(want_counts)])
+    key = lambda a: a[np.lexsort(a.T[::-1])]
+    for d in np.flatnonzero(want_counts)[::37]:  # (every 37th group, row for row)
+        seg = got_send[offs[d]:offs[d + 1]]
+        assert np.array_equal(key(seg), key(rec[live & (dest == d)])), d
+    g = got_send
+    gd = np.where((g[:, 7] & 2) != 0, (g[:, 0] // T) * tx + g[:, 1] // T, (g[:, 2] // T) * tx + g[:, 3] // T)
+    assert np.array_equal(gd, np.repeat(np.arange(ty * tx), want_counts)), "every row sits in its destination's group"
+    o = out.cpu().numpy()
+    assert np.array_equal(o[rec[home, 0], rec[home, 1]].view(np.int32), rec[home, 10])
+    assert int((o != -7.0).sum()) == len(np.unique(rec[home, 0] * T + rec[home, 1]))
+    ctx.close()
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("long_walks", [False, True])
 @pytest.mark.parametrize("heights,widths", [([256, 256], [384, 384]), ([512], [192, 320, 256])])
 def test_downslope_walks_across_rank_borders(heights, widths, long_walks):
