@@ -1,0 +1,11 @@
+#!/bin/bash
+# A/B of two builds on the workloads with flats: the tiled Example (real terrain) and the conditioned rough 16384^2 chain
+#   tools/flat_moves_ab.sh <outdir> <lib> [<lib> ...]
+OUT=$1; shift
+mkdir -p $OUT
+for lib in "$@"; do
+  v=$(basename $lib .so)
+  cp $lib descriptools_amd/libdescriptools_hip.so || exit 1
+  python3 tools/real_terrain_run.py 8 4096 > $OUT/$v.rt.txt 2>&1 || exit 1
+  python3 tools/condition_bench.py 16384 > $OUT/$v.cond.txt 2>&1 || exit 1
+done
