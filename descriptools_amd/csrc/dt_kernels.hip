@@ -809,6 +809,7 @@ __device__ __forceinline__ void ds_win_body(const float *__restrict__ dem,
   // and its barrier (which so overlap the loads), then decode
   float4 vv[4];
   uint32_t cc[4];
+  int nod_here = 0;  // this thread staged a nodata height
   if (interior) {
 #pragma unroll
     for (int u = 0; u < 4; u++) {
@@ -846,6 +847,7 @@ __device__ __forceinline__ void ds_win_body(const float *__restrict__ dem,
         uint32_t m2 = (uint32_t)s_lut[(cc[u] >> 16) & 0xFFu] | rowring;
         uint32_t m3 = (uint32_t)s_lut[cc[u] >> 24] | rowring | (c4 == DW_WIN - 4 ? (MW_RING | MW_STOP) : 0u);
         float4 v = vv[u];
+        nod_here |= (v.x == DT_NODATA || v.y == DT_NODATA || v.z == DT_NODATA || v.w == DT_NODATA) ? 1 : 0;
         v.x = v.x == DT_NODATA ? ninf : v.x;
         v.y = v.y == DT_NODATA ? ninf : v.y;
         v.z = v.z == DT_NODATA ? ninf : v.z;
@@ -896,6 +898,7 @@ __device__ __forceinline__ void ds_win_body(const float *__restrict__ dem,
         if (RANKED && rd[k] && !(gy >= yca && gy < ycb && gx + k >= xca && gx + k < xcb)) mw = MW_RING | MW_STOP | MW_BIAS;
         mwv[k] = mw;
       }
+      nod_here |= (v.x == DT_NODATA || v.y == DT_NODATA || v.z == DT_NODATA || v.w == DT_NODATA) ? 1 : 0;
       v.x = v.x == DT_NODATA ? ninf : v.x;
       v.y = v.y == DT_NODATA ? ninf : v.y;
       v.z = v.z == DT_NODATA ? ninf : v.z;
@@ -903,6 +906,28 @@ __device__ __forceinline__ void ds_win_body(const float *__restrict__ dem,
       *reinterpret_cast<float4 *>(&s_z[r * DW_LD + c4]) = v;
       *reinterpret_cast<uint2 *>(&s_w[r * DW_LD + c4]) =
           make_uint2(mwv[0] | (mwv[1] << 16), mwv[2] | (mwv[3] << 16));
+    }
+  }
+  // NODATA AHEAD (round 4).  The walk does not look before it moves: a lane that steps onto nodata (staged as -inf)
+  // sees an infinite drop, and its cell was then walked again, move by move on global memory, to find where the
+  // reference had stopped -- one move earlier (downslope.py:231-281).  Rare on the synthetic terrain; but the D8 codes
+  // of a conditioned DEM drain every flat next to nodata INTO it, and a GIS raster its whole basin: 0.33 % of the
+  // cells of the conditioned rough raster, one wave in five waiting ~10 us for such a walk.  A window that holds
+  // nodata at all (block-uniform) now marks the cells whose successor is nodata as "the move leaves the raster" --
+  // the same outcome in the reference: the walk so far, failed -- and the walk stops there by itself.  (A height of
+  // -inf is staged like nodata: the candidate's successor is looked up in the raster before it is marked.)  Only in the
+  // kernels with the queue -- what real and conditioned terrain run: the pass costs the synthetic benchmark raster,
+  // whose nodata blobs sit on hill tops where no walk ends, 0.09 ms of the plain kernel's 2.04 and gains it nothing.
+  if (QUEUE && __syncthreads_or(nod_here)) {
+    for (int i = threadIdx.x; i < DW_WIN * DW_WIN; i += 1024) {
+      const int r = i / DW_WIN, c = i - r * DW_WIN;
+      const int p = r * DW_LD + c;
+      const uint32_t mwc = s_w[p];
+      if (mwc & MW_STOP) continue;
+      const int sp = p + (((int)(mwc & MW_OFF) - MW_BIAS) >> 1);  // (the offset field counts bytes of move words)
+      if (s_z[sp] != ninf) continue;
+      const int sr = sp / DW_LD, sc = sp - sr * DW_LD;
+      if (dem[(long long)(wy0 + sr) * w.ld + wx0 + sc] == DT_NODATA) s_w[p] = (uint16_t)(mwc | MW_EDGE | MW_STOP);
     }
   }
   __syncthreads();

@@ -151,6 +151,41 @@ def test_walks_that_end_with_a_drop_of_exactly_zero(env):
     assert (oracle.downslope(dem, fdr, 12.5, 5.0)[:200] == 0).mean() > 0.9
 
 
+def test_walks_that_end_at_nodata_or_at_an_infinite_height(env):
+    """the walk never moves onto nodata: the reference stops one move earlier and keeps the walk so far
+    (downslope.py:231-281).  The kernels with the queue mark the cells whose successor is nodata while they stage a
+    window (round 4: no second walk on global memory); a height of -inf is staged like nodata but is NOT nodata -- the
+    walk steps onto it and ends with an infinite drop.  Streams that drain into nodata blobs after 1 .. 60 moves, a
+    nodata start cell's neighbours, -inf pits; host tier (queue + tables) and the plain device entry."""
+    oracle, downslope, L = env
+    from descriptools_amd import _lib
+    from descriptools_amd.device import Context
+    rng = np.random.default_rng(21)
+    H, W = 500, 900
+    yy, xx = np.mgrid[0:H, 0:W]
+    dem = (300.0 - 0.05 * xx + 0.01 * yy + rng.random((H, W)) * 0.02).astype(np.float32)   # gentle: walks of ~100 moves
+    fdr = np.full((H, W), 1, np.uint8)
+    fdr[rng.random((H, W)) < 0.2] = 2                 # some diagonal moves
+    for _ in range(150):                              # nodata blobs the streams run into
+        cy, cx, r = rng.integers(0, H), rng.integers(0, W), rng.integers(1, 6)
+        dem[max(cy - r, 0):cy + r, max(cx - r, 0):cx + r] = -100
+    for _ in range(40):                               # and heights of -inf (not nodata)
+        dem[rng.integers(0, H), rng.integers(0, W)] = -np.inf
+    for dz in (5.0, 1.0):
+        want = oracle.downslope(dem, fdr, 12.5, dz)
+        with np.errstate(invalid="ignore"):
+            got = downslope.downsloper(dem, fdr, 12.5, dz)
+        _same(got, want)
+    ctx = Context()
+    d, f, a = ctx.to_device(dem), ctx.to_device(fdr), ctx.empty((H, W), np.float32)
+    _lib.check(L.dt_dev_downslope(ctx.h, d.ptr, f.ptr, H, W, 12.5, 5.0, 0, a.ptr))
+    ctx.sync()
+    _same(a.to_host(), oracle.downslope(dem, fdr, 12.5, 5.0))
+    for x in (d, f, a):
+        x.free()
+    ctx.close()
+
+
 def test_chain_with_long_walks_on_the_example():
     """Chain(long_walks=True) on the bundled Example (its GIS D8 raster has the flats): same downslope raster"""
     import os
