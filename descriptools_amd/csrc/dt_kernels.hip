@@ -532,6 +532,9 @@ __device__ __forceinline__ void ds_mem_cell(const DtWin &w, uint32_t e, int &y, 
 // stands after the skip RELATIVE to its start (a skip is at most 64 moves: row and column offsets + 64 in bits 0-7 and
 // 8-15), moves in bits 16-22, the diagonal ones in bits 23-29, bit 30 when the walk cannot go on from there.  (Round 3
 // began with 16-byte entries holding the cell index: every kernel of this path is bound by the bytes of its table.)
+#ifndef DS_Q_CAP
+#define DS_Q_CAP 31 /* with the queue: a walk still running after DS_Q_CAP + 1 moves in the window is handed over */
+#endif
 #define DS_LIFT_STOP (1u << 30)
 #define DS_LIFT_BIAS2 (64u | (64u << 8))
 __device__ __forceinline__ uint32_t ds_lift_pack(int dy, int dx, uint32_t len, uint32_t nd) {
@@ -995,7 +998,7 @@ __device__ __forceinline__ void ds_win_body(const float *__restrict__ dem,
             [k19] "s"(1u << 19), [woff] "n"(DW_LD * DW_WIN * 4),
             // with the queue a walk still running after 32 moves is a long one: hand it over at once (the lanes that
             // are done wait for the wave's longest walk)
-            [cap] "n"(QUEUE ? 31 : 255)
+            [cap] "n"(QUEUE ? DS_Q_CAP : 255)
           : "vcc", "scc", "memory");
     }
     uint32_t loop = acc >> 19;  // moves made
