@@ -761,15 +761,15 @@ __device__ __forceinline__ int hy_flat_sweep_m(const uint8_t *__restrict__ s_m, 
     (void)B_D0;
     (void)B_D1;
     (void)B_D2;
-    // coded cells (0) and cells next to one (1) are final; nodata and the cells beyond the raster have no neighbour of
-    // "their height" (all bits set)
-    const bool lower = dcur > 1u && m != H_INF_DIST;
+    // No test for "coded cells (0) and cells next to one (1) are final" nor for "no neighbour of its height" (nodata,
+    // cells beyond the raster: all bits set): nd = m + 1 is at least 1, so it is never below a distance of 0 or 1, and
+    // with m = H_INF_DIST it is 2^31, above every distance -- `nd < fresh` says it all (four instructions of 36).
     const uint32_t nd = m + 1u;
-    if (lower && nd < fresh) {
+    if (nd < fresh) {
       s_d[p] = nd;
       ch |= (on_side || step == 0 || step == HT - 1) ? 3 : 1;  // bit 1: a cell of the tile's outer ring
     }
-    du = (lower && nd < dcur) ? nd : dcur;  // what this lane leaves behind
+    du = min(nd, dcur);  // what this lane leaves behind
     dhl = dlf;
     dhr = drt;
     dcur = d1;
