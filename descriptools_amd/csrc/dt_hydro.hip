@@ -79,15 +79,15 @@ __device__ __forceinline__ int hy_fill_sweep(float *__restrict__ s_w, const floa
   float hl = s_w[p - SA - SC], hr = s_w[p - SA + SC];  // its cells beside lanes 0 / 63
   float cur = s_w[p], lf = s_w[p - SC], rt = s_w[p + SC];
   const bool on_side = lane == 0 || lane == HT - 1;
+  auto *s_wv = (__attribute__((address_space(3))) const float *)s_w;
+  asm volatile("" : "+v"(s_wv));
   int ch = 0;
 #pragma unroll 4
   for (int step = 0; step < HT; step++) {
-    // (through an index the compiler cannot see through: another wave may have lowered the cell since this lane
-    // fetched it as the line ahead, and with compile-time strides the compiler would reuse that value -- a store
-    // could then RAISE the cell)
-    int pf = p;
-    asm volatile("" : "+v"(pf));
-    const float fresh = s_w[pf];
+    // (through a copy of the base address the compiler cannot see through, made once per sweep: another wave may have
+    // lowered the cell since this lane fetched it as the line ahead, and with compile-time strides the compiler would
+    // reuse that value -- a store could then RAISE the cell)
+    const float fresh = s_wv[p];
     const float d0 = s_w[p + SA - SC], d1 = s_w[p + SA], d2 = s_w[p + SA + SC];
     const float zc = s_z[zi];
     const float upm = hy_from_prev_lane(hl, up), upp = hy_from_next_lane(hr, up);
@@ -739,15 +739,17 @@ __device__ __forceinline__ int hy_flat_sweep_m(const uint8_t *__restrict__ s_m, 
   };
   int p = BY_ROWS ? (K0 + 1) * HLS + lane + 1 : (lane + 1) * HLS + K0 + 1;
   int mi = BY_ROWS ? K0 * HMS + lane : lane * HMS + K0;
+  auto *s_dv = (__attribute__((address_space(3))) const uint32_t *)s_d;
+  asm volatile("" : "+v"(s_dv));
   uint32_t du = s_d[p - SA], dhl = s_d[p - SA - SC], dhr = s_d[p - SA + SC];
   uint32_t dcur = s_d[p], dlf = s_d[p - SC], drt = s_d[p + SC];
   const bool on_side = lane == 0 || lane == HT - 1;
   int ch = 0;
 #pragma unroll 4
   for (int step = 0; step < HT; step++) {
-    int pf = p;  // (see hy_fill_sweep: the fresh read must not be merged with the value fetched a step earlier)
-    asm volatile("" : "+v"(pf));
-    const uint32_t fresh = s_d[pf];
+    // (see hy_fill_sweep: the fresh read must not be merged with the value fetched a step earlier -- it goes through
+    // a copy of the base address the compiler cannot see through, made once per sweep)
+    const uint32_t fresh = s_dv[p];
     const uint32_t d0 = s_d[p + SA - SC], d1 = s_d[p + SA], d2 = s_d[p + SA + SC];
     const uint32_t mk = s_m[mi];
     const uint32_t dum = dpp_prev(dhl, du), dup = dpp_next(dhr, du);
