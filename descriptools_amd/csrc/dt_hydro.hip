@@ -914,36 +914,53 @@ __global__ __launch_bounds__(256) void k_flat_assign_m(const uint8_t *__restrict
   if (has_flat && has_flat[blockIdx.x] == 0) return;
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
   const int y0 = ty * HT, x0 = tx * HT;
-  uint8_t mk[H_CPT];  // (the bytes of the thread's cells, in flight with the staging's loads)
+  // four cells in a row per thread and group (16 groups per tile row): their bytes as one 32-bit load where the rows
+  // allow it, in flight with the staging's loads
+  const bool whole = y0 + HT <= w.H && x0 + HT <= w.W;
+  const bool word_ok = whole && (w.ld & 3) == 0 && ((uintptr_t)nsame & 3) == 0;
+  uint32_t mk4[4];
 #pragma unroll
-  for (int j = 0; j < H_CPT; j++) {
-    const int c = threadIdx.x + 256 * j;
-    const int y = y0 + c / HT, x = x0 + c % HT;
-    mk[j] = (y < w.H && x < w.W) ? nsame[(long long)y * w.ld + x] : (uint8_t)0xFF;
+  for (int k = 0; k < 4; k++) {
+    const int i = (int)threadIdx.x + 256 * k;
+    const int r = i >> 4, c4 = (i & 15) * 4;
+    const uint8_t *src = nsame + (long long)(y0 + r) * w.ld + x0 + c4;
+    if (word_ok) {
+      mk4[k] = *reinterpret_cast<const uint32_t *>(src);
+    } else {
+      mk4[k] = 0xFFFFFFFFu;
+      if (y0 + r < w.H) {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          if (x0 + c4 + q < w.W) mk4[k] = (mk4[k] & ~(0xFFu << (8 * q))) | ((uint32_t)src[q] << (8 * q));
+      }
+    }
   }
   hy_stage<uint32_t>(s_d, dist, w, y0, x0, H_INF_DIST);
   __syncthreads();
   int bad = 0;
 #pragma unroll
-  for (int j = 0; j < H_CPT; j++) {
-    const int c = threadIdx.x + 256 * j;
-    const int ly = c / HT, lx = c % HT;
-    const int y = y0 + ly, x = x0 + lx;
-    if (y >= w.H || x >= w.W) continue;
-    const int p = (ly + 1) * HLS + lx + 1;
-    const uint32_t d = s_d[p];
-    if (d == 0u) continue;
-    uint32_t code = 0u;
-    if (d != H_INF_DIST) {
-      const uint32_t want = d - 1u, m = mk[j];
+  for (int k = 0; k < 4; k++) {
+    const int i = (int)threadIdx.x + 256 * k;
+    const int r = i >> 4, c4 = (i & 15) * 4;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int y = y0 + r, x = x0 + c4 + q;
+      if (y >= w.H || x >= w.W) continue;
+      const int p = (r + 1) * HLS + c4 + q + 1;
+      const uint32_t d = s_d[p];
+      if (d == 0u) continue;
+      uint32_t code = 0u;
+      if (d != H_INF_DIST) {
+        const uint32_t want = d - 1u, m = (mk4[k] >> (8 * q)) & 0xFFu;
 #define HY_A(bit, off, c_) \
   if (!code && !((m >> (bit)) & 1u) && s_d[p + (off)] == want) code = (c_);
-      HY_A(1, -HLS, 64u) HY_A(3, -1, 16u) HY_A(4, 1, 1u) HY_A(6, HLS, 4u)
-      HY_A(0, -HLS - 1, 32u) HY_A(2, -HLS + 1, 128u) HY_A(5, HLS - 1, 8u) HY_A(7, HLS + 1, 2u)
+        HY_A(1, -HLS, 64u) HY_A(3, -1, 16u) HY_A(4, 1, 1u) HY_A(6, HLS, 4u)
+        HY_A(0, -HLS - 1, 32u) HY_A(2, -HLS + 1, 128u) HY_A(5, HLS - 1, 8u) HY_A(7, HLS + 1, 2u)
 #undef HY_A
+      }
+      if (!code) bad++;
+      fdr[(long long)y * w.ld + x] = (uint8_t)code;
     }
-    if (!code) bad++;
-    fdr[(long long)y * w.ld + x] = (uint8_t)code;
   }
   for (int o = 32; o; o >>= 1) bad += __shfl_xor(bad, o);
   if ((threadIdx.x & 63) == 0 && bad) atomicAdd(unresolved, bad);
